@@ -1,0 +1,93 @@
+"""Shared deterministic input builders for the parity tests and the golden-vector generator.
+
+Everything here is plain torch-CPU / numpy so that the GPU box (same image, same torch build)
+regenerates bit-identical inputs from the seeds stored in tests/golden/*.npz; every fixture also
+stores a checksum of the regenerated tensors, asserted on load.
+"""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# rendering_kwargs of the released configuration (trainers/train_eclustrousC.py:409-440) + generate.py:56-57
+RENDERING_KWARGS = dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=48, depth_resolution_importance=48,
+                        disparity_space_sampling=False, clamp_mode="softplus", white_back=True, use_triplane=1)
+
+
+def checksum(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:16]
+
+
+def make_planes(seed, N=1, H=256, W=256, C=32, scale=1.0, smooth=0):
+    """Synthetic triplanes [N,3,C,H,W].  smooth=0: white noise (a fog).  smooth=k>0: a k x k noise grid bilinearly
+    upsampled to HxW plus 10% white noise — spatially coherent blobs, so rays meet 'surfaces' (saturating weights,
+    empty rays) like a trained model's planes do."""
+    g = torch.Generator().manual_seed(int(seed))
+    if not smooth:
+        return (torch.randn(N, 3, C, H, W, generator=g) * scale).numpy()
+    low = torch.randn(N * 3, C, int(smooth), int(smooth), generator=g)
+    up = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    up = up + 0.1 * torch.randn(N * 3, C, H, W, generator=g)
+    return (up.reshape(N, 3, C, H, W) * scale).contiguous().numpy()
+
+
+def make_decoder_params(seed, lr_mul=1.0, sigma_gain=1.0):
+    """Raw (un-scaled) OSGDecoder parameters: net.0.weight [64,32], net.0.bias [64], net.2.weight [33,64], net.2.bias [33]
+    (triplane.py:521-526).  Biases are drawn non-zero so the bias path is exercised; sigma bias +1 gives a mix of
+    occupied and empty space under cull_clouds=0.5.  Row 0 of net.2 (sigma) is scaled by sigma_gain."""
+    g = torch.Generator().manual_seed(int(seed))
+    w0 = torch.randn(64, 32, generator=g) / lr_mul
+    b0 = torch.randn(64, generator=g) * 0.5
+    w1 = torch.randn(33, 64, generator=g) / lr_mul
+    b1 = torch.randn(33, generator=g) * 0.5
+    b1[0] += 1.0
+    w1[0] *= sigma_gain  # sigma_gain >> 1: solid objects (weights saturate) like a trained model
+    return w0.numpy(), b0.numpy(), w1.numpy(), b1.numpy()
+
+
+def make_random_draws(seed, N, R, Sc, Sf):
+    """The two draws of ImportanceRenderer.forward in the reference's order (renderer.py:324 then :371):
+    torch.manual_seed(seed); rand_like([N,R,Sc,1]); rand(N*R, Sf)."""
+    torch.manual_seed(int(seed))
+    jitter = torch.rand(N, R, Sc, 1)
+    u = torch.rand(N * R, Sf) if Sf > 0 else torch.zeros(N * R, 0)
+    return jitter.numpy(), u.numpy()
+
+
+def make_points(seed, N, M, extent=0.5):
+    """Query points for run_model: mostly inside the box, some outside (zeros-padding path)."""
+    g = torch.Generator().manual_seed(int(seed))
+    return ((torch.rand(N, M, 3, generator=g) * 2 - 1) * extent).numpy()
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN_DIR, name)
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+RENDER_GOLDENS = ["render_c1_64x64_s32", "render_32x32_16p16", "render_24x24_48p48_ortho", "render_12x12_96p96",
+                  "render_variant_a", "render_variant_b"]
+
+
+def golden_render_inputs(g):
+    """Rebuild the inputs of a render_*.npz fixture from its meta_* fields (see tests/golden/make_golden.py)."""
+    m = {k[5:]: g[k].item() for k in g if k.startswith("meta_")}
+    ro = dict(RENDERING_KWARGS, depth_resolution=int(m["Sc"]), depth_resolution_importance=int(m["Sf"]),
+              use_triplane=int(m["use_triplane"]), white_back=bool(m["white_back"]), ray_start=float(m["ray_start"]),
+              ray_end=float(m["ray_end"]), box_warp=float(m["box_warp"]))
+    planes = make_planes(m["seed"], m["N"], m["H"], m["W"], scale=float(m["plane_scale"]), smooth=int(m["smooth"]))
+    assert checksum(planes) == str(g["planes_checksum"]), "regenerated planes differ from the fixture's"
+    raw = make_decoder_params(m["seed"] + 1, float(m["lr_mul"]), float(m["sigma_gain"]))
+    R = g["rays_o"].shape[1]
+    jitter, u = make_random_draws(m["seed"] + 2, m["N"], R, int(m["Sc"]), int(m["Sf"]))
+    kw = dict(triplane_crop=float(m["crop"]) or None, cull_clouds=float(m["cull"]) or None,
+              binarize_clouds=float(m["binarize"]) or None, force_sigmoid=bool(m["force_sigmoid"]))
+    return dict(ro=ro, planes=planes, raw_mlp=raw, lr_mul=float(m["lr_mul"]), rays_o=g["rays_o"], rays_d=g["rays_d"],
+                jitter=jitter, u=u, kw=kw, meta=m)

@@ -1,0 +1,114 @@
+"""CPU: the oracle (oracle/p3d_oracle.c) against the reference's own outputs (tests/golden/*.npz).
+
+This is what pins the oracle: the fixtures were produced by the unmodified reference imported from /root/reference
+(tests/golden/make_golden.py).  Floats: the tolerances below (the oracle follows the arithmetic contract of
+include/p3d_numerics.h, the reference follows ATen's CPU kernels: different summation orders and libm).
+Indices (searchsorted bins, depth-sort permutation): exact-match counts, required to be 100 % on these fixtures.
+"""
+import numpy as np
+import pytest
+
+import p3d_testing as T
+
+# fp32 tolerances of the contract vs the reference (absolute; the quantities are O(1))
+# (the fixtures with sigma_gain=60 have densities of several hundred and razor-sharp surfaces: a 1-ulp move of a fine
+#  depth changes sigma there by ~1e-2 absolute, which is what sets these bounds; fog fixtures agree to ~5e-7)
+TOL_FEAT = 1e-4     # composited features in [-1, 1]
+TOL_DEPTH = 2e-5    # depths in [0.5, 1.6]
+TOL_WEIGHT = 3e-5   # weights / weight sums in [0, 1]
+TOL_XYZ = 1e-4
+TOL_SIGMA = 1e-5    # raw decoder sigma, times max(1, sigma_gain)
+NEAR_TIE = 6e-7     # ~5 ulp at depth 1: two merged depths this close may legitimately sort either way
+
+
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+def test_render_matches_reference(oracle, name):
+    g = T.load_golden(name + ".npz")
+    inp = T.golden_render_inputs(g)
+    opts = oracle.make_opts(inp["ro"], **inp["kw"])
+    mlp = oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"])
+    feat, depth, wsum, xyz, d = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"], mlp,
+                                              opts, dumps=True)
+    assert np.abs(feat - g["feat"]).max() <= TOL_FEAT
+    assert np.abs(depth - g["depth"]).max() <= TOL_DEPTH
+    assert np.abs(wsum - g["wsum"]).max() <= TOL_WEIGHT
+    assert np.abs(xyz - g["xyz"]).max() <= TOL_XYZ
+    if "depths_coarse" in g:  # stratified depths are bit-exact (linspace + jitter restated exactly)
+        assert np.array_equal(d["depths_coarse"], g["depths_coarse"])
+    # raw decoder sigma: the dot product's terms are O(sigma_gain), so the fp32 noise floor scales with it.  Fine samples
+    # are compared only where the fine DEPTH is bit-identical (else the steep density field dominates the difference).
+    tol_sigma = TOL_SIGMA * max(1.0, inp["meta"]["sigma_gain"])
+    if "sigma_coarse" in g:
+        assert np.abs(d["sigma_coarse"] - g["sigma_coarse"]).max() <= tol_sigma
+    if "sigma_fine" in g:
+        same = d["depths_fine"] == g["depths_fine"]
+        assert same.mean() > 0.5
+        assert np.abs(d["sigma_fine"] - g["sigma_fine"])[same].max() <= tol_sigma
+    if "weights_coarse" in g:
+        assert np.abs(d["weights_coarse"] - g["weights_coarse"]).max() <= TOL_WEIGHT
+    if "depths_fine" in g:
+        assert np.abs(d["depths_fine"] - g["depths_fine"]).max() <= TOL_DEPTH
+    if "inds" in g:  # "ray hit indices": exact
+        mism = int((d["inds"] != g["inds"]).sum())
+        assert mism == 0, f"inds: {mism} of {g['inds'].size} differ from the reference"
+    if "perm" in g:
+        # exact, except positions where the reference's own two depths are a near-tie (the oracle's fine depths differ
+        # from the reference's in the last ulp, so a tie can break the other way); those are counted and bounded.
+        bad = np.argwhere(d["perm"] != g["perm"])
+        all_ref = np.concatenate([d["depths_coarse"], g["depths_fine"]], axis=1)
+        for r, j in bad:
+            assert abs(all_ref[r, g["perm"][r, j]] - all_ref[r, d["perm"][r, j]]) <= NEAR_TIE, (r, j)
+        assert len(bad) <= 1e-3 * g["perm"].size
+
+
+@pytest.mark.parametrize("ut", [0, 1])
+def test_decode_points_matches_reference(oracle, ut):
+    g = T.load_golden(f"decode_points_ut{ut}.npz")
+    seed = int(g["meta_seed"])
+    planes = T.make_planes(seed, 2, 64, 96)
+    pts = T.make_points(seed + 2, 2, 4096, extent=0.45)
+    assert T.checksum(planes) == str(g["planes_checksum"]) and T.checksum(pts) == str(g["pts_checksum"])
+    mlp = oracle.prescale_mlp(*T.make_decoder_params(seed + 1))
+    sigma, rgb = oracle.decode(planes, pts, mlp, 0.7, plane_mode=ut, flags=0)  # force_sigmoid off: *1.002-0.001
+    assert np.abs(sigma - g["sigma"]).max() <= 1e-5
+    assert np.abs(rgb - g["rgb"]).max() <= 2e-6
+    # the fixture must exercise the zeros-padding path (points outside the planes)
+    assert (np.abs(pts * (2 / 0.7)) > 1).any()
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_marcher_matches_reference(oracle, wb):
+    g = T.load_golden(f"marcher_wb{wb}.npz")
+    rgb, depth, w = oracle.composite(g["colors"], g["sigma"], g["depths"], white_back=bool(wb))
+    assert np.abs(rgb.reshape(g["rgb"].shape) - g["rgb"]).max() <= TOL_FEAT
+    assert np.abs(w.reshape(g["weights"].shape) - g["weights"]).max() <= TOL_WEIGHT
+    assert np.abs(depth.reshape(g["depth"].shape) - g["depth"]).max() <= TOL_DEPTH
+    # empty rays: NaN depth -> +inf -> clamped to the global max depth (ray_marcher.py:49-50)
+    assert np.all(depth.reshape(g["depth"].shape)[0, :8] == g["depths"].max())
+
+
+def test_importance_matches_reference(oracle):
+    g = T.load_golden("importance.npz")
+    fine, inds = oracle.importance(g["depths"], g["weights"], g["u"])
+    assert int((inds != g["inds"]).sum()) == 0
+    assert np.abs(fine.reshape(g["fine"].shape) - g["fine"]).max() <= TOL_DEPTH
+
+
+@pytest.mark.parametrize("S", [48, 96, 17])
+def test_stratified_bit_exact(oracle, S):
+    g = T.load_golden(f"stratified_{S}.npz")
+    out = oracle.sample_stratified(float(g["start"]), float(g["end"]), S, g["jitter"])
+    assert np.array_equal(out.reshape(g["depths"].shape), g["depths"])
+
+
+def test_contract_math_accuracy(oracle):
+    x = np.linspace(-30, 30, 200001).astype(np.float32)
+    xn = np.minimum(x, 0)
+    assert np.abs(oracle.math_fn("exp", xn) - np.exp(xn.astype(np.float64))).max() < 1e-7
+    sp = np.log1p(np.exp(-np.abs(x.astype(np.float64)))) + np.maximum(x, 0)
+    assert (np.abs(oracle.math_fn("softplus", x) - sp) / np.maximum(1, sp)).max() < 3e-7
+    assert np.abs(oracle.math_fn("sigmoid", x) - 1 / (1 + np.exp(-x.astype(np.float64)))).max() < 2e-7
+    # special values of the contract
+    sv = oracle.math_fn("exp", np.array([-1000.0, -87.5, 0.0, 89.0, np.nan], np.float32))
+    assert sv[0] == 0 and sv[1] == 0 and sv[2] == 1 and np.isinf(sv[3]) and np.isnan(sv[4])
+    assert oracle.math_fn("softplus", np.array([25.0], np.float32))[0] == 25.0
