@@ -1,0 +1,123 @@
+/* panic3d_hip.h — C ABI of libpanic3d_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for PAniC-3D's triplane volumetric-rendering hot path.  The reference has NO native code for
+ * this path (it is a composition of stock torch ops); its own FFI convention for native operators is
+ * the pybind11 plugin surface of torch_utils/custom_ops.py:61 (`get_plugin`) as used by torch_utils/ops/bias_act.py:40-50
+ * and bias_act.cpp:36-101: stateless functions, inputs validated, launched on the caller's current stream, nothing
+ * allocated behind the caller's back.  This header keeps that convention in plain C:
+ *
+ *   - every entry point is `extern "C"`, takes raw DEVICE pointers + sizes + a hipStream_t (passed as void*), and
+ *     returns 0 on success, a negative P3D_E_* code for an argument error, or a positive hipError_t;
+ *   - no allocation, no global mutable state, re-entrant; the caller owns every buffer including the workspace
+ *     (size from p3d_render_workspace_bytes);
+ *   - all arithmetic follows include/p3d_numerics.h (the arithmetic contract), so results are reproducible bit-for-bit.
+ *
+ * Each function cites the reference code it replaces (paths relative to /root/reference/_train/eg3dc/src/).
+ * The Python binding a maintainer adds is in INTEGRATION.md; the in-tree one is panic3d-anime-reconstruction_amd/_lib.py.
+ */
+#ifndef PANIC3D_HIP_H
+#define PANIC3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_OK 0
+#define P3D_E_ARG (-1)       /* null pointer / non-positive size */
+#define P3D_E_RANGE (-2)     /* Sc/Sf/H/W/C outside what the kernels support */
+#define P3D_E_WORKSPACE (-3) /* workspace too small */
+
+/* flag bits of p3d_opts.flags */
+#define P3D_FLAG_CROP 1          /* triplane_crop given          (renderer.py:187-188) */
+#define P3D_FLAG_CULL 2          /* cull_clouds given            (renderer.py:194-196) */
+#define P3D_FLAG_BINARIZE 4      /* binarize_clouds given        (renderer.py:190-193) */
+#define P3D_FLAG_FORCE_SIGMOID 8 /* OSGDecoder.force_sigmoid     (training/triplane.py:539-542) */
+#define P3D_FLAG_WHITE_BACK 16   /* rendering_options.white_back (ray_marcher.py:52-53) */
+
+#define P3D_C 32        /* channels per plane (triplane_width, training/triplane.py:41) */
+#define P3D_HID 64      /* OSGDecoder hidden_dim (training/triplane.py:519) */
+#define P3D_MAX_S 192   /* max depth_resolution / depth_resolution_importance */
+
+/* rendering_options + forward() arguments of ImportanceRenderer (renderer.py:162-174), already converted to binary32
+ * by the host exactly as include/p3d_numerics.h states. */
+typedef struct {
+    float coord_scale;  /* (float)(2.0 / box_warp)                              renderer.py:77  */
+    float ray_start;    /* rendering_options['ray_start']                       renderer.py:177 */
+    float ray_end;      /* rendering_options['ray_end']                                          */
+    float depth_delta;  /* (float)((ray_end - ray_start) / (Sc - 1)), in double renderer.py:323 */
+    float crop_limit;   /* (float)(box_warp / 2 - triplane_crop)                renderer.py:139-142 */
+    float cull_thresh;  /* cull_clouds or binarize_clouds value                 renderer.py:190-196 */
+    int32_t Sc;         /* depth_resolution                                                      */
+    int32_t Sf;         /* depth_resolution_importance (0: single pass, renderer.py:254-259)    */
+    int32_t plane_mode; /* use_triplane: plane 2 = (y,z) if 1 else (z,x)        renderer.py:41-49 */
+    int32_t flags;      /* P3D_FLAG_*                                                            */
+} p3d_opts;
+
+/* Optional per-stage dumps of p3d_render_f32 (parity tests).  Any pointer may be NULL. */
+typedef struct {
+    float* depths_coarse;   /* [N*R][Sc]      sample_stratified output                 */
+    float* sigma_coarse;    /* [N*R][Sc]      after crop/cull masks                    */
+    float* weights_coarse;  /* [N*R][Sc-1]    coarse ray-marcher weights               */
+    float* depths_fine;     /* [N*R][Sf]      sample_importance output (draw order)    */
+    int32_t* inds;          /* [N*R][Sf]      searchsorted(cdf, u, right=True)         */
+    float* depths_sorted;   /* [N*R][Sc+Sf]   unify_samples depths                     */
+    float* sigma_sorted;    /* [N*R][Sc+Sf]   unify_samples densities (after masks)    */
+    float* depth_unclamped; /* [N*R]          composite depth before the global clamp  */
+    float* tminmax;         /* [2]            global min / max of all depths           */
+} p3d_dumps;
+
+/* Layout change [n3][C][H][W] -> [n3][H][W][C] (n3 = N*3 planes).  The reference keeps planes NCHW
+ * (training/triplane.py:200-206) and lets grid_sample gather 32 lines per tap (renderer.py:80); every kernel below
+ * wants one 128-byte line per tap. */
+int p3d_planes_to_nhwc_f32(const float* planes_nchw, int n3, int C, int H, int W, float* planes_nhwc, void* stream);
+
+/* ImportanceRenderer.run_model (renderer.py:266-280) = sample_from_planes (:68-81) + OSGDecoder.forward
+ * (training/triplane.py:528-544) + crop/cull masks (renderer.py:138-153,187-198) on a point cloud.
+ * planes_nhwc [N][3][H][W][32]; coords [N][M][3]; w0 [64][32], b0 [64], w1 [33][64], b1 [33] pre-scaled by the host
+ * (networks_stylegan2.py:121-127).  out_sigma [N][M]; out_rgb [N][M][32] or NULL (density only: get_eg3d_volume,
+ * _util/eg3d_metrics3d.py:140-150).  Uses coord_scale, plane_mode, flags, crop_limit, cull_thresh of opts. */
+int p3d_triplane_decode_f32(const float* planes_nhwc, int N, int H, int W, const float* coords, int64_t M,
+                            const float* w0, const float* b0, const float* w1, const float* b1, const p3d_opts* opts,
+                            float* out_sigma, float* out_rgb, void* stream);
+
+/* ImportanceRenderer.forward (renderer.py:162-264), fused: stratified depths, coarse density pass, ray-marcher weights,
+ * importance resampling, depth merge, final decode + compositing.  rays_o/rays_d [N][R][3]; jitter [N][R][Sc] (the
+ * torch.rand_like draw of renderer.py:324); u [N*R][Sf] (the torch.rand draw of :371; may be NULL when Sf == 0).
+ * ray_tile_w: image width in rays if the R rays are a row-major ray_tile_w x (R/ray_tile_w) image (enables 8x4 screen
+ * tiles per wavefront), 0 for an unstructured ray list.  Outputs feat [N][R][32], depth [N][R], wsum [N][R],
+ * xyz [N][R][3].  workspace: p3d_render_workspace_bytes bytes of device memory (holds the global depth min/max). */
+size_t p3d_render_workspace_bytes(int N, int64_t R, int Sc, int Sf);
+int p3d_render_f32(const float* planes_nhwc, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                   int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
+                   const float* w1, const float* b1, const p3d_opts* opts, float* out_feat, float* out_depth,
+                   float* out_wsum, float* out_xyz, void* workspace, size_t workspace_bytes, const p3d_dumps* dumps,
+                   void* stream);
+
+/* sample_stratified (renderer.py:303-326, numeric ray_start/ray_end branch).  jitter, out [NR][S]. */
+int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta, int S, const float* jitter, int64_t NR,
+                              float* out_depths, void* stream);
+
+/* MipRayMarcher2.run_forward (ray_marcher.py:25-57).  colors [NR][S][K], sigma [NR][S], depths [NR][S] ->
+ * out_rgb [NR][K], out_depth [NR], out_weights [NR][S-1] (may be NULL).  workspace: 8 bytes (global depth min/max). */
+int p3d_composite_f32(const float* colors, const float* sigma, const float* depths, int64_t NR, int S, int K,
+                      int white_back, float* out_rgb, float* out_depth, float* out_weights, void* workspace,
+                      void* stream);
+
+/* sample_importance + sample_pdf (renderer.py:328-387).  depths [NR][Sc], weights [NR][Sc-1], u [NR][Sf] ->
+ * out_depths [NR][Sf], out_inds [NR][Sf] (may be NULL). */
+int p3d_importance_f32(const float* depths, const float* weights, int64_t NR, int Sc, int Sf, const float* u,
+                       float* out_depths, int32_t* out_inds, void* stream);
+
+/* unify_samples' sort (renderer.py:289-301): stable ascending permutation of [coarse ++ fine] depths. perm [NR][Sc+Sf]. */
+int p3d_unify_perm_f32(const float* depths_coarse, const float* depths_fine, int64_t NR, int Sc, int Sf, int32_t* perm,
+                       void* stream);
+
+/* Library / build identification ("gfx950"). */
+const char* p3d_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+"""In-tree build of libpanic3d_hip.so (hipcc cross-compiles gfx950 without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libpanic3d_hip.so")
+SOURCES = ["p3d_kernels.hip"]
+HEADERS = ["p3d_math.hpp", "p3d_decode.hpp", os.path.join("..", "..", "include", "panic3d_hip.h"),
+           os.path.join("..", "..", "include", "p3d_numerics.h")]
+# -ffp-contract=off: the arithmetic contract (include/p3d_numerics.h) names every fma explicitly.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> libpanic3d_hip.so next to this file.  Returns the path."""
+    if not force and not needs_build():
+        return SO
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(SO + ".tmp", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

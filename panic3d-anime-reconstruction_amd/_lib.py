@@ -1,0 +1,65 @@
+"""ctypes binding of libpanic3d_hip.so — the C ABI of include/panic3d_hip.h.  No torch types cross this boundary.
+
+The library is the product: if it is missing this module raises (there is NO CPU / PyTorch fallback path).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libpanic3d_hip.so")
+
+P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK = 1, 2, 4, 8, 16
+P3D_MAX_S = 192
+
+
+class Opts(C.Structure):
+    """p3d_opts"""
+    _fields_ = [("coord_scale", C.c_float), ("ray_start", C.c_float), ("ray_end", C.c_float),
+                ("depth_delta", C.c_float), ("crop_limit", C.c_float), ("cull_thresh", C.c_float),
+                ("Sc", C.c_int32), ("Sf", C.c_int32), ("plane_mode", C.c_int32), ("flags", C.c_int32)]
+
+
+class Dumps(C.Structure):
+    """p3d_dumps"""
+    _fields_ = [("depths_coarse", C.c_void_p), ("sigma_coarse", C.c_void_p), ("weights_coarse", C.c_void_p),
+                ("depths_fine", C.c_void_p), ("inds", C.c_void_p), ("depths_sorted", C.c_void_p),
+                ("sigma_sorted", C.c_void_p), ("depth_unclamped", C.c_void_p), ("tminmax", C.c_void_p)]
+
+
+# symbol -> (restype, argtypes); every function include/panic3d_hip.h declares
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "p3d_planes_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "p3d_triplane_decode_f32": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P]),
+    "p3d_render_workspace_bytes": (_Z, [_I, _L, _I, _I]),
+    "p3d_render_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
+                            _Z, C.POINTER(Dumps), _P]),
+    "p3d_sample_stratified_f32": (_I, [_F, _F, _F, _I, _P, _L, _P, _P]),
+    "p3d_composite_f32": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "p3d_importance_f32": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "p3d_unify_perm_f32": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "p3d_build_info": (C.c_char_p, []),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "size out of supported range", -3: "workspace too small"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {kind} (code {rc})")

@@ -1,0 +1,684 @@
+// p3d_kernels.hip — HIP kernels + the C ABI (include/panic3d_hip.h) of libpanic3d_hip.so.  gfx950 only.
+//
+// Kernels:
+//   k_planes_to_nhwc   LDS-tiled transpose of the reference's NCHW planes to channels-last.
+//   k_decode_points    run_model on a point cloud (32 points per wavefront, see p3d_decode.hpp).
+//   k_render           ImportanceRenderer.forward fused per wavefront: 32 rays per wave (lane pair = ray x channel half);
+//                      coarse density pass -> weights -> importance resampling -> merge -> final decode + compositing,
+//                      all per-ray state in registers / LDS; no intermediate tensor ever reaches HBM.
+//   k_render_finish    the one cross-ray dependency: depth clamp to the global [min t, max t] (ray_marcher.py:49-50).
+//   k_stratified / k_composite / k_importance / k_unify_perm   operator-level stand-alone stages (one thread per ray).
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see panic3d-anime-reconstruction_amd/_build.py).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "p3d_decode.hpp"
+
+#define P3D_WAVES_PER_WG 4
+#define P3D_WG (64 * P3D_WAVES_PER_WG)
+
+// =====================================================================================================================
+// planes NCHW -> NHWC
+// =====================================================================================================================
+// grid: (ceil(H*W/64), n3); block 256.  Each block moves a [32 ch][64 px] tile through LDS.
+__global__ __launch_bounds__(256) void k_planes_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int HW) {
+    __shared__ float tile[32][65];
+    const int p0 = blockIdx.x * 64;
+    const size_t img = (size_t)blockIdx.y * 32 * HW;
+    {
+        int px = threadIdx.x & 63, c0 = threadIdx.x >> 6;  // 4 channels per pass
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int c = c0 + 4 * k;
+            tile[c][px] = (p0 + px < HW) ? src[img + (size_t)c * HW + p0 + px] : 0.0f;
+        }
+    }
+    __syncthreads();
+    {
+        int c = threadIdx.x & 31, q0 = threadIdx.x >> 5;  // 8 pixels per pass
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int px = q0 + 8 * k;
+            if (p0 + px < HW) dst[img + (size_t)(p0 + px) * 32 + c] = tile[c][px];
+        }
+    }
+}
+
+// =====================================================================================================================
+// run_model on a point cloud
+// =====================================================================================================================
+struct DecodeParams {
+    const float* planes;  // [N][3][H][W][32]
+    const float* coords;  // [N][M][3]
+    const float *w0, *b0, *w1, *b1;
+    float* out_sigma;  // [N][M]
+    float* out_rgb;    // [N][M][32] or null
+    long long M;
+    long long tiles_per_img;  // ceil(M/32)
+    long long ntiles;
+    int H, W;
+    P3dDecodeCfg cfg;
+};
+
+template <bool WANT_RGB>
+__global__ __launch_bounds__(P3D_WG) void k_decode_points(DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[P3D_LDS_MLP_FLOATS];
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    P3dPlaneGeom g;
+    g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
+    g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
+    // grid-stride over tiles of 32 points; a tile never straddles two images
+    for (long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave; tile < p.ntiles;
+         tile += (long long)gridDim.x * P3D_WAVES_PER_WG) {
+        long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
+        long long m = tl * 32 + j;
+        bool active = m < p.M;
+        long long mc = active ? m : p.M - 1;
+        unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
+        const float* base = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
+        const float* c = p.coords + ((size_t)n * p.M + mc) * 3;
+        float px = c[0], py = c[1], pz = c[2];
+        float sigma;
+        f32x16 rgb;
+        p3d_decode_wave<WANT_RGB>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
+        if (active) {
+            size_t o = (size_t)n * p.M + m;
+            if (h == 0) p.out_sigma[o] = sigma;
+            if (WANT_RGB) {
+                float* dst = p.out_rgb + o * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4*)(dst + 8 * q) = (f32x4){rgb[4 * q], rgb[4 * q + 1], rgb[4 * q + 2], rgb[4 * q + 3]};
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
+// fused ImportanceRenderer.forward
+// =====================================================================================================================
+struct RenderParams {
+    const float* planes;  // [N][3][H][W][32]
+    const float *rays_o, *rays_d;  // [N][R][3]
+    const float* jitter;  // [N][R][Sc]
+    const float* u;       // [N*R][Sf]
+    const float *w0, *b0, *w1, *b1;
+    float *out_feat, *out_depth, *out_wsum, *out_xyz;
+    uint32_t* gminmax;  // [2] order-mapped min / max of all depths
+    p3d_dumps dumps;
+    long long R;
+    long long tiles_per_img, ntiles;
+    int tile_w;       // >0: 8x4 screen tiles over a tile_w-wide image
+    int tiles_x;      // tile_w / 8
+    int H, W;
+    int Sc, Sf;
+    float ray_start, ray_end, depth_delta;
+    int white_back;
+    int lds_rows;     // rows (of 32 floats) of per-wave LDS
+    P3dDecodeCfg cfg;
+};
+
+// per-ray running state of MipRayMarcher2 (ray_marcher.py:25-57)
+struct MarchState {
+    double Td;
+    float W, D;
+    float prev_t, prev_sigma;
+};
+
+// weight of interval (prev, cur); advances the transmittance.  ray_marcher.py:26-42
+P3D_DEV float p3d_march_weight(MarchState& st, float t, float sigma, float& tm_out) {
+    float dl = t - st.prev_t;
+    float sm = (st.prev_sigma + sigma) * 0.5f;
+    float tm = (st.prev_t + t) * 0.5f;
+    float rho = p3d_softplus(sm - 1.0f);
+    float dd = rho * dl;
+    float alpha = 1.0f - p3d_exp(-dd);
+    float T = (float)st.Td;
+    float w = alpha * T;
+    st.Td = st.Td * (double)((1.0f - alpha) + 1e-10f);
+    tm_out = tm;
+    return w;
+}
+
+__global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    // XCD-aware block swizzle: hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles so that
+    // the plane texels its rays touch stay in that XCD's L2.
+    long long nblk = gridDim.x, b = blockIdx.x;
+    long long per = nblk >> 3;
+    long long bs = (b < per * 8) ? (b & 7) * per + (b >> 3) : b;
+    long long tile = bs * P3D_WAVES_PER_WG + wave;
+    if (tile >= p.ntiles) return;  // no workgroup barrier below this line
+    float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;  // per-wave rows, 16-B aligned
+
+    const int Sc = p.Sc, Sf = p.Sf, S = Sc + Sf;
+    long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
+    long long r;
+    if (p.tile_w > 0) {
+        long long ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
+        r = (ty * 4 + (j >> 3)) * p.tile_w + tx * 8 + (j & 7);
+    } else {
+        r = tl * 32 + j;
+    }
+    const bool active = r < p.R;
+    const long long rc = active ? r : p.R - 1;
+    const size_t ray = (size_t)n * p.R + rc;
+
+    P3dPlaneGeom g;
+    g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
+    g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
+    unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
+    const float* pbase = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
+
+    const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
+    const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+
+    // LDS rows of this wave: row(i)[j]
+    float* tcA = wl;                    // [Sc]   coarse depths
+    float* wcA = tcA + Sc * 32;         // [Sc]   coarse weights, then pdf / cdf (row 0 = cdf[0])
+    float* tfA = wcA + Sc * 32;         // [Sf]   fine depths (draw order, then sorted)
+    float* mgA = tfA + Sf * 32;         // [S]    merged sorted depths
+    const bool dump = active && h == 0;
+
+    // ---- sample_stratified: renderer.py:320-324
+    {
+        const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
+        const float* jit = p.jitter + ray * Sc;
+        for (int i = 0; i < Sc; ++i) {
+            float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
+            float t = lin + jit[i] * p.depth_delta;
+            tcA[i * 32 + j] = t;
+            if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
+        }
+    }
+    float tmin = __builtin_inff(), tmax = -__builtin_inff();
+    const float* mg = tcA;
+    int Sm = Sc;
+    if (Sf > 0) {
+        // ---- coarse pass, densities only -> ray-marcher weights: renderer.py:179-211
+        MarchState st;
+        st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+        for (int i = 0; i < Sc; ++i) {
+            float t = tcA[i * 32 + j];
+            float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
+            float sigma;
+            f32x16 dummy;
+            p3d_decode_wave<false>(lds, rs, g, p.cfg, px, py, pz, sigma, dummy);
+            if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
+            if (i > 0) {
+                float tm;
+                float w = p3d_march_weight(st, t, sigma, tm);
+                wcA[(i - 1) * 32 + j] = w;
+                if (dump && p.dumps.weights_coarse) p.dumps.weights_coarse[ray * (Sc - 1) + i - 1] = w;
+            }
+            st.prev_t = t; st.prev_sigma = sigma;
+        }
+        // ---- sample_importance / sample_pdf: renderer.py:328-387 (per ray; both lanes of a pair compute the same)
+        const int Ns = Sc - 3;
+        {
+            // v[jj] = ws[jj+1] + 1e-5, ws[q] = (max(w[q-1],w[q]) + max(w[q],w[q+1])) * 0.5 + 0.01 ; stored at row jj+1
+            double sum = 0.0;
+            float wa = wcA[0 * 32 + j], wb = wcA[1 * 32 + j];
+            for (int jj = 0; jj < Ns; ++jj) {
+                float wc = wcA[(jj + 2) * 32 + j];
+                float m1 = __builtin_fmaxf(wa, wb), m2 = __builtin_fmaxf(wb, wc);
+                float v = ((m1 + m2) * 0.5f + 0.01f) + 1e-5f;
+                sum += (double)v;
+                wcA[(jj + 1) * 32 + j] = v;
+                wa = wb; wb = wc;
+            }
+            float fsum = (float)sum;
+            double acc = 0.0;
+            wcA[j] = 0.0f;  // cdf[0]
+            for (int jj = 0; jj < Ns; ++jj) {
+                float pdf = wcA[(jj + 1) * 32 + j] / fsum;
+                acc += (double)pdf;
+                wcA[(jj + 1) * 32 + j] = (float)acc;  // cdf[jj+1]
+            }
+        }
+        {
+            const float* uu = p.u + ray * Sf;
+            for (int i = 0; i < Sf; ++i) {
+                float ui = uu[i];
+                // k = #{q in 0..Ns : cdf[q] <= u}  (searchsorted right=True) — binary search on the non-decreasing cdf
+                int lo = 0, hi = Ns + 1;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (wcA[mid * 32 + j] <= ui) lo = mid + 1; else hi = mid;
+                }
+                int k = lo;
+                int below = k - 1 > 0 ? k - 1 : 0;
+                int above = k < Ns ? k : Ns;
+                float cb = wcA[below * 32 + j], ca = wcA[above * 32 + j];
+                float den = ca - cb;
+                if (den < 1e-5f) den = 1.0f;
+                float bb = 0.5f * (tcA[below * 32 + j] + tcA[(below + 1) * 32 + j]);
+                float ba = 0.5f * (tcA[above * 32 + j] + tcA[(above + 1) * 32 + j]);
+                float tf = bb + ((ui - cb) / den) * (ba - bb);
+                tfA[i * 32 + j] = tf;
+                if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = tf;
+                if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+            }
+        }
+        // ---- unify_samples depths: sort fine (insertion), then stable merge with the coarse list: renderer.py:289-301
+        for (int i = 1; i < Sf; ++i) {
+            float key = tfA[i * 32 + j];
+            int q = i - 1;
+            while (q >= 0) {
+                float v = tfA[q * 32 + j];
+                if (!(v > key)) break;
+                tfA[(q + 1) * 32 + j] = v;
+                --q;
+            }
+            tfA[(q + 1) * 32 + j] = key;
+        }
+        {
+            // the coarse list is sorted unless rounding reversed two neighbours; insertion-sort it too (no-op when sorted)
+            for (int i = 1; i < Sc; ++i) {
+                float key = tcA[i * 32 + j];
+                int q = i - 1;
+                while (q >= 0) {
+                    float v = tcA[q * 32 + j];
+                    if (!(v > key)) break;
+                    tcA[(q + 1) * 32 + j] = v;
+                    --q;
+                }
+                tcA[(q + 1) * 32 + j] = key;
+            }
+            int ci = 0, fi = 0;
+            for (int m = 0; m < S; ++m) {
+                float a = ci < Sc ? tcA[ci * 32 + j] : __builtin_inff();
+                float bq = fi < Sf ? tfA[fi * 32 + j] : __builtin_inff();
+                bool take_c = (ci < Sc) && (fi >= Sf || a <= bq);  // ties: coarse first (stable)
+                mgA[m * 32 + j] = take_c ? a : bq;
+                ci += take_c ? 1 : 0;
+                fi += take_c ? 0 : 1;
+            }
+        }
+        mg = mgA;
+        Sm = S;
+    }
+    // ---- final pass: decode every merged sample + composite [rgb | xyz]: renderer.py:243-259, ray_marcher.py:25-57
+    MarchState st;
+    st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+    f32x16 C, prev_rgb;
+    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
+    for (int m = 0; m < Sm; ++m) {
+        float t = mg[m * 32 + j];
+        tmin = __builtin_fminf(tmin, t);
+        tmax = __builtin_fmaxf(tmax, t);
+        float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+        float sigma;
+        f32x16 rgb;
+        p3d_decode_wave<true>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
+        if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * Sm + m] = t;
+        if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * Sm + m] = sigma;
+        if (m > 0) {
+            float tm;
+            float w = p3d_march_weight(st, t, sigma, tm);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+            Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+            Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+            Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+            st.W = st.W + w;
+            st.D = p3d_fma(w, tm, st.D);
+        }
+        st.prev_t = t; st.prev_sigma = sigma;
+        prev_rgb = rgb;
+        ppx = px; ppy = py; ppz = pz;
+    }
+    // ---- outputs.  white_back and the [-1,1] rescale are per ray (ray_marcher.py:52-55); the depth clamp is global.
+    {
+        const float Wt = st.W;
+        float d = st.D / Wt;
+        if (d != d) d = __builtin_inff();  // nan_to_num(nan=inf): ray_marcher.py:49
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = C[c];
+            if (p.white_back) v = (v + 1.0f) - Wt;
+            C[c] = v * 2.0f - 1.0f;
+        }
+        if (p.white_back) { Cx = (Cx + 1.0f) - Wt; Cy = (Cy + 1.0f) - Wt; Cz = (Cz + 1.0f) - Wt; }
+        Cx = Cx * 2.0f - 1.0f; Cy = Cy * 2.0f - 1.0f; Cz = Cz * 2.0f - 1.0f;
+        if (active) {
+            float* dst = p.out_feat + ray * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){C[4 * q], C[4 * q + 1], C[4 * q + 2], C[4 * q + 3]};
+            if (h == 0) {
+                p.out_depth[ray] = d;  // clamped by k_render_finish
+                p.out_wsum[ray] = Wt;  // weights.sum(2): renderer.py:264
+                p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz;
+                if (p.dumps.depth_unclamped) p.dumps.depth_unclamped[ray] = st.D / Wt;
+            }
+        }
+    }
+    // global min / max of all depths of the call (torch.min/max(depths): ray_marcher.py:50)
+    if (!active) { tmin = __builtin_inff(); tmax = -__builtin_inff(); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        tmin = __builtin_fminf(tmin, __shfl_xor(tmin, o));
+        tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, o));
+    }
+    if (lane == 0) {
+        atomicMin(p.gminmax, p3d_f2ord(tmin));
+        atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+    }
+}
+
+__global__ void k_minmax_init(uint32_t* g) {
+    g[0] = 0xffffffffu;
+    g[1] = 0u;
+}
+
+__global__ void k_render_finish(float* depth, long long n, const uint32_t* g, float* dump_tminmax) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float lo = p3d_ord2f(g[0]), hi = p3d_ord2f(g[1]);
+    if (i == 0 && dump_tminmax) { dump_tminmax[0] = lo; dump_tminmax[1] = hi; }
+    if (i < n) {
+        float d = depth[i];
+        d = d < lo ? lo : d;  // torch.clamp(x, min, max) = min(max(x, min), max)
+        d = d > hi ? hi : d;
+        depth[i] = d;
+    }
+}
+
+// =====================================================================================================================
+// operator-level stand-alone stages (one thread per ray)
+// =====================================================================================================================
+__global__ void k_stratified(float start, float end, float delta, int S, const float* __restrict__ jitter, long long NR,
+                             float* __restrict__ out) {
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= NR) return;
+    const float step = (end - start) / (float)(S - 1);
+    for (int i = 0; i < S; ++i) {
+        float lin = (i < S / 2) ? p3d_fma(step, (float)i, start) : p3d_fma(-step, (float)(S - 1 - i), end);
+        out[r * S + i] = lin + jitter[r * S + i] * delta;
+    }
+}
+
+__global__ void k_depth_minmax(const float* __restrict__ d, long long n, uint32_t* g) {
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        lo = __builtin_fminf(lo, d[i]);
+        hi = __builtin_fmaxf(hi, d[i]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = __builtin_fminf(lo, __shfl_xor(lo, o));
+        hi = __builtin_fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(g, p3d_f2ord(lo));
+        atomicMax(g + 1, p3d_f2ord(hi));
+    }
+}
+
+// MipRayMarcher2.run_forward, one thread per (ray, channel-slice): thread handles channels k = c0, c0+KS, ...
+// To keep the weights bit-identical across the slices every thread recomputes them (cheap) — ray_marcher.py:25-57.
+__global__ void k_composite(const float* __restrict__ colors, const float* __restrict__ sigma,
+                            const float* __restrict__ depths, long long NR, int S, int K, int white_back,
+                            float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_w) {
+    long long r = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (r >= NR) return;
+    const int c0 = threadIdx.x, KS = blockDim.x;
+    const float* col = colors + r * S * K;
+    const float* sg = sigma + r * S;
+    const float* t = depths + r * S;
+    MarchState st;
+    st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = t[0]; st.prev_sigma = sg[0];
+    float C[8];  // up to 8 channels per thread (K <= 8*KS)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) C[q] = 0.0f;
+    for (int i = 1; i < S; ++i) {
+        float tm;
+        float w = p3d_march_weight(st, t[i], sg[i], tm);
+        if (out_w && c0 == 0) out_w[r * (S - 1) + i - 1] = w;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int k = c0 + q * KS;
+            if (k < K) C[q] = p3d_fma(w, (col[(i - 1) * K + k] + col[i * K + k]) * 0.5f, C[q]);
+        }
+        st.W = st.W + w;
+        st.D = p3d_fma(w, tm, st.D);
+        st.prev_t = t[i]; st.prev_sigma = sg[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int k = c0 + q * KS;
+        if (k < K) {
+            float v = C[q];
+            if (white_back) v = (v + 1.0f) - st.W;
+            out_rgb[r * K + k] = v * 2.0f - 1.0f;
+        }
+    }
+    if (c0 == 0) {
+        float d = st.D / st.W;
+        if (d != d) d = __builtin_inff();
+        out_depth[r] = d;
+    }
+}
+
+// sample_importance + sample_pdf, one thread per ray, scratch in registers/local memory — renderer.py:328-387
+__global__ void k_importance(const float* __restrict__ depths, const float* __restrict__ weights, long long NR, int Sc,
+                             int Sf, const float* __restrict__ u, float* __restrict__ out_depths,
+                             int* __restrict__ out_inds) {
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= NR) return;
+    const float* t = depths + r * Sc;
+    const float* w = weights + r * (Sc - 1);
+    const int Ns = Sc - 3;
+    float cdf[P3D_MAX_S];
+    double sum = 0.0;
+    for (int jj = 0; jj < Ns; ++jj) {
+        float m1 = __builtin_fmaxf(w[jj], w[jj + 1]), m2 = __builtin_fmaxf(w[jj + 1], w[jj + 2]);
+        float v = ((m1 + m2) * 0.5f + 0.01f) + 1e-5f;
+        sum += (double)v;
+        cdf[jj + 1] = v;
+    }
+    float fsum = (float)sum;
+    double acc = 0.0;
+    cdf[0] = 0.0f;
+    for (int jj = 0; jj < Ns; ++jj) {
+        float pdf = cdf[jj + 1] / fsum;
+        acc += (double)pdf;
+        cdf[jj + 1] = (float)acc;
+    }
+    for (int i = 0; i < Sf; ++i) {
+        float ui = u[r * Sf + i];
+        int lo = 0, hi = Ns + 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= ui) lo = mid + 1; else hi = mid;
+        }
+        int k = lo;
+        int below = k - 1 > 0 ? k - 1 : 0;
+        int above = k < Ns ? k : Ns;
+        float den = cdf[above] - cdf[below];
+        if (den < 1e-5f) den = 1.0f;
+        float bb = 0.5f * (t[below] + t[below + 1]);
+        float ba = 0.5f * (t[above] + t[above + 1]);
+        out_depths[r * Sf + i] = bb + ((ui - cdf[below]) / den) * (ba - bb);
+        if (out_inds) out_inds[r * Sf + i] = k;
+    }
+}
+
+// unify_samples permutation (stable ascending), one thread per ray, rank counting — renderer.py:289-301
+__global__ void k_unify_perm(const float* __restrict__ tc, const float* __restrict__ tf, long long NR, int Sc, int Sf,
+                             int* __restrict__ perm) {
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= NR) return;
+    const int S = Sc + Sf;
+    const float* a = tc + r * Sc;
+    const float* b = tf + r * Sf;
+    for (int i = 0; i < S; ++i) {
+        float ki = i < Sc ? a[i] : b[i - Sc];
+        int rank = 0;
+        for (int q = 0; q < S; ++q) {
+            float kq = q < Sc ? a[q] : b[q - Sc];
+            rank += (kq < ki || (kq == ki && q < i)) ? 1 : 0;
+        }
+        perm[r * S + rank] = i;
+    }
+}
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+static inline int p3d_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? P3D_OK : (int)e;
+}
+
+static P3dDecodeCfg make_cfg(const p3d_opts* o) {
+    P3dDecodeCfg c;
+    c.coord_scale = o->coord_scale;
+    c.crop_limit = o->crop_limit;
+    c.cull_thresh = o->cull_thresh;
+    c.plane_mode = o->plane_mode;
+    c.flags = o->flags;
+    return c;
+}
+
+extern "C" {
+
+const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1"; }
+
+int p3d_planes_to_nhwc_f32(const float* src, int n3, int C, int H, int W, float* dst, void* stream) {
+    if (!src || !dst || n3 <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if (C != P3D_C) return P3D_E_RANGE;
+    int HW = H * W;
+    dim3 grid((HW + 63) / 64, n3);
+    hipLaunchKernelGGL(k_planes_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, src, dst, HW);
+    return p3d_check_launch();
+}
+
+int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const float* coords, int64_t M, const float* w0,
+                            const float* b0, const float* w1, const float* b1, const p3d_opts* opts, float* out_sigma,
+                            float* out_rgb, void* stream) {
+    if (!planes || !coords || !w0 || !b0 || !w1 || !b1 || !opts || !out_sigma || N <= 0 || M <= 0) return P3D_E_ARG;
+    if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL) return P3D_E_RANGE;
+    DecodeParams p;
+    p.planes = planes; p.coords = coords; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+    p.out_sigma = out_sigma; p.out_rgb = out_rgb; p.M = M; p.H = H; p.W = W;
+    p.tiles_per_img = (M + 31) / 32;
+    p.ntiles = p.tiles_per_img * N;
+    p.cfg = make_cfg(opts);
+    long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    if (out_rgb)
+        hipLaunchKernelGGL(k_decode_points<true>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+    return p3d_check_launch();
+}
+
+size_t p3d_render_workspace_bytes(int N, int64_t R, int Sc, int Sf) {
+    (void)N; (void)R; (void)Sc; (void)Sf;
+    return 256;
+}
+
+int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                   int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
+                   const float* w1, const float* b1, const p3d_opts* opts, float* out_feat, float* out_depth,
+                   float* out_wsum, float* out_xyz, void* workspace, size_t workspace_bytes, const p3d_dumps* dumps,
+                   void* stream) {
+    if (!planes || !rays_o || !rays_d || !jitter || !w0 || !b0 || !w1 || !b1 || !opts || !out_feat || !out_depth ||
+        !out_wsum || !out_xyz || !workspace || N <= 0 || R <= 0)
+        return P3D_E_ARG;
+    const int Sc = opts->Sc, Sf = opts->Sf;
+    if (Sc < 4 || Sc > P3D_MAX_S || Sf < 0 || Sf > P3D_MAX_S) return P3D_E_RANGE;
+    if (Sf > 0 && !u) return P3D_E_ARG;
+    if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL) return P3D_E_RANGE;
+    if (workspace_bytes < p3d_render_workspace_bytes(N, R, Sc, Sf)) return P3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    RenderParams p;
+    p.planes = planes; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.u = u;
+    p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+    p.out_feat = out_feat; p.out_depth = out_depth; p.out_wsum = out_wsum; p.out_xyz = out_xyz;
+    p.gminmax = (uint32_t*)workspace;
+    if (dumps) p.dumps = *dumps; else memset(&p.dumps, 0, sizeof(p.dumps));
+    p.R = R; p.H = H; p.W = W; p.Sc = Sc; p.Sf = Sf;
+    p.ray_start = opts->ray_start; p.ray_end = opts->ray_end; p.depth_delta = opts->depth_delta;
+    p.white_back = (opts->flags & P3D_FLAG_WHITE_BACK) ? 1 : 0;
+    p.cfg = make_cfg(opts);
+    if (ray_tile_w > 0 && R % ray_tile_w == 0 && ray_tile_w % 8 == 0 && (R / ray_tile_w) % 4 == 0) {
+        p.tile_w = ray_tile_w;
+        p.tiles_x = ray_tile_w / 8;
+        p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4);
+    } else {
+        p.tile_w = 0;
+        p.tiles_x = 0;
+        p.tiles_per_img = (R + 31) / 32;
+    }
+    p.ntiles = p.tiles_per_img * N;
+    p.lds_rows = Sc + Sc + Sf + (Sf > 0 ? Sc + Sf : 0);
+    size_t lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)P3D_WAVES_PER_WG * p.lds_rows * 128;
+    if (lds_bytes > 160 * 1024) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
+    hipError_t e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
+    hipLaunchKernelGGL(k_render, dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, st, p);
+    int rc = p3d_check_launch();
+    if (rc) return rc;
+    long long NR = (long long)N * R;
+    hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR + 255) / 256)), dim3(256), 0, st, out_depth, NR, p.gminmax,
+                       dumps ? dumps->tminmax : nullptr);
+    return p3d_check_launch();
+}
+
+int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta, int S, const float* jitter, int64_t NR,
+                              float* out, void* stream) {
+    if (!jitter || !out || NR <= 0) return P3D_E_ARG;
+    if (S < 2 || S > P3D_MAX_S) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_stratified, dim3((unsigned)((NR + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ray_start,
+                       ray_end, depth_delta, S, jitter, (long long)NR, out);
+    return p3d_check_launch();
+}
+
+int p3d_composite_f32(const float* colors, const float* sigma, const float* depths, int64_t NR, int S, int K,
+                      int white_back, float* out_rgb, float* out_depth, float* out_weights, void* workspace,
+                      void* stream) {
+    if (!colors || !sigma || !depths || !out_rgb || !out_depth || !workspace || NR <= 0) return P3D_E_ARG;
+    if (S < 2 || K < 1 || K > 64) return P3D_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* g = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, g);
+    hipLaunchKernelGGL(k_depth_minmax, dim3(1024), dim3(256), 0, st, depths, (long long)NR * S, g);
+    dim3 blk(8, 32);
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((NR + 31) / 32)), blk, 0, st, colors, sigma, depths, (long long)NR, S,
+                       K, white_back, out_rgb, out_depth, out_weights);
+    hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR + 255) / 256)), dim3(256), 0, st, out_depth, (long long)NR, g,
+                       (float*)nullptr);
+    return p3d_check_launch();
+}
+
+int p3d_importance_f32(const float* depths, const float* weights, int64_t NR, int Sc, int Sf, const float* u,
+                       float* out_depths, int32_t* out_inds, void* stream) {
+    if (!depths || !weights || !u || !out_depths || NR <= 0) return P3D_E_ARG;
+    if (Sc < 4 || Sc > P3D_MAX_S || Sf < 1) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_importance, dim3((unsigned)((NR + 63) / 64)), dim3(64), 0, (hipStream_t)stream, depths, weights,
+                       (long long)NR, Sc, Sf, u, out_depths, out_inds);
+    return p3d_check_launch();
+}
+
+int p3d_unify_perm_f32(const float* tc, const float* tf, int64_t NR, int Sc, int Sf, int32_t* perm, void* stream) {
+    if (!tc || !tf || !perm || NR <= 0) return P3D_E_ARG;
+    if (Sc < 1 || Sf < 0) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_unify_perm, dim3((unsigned)((NR + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tc, tf,
+                       (long long)NR, Sc, Sf, perm);
+    return p3d_check_launch();
+}
+
+}  // extern "C"

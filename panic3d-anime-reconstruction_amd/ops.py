@@ -1,0 +1,231 @@
+"""Tensor-level operators over the C ABI (include/panic3d_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every computation is a call into
+libpanic3d_hip.so.  All tensors must be float32 CUDA(ROCm) tensors; misuse raises like the reference's plugins do
+(TORCH_CHECK -> RuntimeError, torch_utils/ops/bias_act.cpp:39-55).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Opts, Dumps
+
+__all__ = ["make_opts", "prescale_mlp", "planes_to_nhwc", "triplane_decode", "render", "sample_stratified", "composite",
+           "importance", "unify_perm"]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_clouds=None, force_sigmoid=False):
+    """rendering_kwargs + ImportanceRenderer.forward arguments (renderer.py:162) -> p3d_opts.
+    The double -> binary32 conversions are the ones include/p3d_numerics.h states."""
+    ro = rendering_options
+    if ro.get("ray_start") == "auto" or ro.get("ray_end") == "auto":
+        raise NotImplementedError("ray_start/ray_end='auto' (renderer.py:165-171) is not used by PAniC-3D configs")
+    if ro.get("disparity_space_sampling", False):
+        raise NotImplementedError("disparity_space_sampling (renderer.py:309-316) is not used by PAniC-3D configs")
+    if ro.get("clamp_mode", "softplus") != "softplus":
+        raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")  # ray_marcher.py:35
+    if ro.get("density_noise", 0) > 0:
+        raise NotImplementedError("density_noise > 0 (renderer.py:276-277) is a training-time option")
+    if ro.get("triplane_depth", 1) != 1:
+        raise NotImplementedError("triplane_depth != 1")
+    bw = float(ro["box_warp"])
+    Sc = int(ro["depth_resolution"])
+    Sf = int(ro.get("depth_resolution_importance", 0) or 0)
+    flags, crop_limit, thr = 0, 0.0, 0.0
+    if triplane_crop:
+        flags |= _lib.P3D_FLAG_CROP
+        crop_limit = bw / 2 - float(triplane_crop)
+    if binarize_clouds:
+        flags |= _lib.P3D_FLAG_BINARIZE
+        thr = float(binarize_clouds)
+    elif cull_clouds:
+        flags |= _lib.P3D_FLAG_CULL
+        thr = float(cull_clouds)
+    if force_sigmoid:
+        flags |= _lib.P3D_FLAG_FORCE_SIGMOID
+    if ro.get("white_back", False):
+        flags |= _lib.P3D_FLAG_WHITE_BACK
+    rs, re = float(ro["ray_start"]), float(ro["ray_end"])
+    return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
+                np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
+
+
+def prescale_mlp(w0, b0, w1, b1, weight_gain0, bias_gain0, weight_gain1, bias_gain1):
+    """FullyConnectedLayer.forward's `w * weight_gain`, `b * bias_gain` (networks_stylegan2.py:121-127), in float32."""
+    w0s = (w0.detach().float() * float(weight_gain0)).contiguous()
+    w1s = (w1.detach().float() * float(weight_gain1)).contiguous()
+    b0s = b0.detach().float()
+    b1s = b1.detach().float()
+    if bias_gain0 != 1:
+        b0s = b0s * float(bias_gain0)
+    if bias_gain1 != 1:
+        b1s = b1s * float(bias_gain1)
+    return w0s, b0s.contiguous(), w1s, b1s.contiguous()
+
+
+def planes_to_nhwc(planes):
+    """[N,3,32,H,W] (training/triplane.py:200-206) -> channels-last [N,3,H,W,32]."""
+    planes = _chk(planes, "planes")
+    if planes.dim() != 5 or planes.shape[1] != 3 or planes.shape[2] != 32:
+        raise RuntimeError(f"planes must be [N,3,32,H,W], got {tuple(planes.shape)}")
+    N, _, Cc, H, W = planes.shape
+    out = torch.empty((N, 3, H, W, Cc), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        _lib.check(_lib.lib().p3d_planes_to_nhwc_f32(_p(planes), N * 3, Cc, H, W, _p(out), _stream()), "p3d_planes_to_nhwc_f32")
+    return out
+
+
+def _chk_mlp(mlp):
+    w0, b0, w1, b1 = (_chk(t, n) for t, n in zip(mlp, ("w0", "b0", "w1", "b1")))
+    if tuple(w0.shape) != (64, 32) or tuple(b0.shape) != (64,) or tuple(w1.shape) != (33, 64) or tuple(b1.shape) != (33,):
+        raise RuntimeError("decoder must be OSGDecoder-shaped: 32 -> 64 -> 33 (training/triplane.py:521-526)")
+    return w0, b0, w1, b1
+
+
+def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
+    """run_model (renderer.py:266-280) on coords [N,M,3] -> sigma [N,M,1], rgb [N,M,32] (None if density_only).
+    Masks are applied iff opts.flags carries CROP/CULL/BINARIZE."""
+    planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
+    coords = _chk(coords, "coords")
+    N, three, H, W, Cc = planes_nhwc.shape
+    if three != 3 or Cc != 32 or coords.dim() != 3 or coords.shape[0] != N or coords.shape[2] != 3:
+        raise RuntimeError("planes_nhwc must be [N,3,H,W,32] and coords [N,M,3]")
+    w0, b0, w1, b1 = _chk_mlp(mlp)
+    M = coords.shape[1]
+    sigma = torch.empty((N, M, 1), dtype=torch.float32, device=coords.device)
+    rgb = None if density_only else torch.empty((N, M, 32), dtype=torch.float32, device=coords.device)
+    with torch.cuda.device(coords.device):
+        rc = _lib.lib().p3d_triplane_decode_f32(_p(planes_nhwc), N, H, W, _p(coords), M, _p(w0), _p(b0), _p(w1), _p(b1),
+                                                C.byref(opts), _p(sigma), _p(rgb), _stream())
+    _lib.check(rc, "p3d_triplane_decode_f32")
+    return sigma, rgb
+
+
+DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "inds", "depths_sorted", "sigma_sorted",
+             "depth_unclamped", "tminmax")
+
+
+def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False):
+    """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
+    jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
+    Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps)."""
+    planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
+    rays_o, rays_d, jitter = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions"), _chk(jitter, "jitter")
+    N, three, H, W, Cc = planes_nhwc.shape
+    if three != 3 or Cc != 32 or rays_o.dim() != 3 or rays_o.shape[0] != N or rays_o.shape[2] != 3 or rays_d.shape != rays_o.shape:
+        raise RuntimeError("planes_nhwc must be [N,3,H,W,32]; ray_origins / ray_directions [N,R,3]")
+    R = rays_o.shape[1]
+    Sc, Sf = opts.Sc, opts.Sf
+    if jitter.numel() != N * R * Sc:
+        raise RuntimeError(f"jitter must hold N*R*Sc = {N * R * Sc} values")
+    if Sf > 0:
+        u = _chk(u, "u")
+        if u.numel() != N * R * Sf:
+            raise RuntimeError(f"u must hold N*R*Sf = {N * R * Sf} values")
+    else:
+        u = None
+    w0, b0, w1, b1 = _chk_mlp(mlp)
+    dev = rays_o.device
+    feat = torch.empty((N, R, 32), dtype=torch.float32, device=dev)
+    depth = torch.empty((N, R, 1), dtype=torch.float32, device=dev)
+    wsum = torch.empty((N, R, 1), dtype=torch.float32, device=dev)
+    xyz = torch.empty((N, R, 3), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    wsb = L.p3d_render_workspace_bytes(N, R, Sc, Sf)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    d, dm = None, None
+    if dumps:
+        NR, S = N * R, Sc + Sf
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = dict(depths_coarse=torch.empty((NR, Sc), **f32), sigma_coarse=torch.empty((NR, Sc), **f32),
+                 weights_coarse=torch.empty((NR, Sc - 1), **f32), depths_fine=torch.empty((NR, Sf), **f32),
+                 inds=torch.empty((NR, Sf), dtype=torch.int32, device=dev), depths_sorted=torch.empty((NR, S), **f32),
+                 sigma_sorted=torch.empty((NR, S), **f32), depth_unclamped=torch.empty((NR,), **f32),
+                 tminmax=torch.empty((2,), **f32))
+        dm = Dumps(*[_p(d[k]) for k in DUMP_KEYS])
+    with torch.cuda.device(dev):
+        rc = L.p3d_render_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), _p(jitter), _p(u),
+                              _p(w0), _p(b0), _p(w1), _p(b1), C.byref(opts), _p(feat), _p(depth), _p(wsum), _p(xyz),
+                              _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
+    _lib.check(rc, "p3d_render_f32")
+    return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)
+
+
+def sample_stratified(ray_start, ray_end, S, jitter):
+    """sample_stratified (renderer.py:320-324): jitter [...,S(,1)] -> depths, same shape."""
+    jitter = _chk(jitter, "jitter")
+    out = torch.empty_like(jitter)
+    NR = jitter.numel() // S
+    with torch.cuda.device(jitter.device):
+        rc = _lib.lib().p3d_sample_stratified_f32(np.float32(ray_start), np.float32(ray_end),
+                                                  np.float32((float(ray_end) - float(ray_start)) / (S - 1)), int(S),
+                                                  _p(jitter), NR, _p(out), _stream())
+    _lib.check(rc, "p3d_sample_stratified_f32")
+    return out
+
+
+def composite(colors, densities, depths, white_back=True):
+    """MipRayMarcher2.run_forward (ray_marcher.py:25-57): colors [N,R,S,K], densities [N,R,S,1], depths [N,R,S,1] ->
+    (rgb [N,R,K], depth [N,R,1], weights [N,R,S-1,1])."""
+    colors, densities, depths = _chk(colors, "colors"), _chk(densities, "densities"), _chk(depths, "depths")
+    lead = colors.shape[:-2]
+    S, K = colors.shape[-2], colors.shape[-1]
+    NR = colors.numel() // (S * K)
+    if densities.numel() != NR * S or depths.numel() != NR * S:
+        raise RuntimeError("densities / depths must be [...,S,1] matching colors [...,S,K]")
+    dev = colors.device
+    rgb = torch.empty(lead + (K,), dtype=torch.float32, device=dev)
+    depth = torch.empty(lead + (1,), dtype=torch.float32, device=dev)
+    w = torch.empty(lead + (S - 1, 1), dtype=torch.float32, device=dev)
+    ws = torch.empty((16,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().p3d_composite_f32(_p(colors), _p(densities), _p(depths), NR, S, K, int(bool(white_back)), _p(rgb),
+                                          _p(depth), _p(w), _p(ws), _stream())
+    _lib.check(rc, "p3d_composite_f32")
+    return rgb, depth, w
+
+
+def importance(depths, weights, u, return_inds=False):
+    """sample_importance (renderer.py:328-346): depths [N,R,Sc,1], weights [N,R,Sc-1,1], u [N*R,Sf] -> [N,R,Sf,1]."""
+    depths, weights, u = _chk(depths, "depths"), _chk(weights, "weights"), _chk(u, "u")
+    Sf = u.shape[-1]
+    NR = u.numel() // Sf
+    Sc = depths.numel() // NR
+    if weights.numel() != NR * (Sc - 1):
+        raise RuntimeError("weights must hold Sc-1 values per ray")
+    out = torch.empty(tuple(depths.shape[:2]) + (Sf, 1) if depths.dim() == 4 else (NR, Sf), dtype=torch.float32, device=u.device)
+    inds = torch.empty((NR, Sf), dtype=torch.int32, device=u.device) if return_inds else None
+    with torch.cuda.device(u.device):
+        rc = _lib.lib().p3d_importance_f32(_p(depths), _p(weights), NR, Sc, Sf, _p(u), _p(out), _p(inds), _stream())
+    _lib.check(rc, "p3d_importance_f32")
+    return (out, inds) if return_inds else out
+
+
+def unify_perm(depths_coarse, depths_fine):
+    """The sort of unify_samples (renderer.py:295): stable ascending permutation of cat([coarse, fine]) per ray -> int32 [NR,S]."""
+    dc, df = _chk(depths_coarse, "depths_coarse"), _chk(depths_fine, "depths_fine")
+    NR = dc.shape[0] if dc.dim() == 2 else dc.numel() // dc.shape[-2]
+    Sc, Sf = dc.numel() // NR, df.numel() // NR
+    perm = torch.empty((NR, Sc + Sf), dtype=torch.int32, device=dc.device)
+    with torch.cuda.device(dc.device):
+        rc = _lib.lib().p3d_unify_perm_f32(_p(dc), _p(df), NR, Sc, Sf, _p(perm), _stream())
+    _lib.check(rc, "p3d_unify_perm_f32")
+    return perm

@@ -1,0 +1,75 @@
+"""Host-side mirror of the reference's volumetric renderer call surface, on the HIP path.
+
+Same class name, method names, argument order and return values as
+training/volumetric_rendering/renderer.py:156-387 (ImportanceRenderer) so that
+training/triplane.py:209 (`self.renderer(planes, self.decoder, ray_origins, ray_directions, rendering_kwargs, ...)`)
+and :292 (`self.renderer.run_model(...)`) keep working when the class is swapped in.
+
+Differences that are deliberate:
+  * the two random draws (renderer.py:324 `torch.rand_like`, :371 `torch.rand`) are made on the device with the same
+    call order and shapes, or injected via `jitter=` / `u=` (parity tests, CPU-generated draws);
+  * the decoder module is read for its parameters only (it is evaluated inside the fused kernel), so it must be an
+    OSGDecoder-shaped module: net[0] 32->64, Softplus, net[2] 64->33 (training/triplane.py:516-544);
+  * CPU tensors raise: the product path has no CPU fallback.
+"""
+import torch
+
+from . import ops
+
+
+def decoder_params(decoder):
+    """(w0, b0, w1, b1) pre-scaled exactly like FullyConnectedLayer.forward (networks_stylegan2.py:121-127)."""
+    l0, l2 = decoder.net[0], decoder.net[2]
+    return ops.prescale_mlp(l0.weight, l0.bias, l2.weight, l2.bias, l0.weight_gain, l0.bias_gain, l2.weight_gain,
+                            l2.bias_gain)
+
+
+class ImportanceRenderer(torch.nn.Module):
+    def __init__(self, use_triplane=False):
+        super().__init__()
+        self.use_triplane = bool(use_triplane)  # generate_planes(use_triplane): renderer.py:26-50
+        self._planes_cache = (None, None)
+
+    def _nhwc(self, planes):
+        # planes arrive NCHW [N,3,32,H,W] (training/triplane.py:200-206).  Reuse the channels-last copy while the same
+        # tensor (same storage, same version) is rendered again — generate.py renders 16 views per subject.
+        key = (planes.data_ptr(), planes._version, tuple(planes.shape), planes.device)
+        if self._planes_cache[0] != key:
+            self._planes_cache = (key, ops.planes_to_nhwc(planes))
+        return self._planes_cache[1]
+
+    def _opts(self, rendering_options, decoder, **kw):
+        ro = dict(rendering_options)
+        ro["use_triplane"] = self.use_triplane
+        return ops.make_opts(ro, force_sigmoid=bool(getattr(decoder, "force_sigmoid", False)), **kw)
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None,
+                cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False):
+        opts = self._opts(rendering_options, decoder, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
+                          binarize_clouds=binarize_clouds)
+        N, R, _ = ray_origins.shape
+        dev = ray_origins.device
+        if jitter is None:  # renderer.py:324
+            jitter = torch.rand((N, R, opts.Sc, 1), dtype=torch.float32, device=dev)
+        if u is None and opts.Sf > 0:  # renderer.py:371
+            u = torch.rand((N * R, opts.Sf), dtype=torch.float32, device=dev)
+        if ray_tile_w is None:  # square images are the reference's only use (training/triplane.py:222-226)
+            side = int(round(R ** 0.5))
+            ray_tile_w = side if side * side == R else 0
+        out = ops.render(self._nhwc(planes), ray_origins.float(), ray_directions.float(), jitter, u,
+                         decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps)
+        return out  # rgb_final, depth_final, weights.sum(2), xyz_final  (renderer.py:264)
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        """renderer.py:266-280 — sample_directions are ignored, as the reference's decoder ignores them
+        (training/triplane.py:528-531)."""
+        opts = self._opts(options, decoder)
+        sigma, rgb = ops.triplane_decode(self._nhwc(planes), sample_coordinates.float(), decoder_params(decoder), opts)
+        return {"rgb": rgb, "sigma": sigma, "xyz": sample_coordinates}
+
+    def run_model_density(self, planes, decoder, sample_coordinates, options):
+        """Density-only variant for get_eg3d_volume (_util/eg3d_metrics3d.py:140-150 keeps only sigma and rgb[:3])."""
+        opts = self._opts(options, decoder)
+        sigma, _ = ops.triplane_decode(self._nhwc(planes), sample_coordinates.float(), decoder_params(decoder), opts,
+                                       density_only=True)
+        return sigma

@@ -1,0 +1,153 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle — BIT-EXACT — and against the reference's golden outputs.
+
+Both sides implement include/p3d_numerics.h, so every float, every searchsorted index and every merged depth must be
+identical (np.array_equal), not merely close.  Agreement with the reference itself is the tolerance test of
+tests/test_oracle_golden.py, repeated here on the HIP outputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import p3d_testing as T
+
+pytestmark = pytest.mark.gpu
+
+TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ = 1e-4, 2e-5, 3e-5, 1e-4  # same as tests/test_oracle_golden.py
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import panic3d_amd
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    panic3d_amd._lib.lib()  # must load: no fallback
+    return panic3d_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def hip_opts(hip, ro, kw):
+    return hip.ops.make_opts(ro, **kw)
+
+
+def hip_mlp(hip, raw, lr_mul):
+    w0, b0, w1, b1 = (dev(x) for x in raw)
+    return hip.ops.prescale_mlp(w0, b0, w1, b1, lr_mul / np.sqrt(32), lr_mul, lr_mul / np.sqrt(64), lr_mul)
+
+
+def run_hip_render(hip, inp, tile_w=0):
+    opts = hip_opts(hip, inp["ro"], inp["kw"])
+    mlp = hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"])
+    planes = hip.ops.planes_to_nhwc(dev(inp["planes"]))
+    out = hip.ops.render(planes, dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"]), mlp, opts,
+                         ray_tile_w=tile_w, dumps=True)
+    torch.cuda.synchronize()
+    feat, depth, wsum, xyz, d = out
+    return feat.cpu().numpy(), depth.cpu().numpy(), wsum.cpu().numpy(), xyz.cpu().numpy(), {k: v.cpu().numpy() for k, v in d.items()}
+
+
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
+    g = T.load_golden(name + ".npz")
+    inp = T.golden_render_inputs(g)
+    R = inp["rays_o"].shape[1]
+    side = int(round(R ** 0.5))
+    if tiled and (side * side != R or side % 8):
+        pytest.skip("not an 8x4-tileable image")
+    oo = oracle.make_opts(inp["ro"], **inp["kw"])
+    om = oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"])
+    of, od, ow, ox, odm = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"], om, oo, dumps=True)
+    hf, hd, hw, hx, hdm = run_hip_render(hip, inp, tile_w=side if tiled else 0)
+    # host-side parameter preparation is part of the contract
+    hm = hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"])
+    for a, b in zip(hm, om):
+        assert np.array_equal(a.cpu().numpy(), b)
+    Sc, Sf = oo.Sc, oo.Sf
+    assert np.array_equal(hdm["depths_coarse"], odm["depths_coarse"])
+    if Sf > 0:
+        assert np.array_equal(hdm["sigma_coarse"], odm["sigma_coarse"])
+        assert np.array_equal(hdm["weights_coarse"], odm["weights_coarse"])
+        assert np.array_equal(hdm["depths_fine"], odm["depths_fine"])
+        assert np.array_equal(hdm["inds"], odm["inds"])  # "ray hit indices"
+        all_d = np.concatenate([odm["depths_coarse"], odm["depths_fine"]], axis=1)
+        all_s = np.concatenate([odm["sigma_coarse"], odm["sigma_fine"]], axis=1)
+        assert np.array_equal(hdm["depths_sorted"], np.take_along_axis(all_d, odm["perm"], axis=1))
+        assert np.array_equal(hdm["sigma_sorted"], np.take_along_axis(all_s, odm["perm"], axis=1))
+        # the stand-alone sort operator reproduces the oracle's permutation exactly
+        perm = hip.ops.unify_perm(dev(odm["depths_coarse"]), dev(odm["depths_fine"])).cpu().numpy()
+        assert np.array_equal(perm, odm["perm"])
+    assert np.array_equal(hdm["tminmax"], odm["tminmax"])
+    assert np.array_equal(hdm["depth_unclamped"], odm["depth_unclamped"], equal_nan=True)
+    assert np.array_equal(hf, of)
+    assert np.array_equal(hd, od)
+    assert np.array_equal(hw, ow)
+    assert np.array_equal(hx, ox)
+    # and the HIP outputs agree with the REFERENCE's own outputs within the fp32 tolerance
+    assert np.abs(hf - g["feat"]).max() <= TOL_FEAT
+    assert np.abs(hd - g["depth"]).max() <= TOL_DEPTH
+    assert np.abs(hw - g["wsum"]).max() <= TOL_WEIGHT
+    assert np.abs(hx - g["xyz"]).max() <= TOL_XYZ
+    if "inds" in g:
+        assert int((hdm["inds"] != g["inds"]).sum()) == 0
+
+
+@pytest.mark.parametrize("ut", [0, 1])
+def test_decode_points(hip, oracle, ut):
+    g = T.load_golden(f"decode_points_ut{ut}.npz")
+    seed = int(g["meta_seed"])
+    planes = T.make_planes(seed, 2, 64, 96)
+    pts = T.make_points(seed + 2, 2, 4096, extent=0.45)
+    raw = T.make_decoder_params(seed + 1)
+    om = oracle.prescale_mlp(*raw)
+    osig, orgb = oracle.decode(planes, pts, om, 0.7, plane_mode=ut, flags=0)
+    ro = dict(T.RENDERING_KWARGS, use_triplane=ut)
+    opts = hip.ops.make_opts(ro, force_sigmoid=False)
+    pl = hip.ops.planes_to_nhwc(dev(planes))
+    assert np.array_equal(pl.cpu().numpy(), np.ascontiguousarray(planes.transpose(0, 1, 3, 4, 2)))
+    hs, hr = hip.ops.triplane_decode(pl, dev(pts), hip_mlp(hip, raw, 1.0), opts)
+    assert np.array_equal(hs.cpu().numpy(), osig)
+    assert np.array_equal(hr.cpu().numpy(), orgb)
+    assert np.abs(hs.cpu().numpy() - g["sigma"]).max() <= 1e-5  # vs the reference
+    assert np.abs(hr.cpu().numpy() - g["rgb"]).max() <= 2e-6
+    # density-only entry point (get_eg3d_volume) and a ragged point count (M % 32 != 0)
+    hs2, none = hip.ops.triplane_decode(pl, dev(pts[:, :1000]), hip_mlp(hip, raw, 1.0), opts, density_only=True)
+    assert none is None and np.array_equal(hs2.cpu().numpy(), osig[:, :1000])
+    # masks through the flags (crop + cull), as ImportanceRenderer.forward applies them
+    ok = dict(triplane_crop=0.1, cull_clouds=0.5)
+    oo = oracle.make_opts(ro, **ok)
+    osig3, _ = oracle.decode(planes, pts, om, 0.7, plane_mode=ut, flags=oo.flags, crop_limit=oo.crop_limit, cull_thresh=oo.cull_thresh)
+    hs3, _ = hip.ops.triplane_decode(pl, dev(pts), hip_mlp(hip, raw, 1.0), hip.ops.make_opts(ro, **ok))
+    assert np.array_equal(hs3.cpu().numpy(), osig3) and (osig3 == -1000).any()
+
+
+@pytest.mark.parametrize("wb", [0, 1])
+def test_composite_op(hip, oracle, wb):
+    g = T.load_golden(f"marcher_wb{wb}.npz")
+    orgb, odepth, ow = oracle.composite(g["colors"], g["sigma"], g["depths"], white_back=bool(wb))
+    hrgb, hdepth, hw = hip.ops.composite(dev(g["colors"]), dev(g["sigma"]), dev(g["depths"]), white_back=bool(wb))
+    assert np.array_equal(hrgb.cpu().numpy().reshape(orgb.shape), orgb)
+    assert np.array_equal(hdepth.cpu().numpy().reshape(odepth.shape), odepth)
+    assert np.array_equal(hw.cpu().numpy().reshape(ow.shape), ow)
+    assert np.abs(hrgb.cpu().numpy() - g["rgb"]).max() <= TOL_FEAT
+
+
+def test_importance_op(hip, oracle):
+    g = T.load_golden("importance.npz")
+    ofine, oinds = oracle.importance(g["depths"], g["weights"], g["u"])
+    hfine, hinds = hip.ops.importance(dev(g["depths"]), dev(g["weights"]), dev(g["u"]), return_inds=True)
+    assert np.array_equal(hinds.cpu().numpy(), oinds) and np.array_equal(hinds.cpu().numpy(), g["inds"])
+    assert np.array_equal(hfine.cpu().numpy().reshape(ofine.shape), ofine)
+
+
+@pytest.mark.parametrize("S", [48, 96, 17])
+def test_stratified_op(hip, S):
+    g = T.load_golden(f"stratified_{S}.npz")
+    out = hip.ops.sample_stratified(float(g["start"]), float(g["end"]), S, dev(g["jitter"]))
+    assert np.array_equal(out.cpu().numpy().reshape(g["depths"].shape), g["depths"])  # bit-exact vs the REFERENCE
+
+
+def test_cpu_tensors_raise(hip):
+    with pytest.raises(RuntimeError):
+        hip.ops.planes_to_nhwc(torch.zeros(1, 3, 32, 8, 8))
