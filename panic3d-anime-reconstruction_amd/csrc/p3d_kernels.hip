@@ -154,7 +154,8 @@ __global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
     long long nblk = gridDim.x, b = blockIdx.x;
     long long per = nblk >> 3;
     long long bs = (b < per * 8) ? (b & 7) * per + (b >> 3) : b;
-    long long tile = bs * P3D_WAVES_PER_WG + wave;
+    const int nwaves = blockDim.x >> 6;
+    long long tile = bs * nwaves + wave;
     if (tile >= p.ntiles) return;  // no workgroup barrier below this line
     float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;  // per-wave rows, 16-B aligned
 
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
     // LDS rows of this wave: row(i)[j]
     float* tcA = wl;                    // [Sc]   coarse depths
     float* wcA = tcA + Sc * 32;         // [Sc]   coarse weights, then pdf / cdf (row 0 = cdf[0])
-    float* tfA = wcA + Sc * 32;         // [Sf]   fine depths (draw order, then sorted)
-    float* mgA = tfA + Sf * 32;         // [S]    merged sorted depths
+    float* tfA = tcA + (S > 2 * Sc ? S : 2 * Sc) * 32;  // [Sf] fine depths (draw order, then sorted)
+    float* mgA = tcA;                   // [S]    merged sorted depths, built in place over [tc | wc] (backward merge)
     const bool dump = active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
@@ -293,14 +294,16 @@ __global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
                 }
                 tcA[(q + 1) * 32 + j] = key;
             }
-            int ci = 0, fi = 0;
-            for (int m = 0; m < S; ++m) {
-                float a = ci < Sc ? tcA[ci * 32 + j] : __builtin_inff();
-                float bq = fi < Sf ? tfA[fi * 32 + j] : __builtin_inff();
-                bool take_c = (ci < Sc) && (fi >= Sf || a <= bq);  // ties: coarse first (stable)
-                mgA[m * 32 + j] = take_c ? a : bq;
-                ci += take_c ? 1 : 0;
-                fi += take_c ? 0 : 1;
+            // backward merge into rows [0, S) (S <= 2*Sc rows are reserved): the write row m = ci + fi + 1 is never below
+            // an unread coarse row.  Ties: the coarse sample goes first (stable), i.e. the fine one is taken first here.
+            int ci = Sc - 1, fi = Sf - 1;
+            for (int m = S - 1; m >= 0; --m) {
+                float a = ci >= 0 ? tcA[ci * 32 + j] : -__builtin_inff();
+                float bq = fi >= 0 ? tfA[fi * 32 + j] : -__builtin_inff();
+                bool take_f = (fi >= 0) && (ci < 0 || bq >= a);
+                mgA[m * 32 + j] = take_f ? bq : a;
+                fi -= take_f ? 1 : 0;
+                ci -= take_f ? 0 : 1;
             }
         }
         mg = mgA;
@@ -622,14 +625,20 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         p.tiles_per_img = (R + 31) / 32;
     }
     p.ntiles = p.tiles_per_img * N;
-    p.lds_rows = Sc + Sc + Sf + (Sf > 0 ? Sc + Sf : 0);
-    size_t lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)P3D_WAVES_PER_WG * p.lds_rows * 128;
-    if (lds_bytes > 160 * 1024) return P3D_E_RANGE;
+    // per-wave LDS rows: [tc | wc] (2*Sc, later the merged list of Sc+Sf) and tf (Sf)
+    p.lds_rows = (Sc + Sf > 2 * Sc ? Sc + Sf : 2 * Sc) + Sf;
+    int nwaves = P3D_WAVES_PER_WG;
+    size_t lds_bytes;
+    for (;; nwaves >>= 1) {
+        lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
+        if (lds_bytes <= 160 * 1024) break;
+        if (nwaves == 1) return P3D_E_RANGE;
+    }
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
     hipError_t e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
-    long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
-    hipLaunchKernelGGL(k_render, dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, st, p);
+    long long blocks = (p.ntiles + nwaves - 1) / nwaves;
+    hipLaunchKernelGGL(k_render, dim3((unsigned)blocks), dim3(64 * nwaves), lds_bytes, st, p);
     int rc = p3d_check_launch();
     if (rc) return rc;
     long long NR = (long long)N * R;
