@@ -1,0 +1,72 @@
+"""Multi-GPU layer of the hot path: independent views (or density-grid slabs) are sharded over ranks, one process per
+GPU; the ONLY collective is one gather of final RGBA frames to rank 0 (RCCL over xGMI: backend 'nccl' on ROCm; 'gloo'
+in the CPU tests).  The reference's eval path is single-GPU (_scripts/eval/generate.py:16); its view loop
+(generate.py:108-117) and the 360-degree sweep (_train/eg3dc/util/eg3dc_v0.py:64-87 quickspin) are what gets sharded.
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition(n_items, world_size, rank):
+    """Contiguous block partition: rank r gets items [lo, hi).  First (n % world) ranks get one extra item."""
+    base, rem = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def frames_rgba(feat, wsum, res):
+    """Final RGBA frame of one render: RGB = first 3 feature channels (training/triplane.py:223 image_raw), A = weights
+    sum (generate.py:143-146).  feat [N,R,32], wsum [N,R,1] -> [N,4,res,res]."""
+    N = feat.shape[0]
+    rgba = torch.cat([feat[..., :3], wsum], dim=-1)
+    return rgba.permute(0, 2, 1).reshape(N, 4, res, res).contiguous()
+
+
+def gather_frames(local, counts=None, dst=0):
+    """Gather per-rank frame stacks [n_r,4,H,W] to rank `dst` in rank order.  Every rank pads to max(counts) so a single
+    fixed-size collective is issued per sweep (one large message per xGMI link rather than one per frame).
+    Returns the concatenated [sum n_r,4,H,W] tensor on dst, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if counts is None:
+        c = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+        allc = [torch.zeros_like(c) for _ in range(world)]
+        dist.all_gather(allc, c)
+        counts = [int(x.item()) for x in allc]
+    mx = max(counts)
+    buf = local
+    if local.shape[0] < mx:
+        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        buf = torch.cat([local, pad])
+    buf = buf.contiguous()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, buf)
+        if rank != dst:
+            return None
+        parts = [out[r * mx:r * mx + counts[r]] for r in range(world)]
+    else:
+        lst = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, lst, dst=dst)
+        if rank != dst:
+            return None
+        parts = [lst[r][:counts[r]] for r in range(world)]
+    return torch.cat(parts)
+
+
+def render_views_sharded(render_one, n_views, res, dst=0):
+    """Render views [0, n_views) sharded over the ranks; `render_one(view_index) -> (feat, wsum)` for one view.
+    Returns [n_views,4,res,res] on rank dst."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = partition(n_views, world, rank)
+    frames = []
+    for v in range(lo, hi):
+        feat, wsum = render_one(v)
+        frames.append(frames_rgba(feat, wsum, res))
+    local = torch.cat(frames) if frames else None
+    counts = [partition(n_views, world, r)[1] - partition(n_views, world, r)[0] for r in range(world)]
+    if local is None:
+        raise RuntimeError("a rank received no views; use world_size <= n_views")
+    return gather_frames(local, counts, dst)
