@@ -104,6 +104,19 @@ P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
     return v;
 }
 
+P3D_DEV f32x16 p3d_bilerp(const float wgt[4], const f32x16& v00, const f32x16& v01, const f32x16& v10, const f32x16& v11) {
+    f32x16 f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float a = wgt[0] * v00[c];
+        a = p3d_fma(wgt[1], v01[c], a);
+        a = p3d_fma(wgt[2], v10[c], a);
+        a = p3d_fma(wgt[3], v11[c], a);
+        f[c] = a;
+    }
+    return f;
+}
+
 template <typename RSRC>
 P3D_DEV f32x16 p3d_sample_plane(RSRC rs, const P3dPlaneGeom& g, uint32_t plane_off, uint32_t chan_off, float gx,
                                 float gy) {
@@ -150,13 +163,33 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
     const uint32_t chan_off = (uint32_t)h * 64u;
     float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
     // generate_planes / project_onto_planes: renderer.py:26-66
-    f32x16 f0 = p3d_sample_plane(rs, g, 0u, chan_off, qx, qy);
-    f32x16 f1 = p3d_sample_plane(rs, g, g.plane_bytes, chan_off, qx, qz);
+    // Plane-at-a-time software pipeline: the taps of plane p+1 are in flight while plane p is interpolated, which bounds
+    // the live tap registers to 2 x 64 (the compiler would otherwise hoist all 48 loads = 192 VGPRs).
     float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
-    f32x16 f2 = p3d_sample_plane(rs, g, 2u * g.plane_bytes, chan_off, g2x, g2y);
-    f32x16 X;
+    uint32_t of0[4], of1[4], of2[4];
+    float wg0[4], wg1[4], wg2[4];
+    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of0, wg0);
+    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of1, wg1);
+    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of2, wg2);
+    f32x16 a00 = p3d_load16(rs, of0[0]), a01 = p3d_load16(rs, of0[1]), a10 = p3d_load16(rs, of0[2]), a11 = p3d_load16(rs, of0[3]);
+    f32x16 b00 = p3d_load16(rs, of1[0]), b01 = p3d_load16(rs, of1[1]), b10 = p3d_load16(rs, of1[2]), b11 = p3d_load16(rs, of1[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 X = p3d_bilerp(wg0, a00, a01, a10, a11);
+    __builtin_amdgcn_sched_barrier(0);
+    a00 = p3d_load16(rs, of2[0]); a01 = p3d_load16(rs, of2[1]); a10 = p3d_load16(rs, of2[2]); a11 = p3d_load16(rs, of2[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x16 f1 = p3d_bilerp(wg1, b00, b01, b10, b11);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) X[c] = ((f0[c] + f1[c]) + f2[c]) * P3D_THIRD;  // triplane.py:530 mean(1)
+        for (int c = 0; c < 16; ++c) X[c] = X[c] + f1[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x16 f2 = p3d_bilerp(wg2, a00, a01, a10, a11);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) X[c] = (X[c] + f2[c]) * P3D_THIRD;  // triplane.py:530 mean(1)
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- layer 1 on the matrix cores: acc[t][r] = b0[n] + sum_k w0[n][k] X[k], n = 32t + rowof(r) + 4h
     const f32x4* b0p = (const f32x4*)(lds + P3D_LDS_B0P + h * 32);

@@ -144,7 +144,71 @@ P3D_DEV float p3d_march_weight(MarchState& st, float t, float sigma, float& tm_o
     return w;
 }
 
-__global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
+// Batcher odd-even merge sort network on N (power of two) register-resident keys; fully unrolled at compile time.
+template <int N>
+P3D_DEV void p3d_sort_network(float (&a)[N]) {
+#pragma unroll
+    for (int pp = 1; pp < N; pp <<= 1) {
+#pragma unroll
+        for (int k = pp; k >= 1; k >>= 1) {
+#pragma unroll
+            for (int jj = k % pp; jj + k < N; jj += 2 * k) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) {
+                    if (i + jj + k < N && (i + jj) / (2 * pp) == (i + jj + k) / (2 * pp)) {
+                        float x = a[i + jj], y = a[i + jj + k];
+                        a[i + jj] = __builtin_fminf(x, y);
+                        a[i + jj + k] = __builtin_fmaxf(x, y);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// insertion sort of rows [0, n) of a per-wave LDS column (generic / rare path)
+P3D_DEV void p3d_lds_insertion_sort(float* A, int n, int j) {
+    for (int i = 1; i < n; ++i) {
+        float key = A[i * 32 + j];
+        int q = i - 1;
+        while (q >= 0) {
+            float v = A[q * 32 + j];
+            if (!(v > key)) break;
+            A[(q + 1) * 32 + j] = v;
+            --q;
+        }
+        A[(q + 1) * 32 + j] = key;
+    }
+}
+
+// one inverse-CDF draw: renderer.py:371-386.  cdf rows [0, Ns], coarse depths tc rows [0, Sc)
+P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j, float ui, int& k_out) {
+    // k = #{q in 0..Ns : cdf[q] <= u}  (searchsorted right=True): branchless binary search on the non-decreasing cdf
+    const int n = Ns + 1;
+    int pos = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        int np = pos + step;
+        if (step <= n) {  // wave-uniform
+            bool ok = (np <= n) && (cdfA[((np <= n) ? np - 1 : 0) * 32 + j] <= ui);
+            pos = ok ? np : pos;
+        }
+    }
+    int k = pos;
+    int below = k - 1 > 0 ? k - 1 : 0;
+    int above = k < Ns ? k : Ns;
+    float cb = cdfA[below * 32 + j], ca = cdfA[above * 32 + j];
+    float den = ca - cb;
+    if (den < 1e-5f) den = 1.0f;
+    float bb = 0.5f * (tcA[below * 32 + j] + tcA[(below + 1) * 32 + j]);
+    float ba = 0.5f * (tcA[above * 32 + j] + tcA[(above + 1) * 32 + j]);
+    k_out = k;
+    return bb + ((ui - cb) / den) * (ba - bb);
+}
+
+// NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
+template <int NF>
+__global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
     __syncthreads();
@@ -183,26 +247,27 @@ __global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
     const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
 
     // LDS rows of this wave: row(i)[j]
-    float* tcA = wl;                    // [Sc]   coarse depths
-    float* wcA = tcA + Sc * 32;         // [Sc]   coarse weights, then pdf / cdf (row 0 = cdf[0])
-    float* tfA = tcA + (S > 2 * Sc ? S : 2 * Sc) * 32;  // [Sf] fine depths (draw order, then sorted)
-    float* mgA = tcA;                   // [S]    merged sorted depths, built in place over [tc | wc] (backward merge)
+    float* tcA = wl;             // [Sc]            coarse depths
+    float* wcA = tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
+    float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;  // [Sf] sorted fine depths
     const bool dump = active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
+    bool unsorted = false;
     {
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
+        float prev = -__builtin_inff();
         for (int i = 0; i < Sc; ++i) {
             float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
             float t = lin + jit[i] * p.depth_delta;
             tcA[i * 32 + j] = t;
+            unsorted |= (t < prev);
+            prev = t;
             if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
         }
     }
     float tmin = __builtin_inff(), tmax = -__builtin_inff();
-    const float* mg = tcA;
-    int Sm = Sc;
     if (Sf > 0) {
         // ---- coarse pass, densities only -> ray-marcher weights: renderer.py:179-211
         MarchState st;
@@ -245,87 +310,63 @@ __global__ __launch_bounds__(P3D_WG) void k_render(RenderParams p) {
                 wcA[(jj + 1) * 32 + j] = (float)acc;  // cdf[jj+1]
             }
         }
-        {
-            const float* uu = p.u + ray * Sf;
-            for (int i = 0; i < Sf; ++i) {
-                float ui = uu[i];
-                // k = #{q in 0..Ns : cdf[q] <= u}  (searchsorted right=True) — binary search on the non-decreasing cdf
-                int lo = 0, hi = Ns + 1;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (wcA[mid * 32 + j] <= ui) lo = mid + 1; else hi = mid;
+        const float* uu = p.u + ray * Sf;
+        if constexpr (NF > 0) {
+            float tf[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                tf[i] = __builtin_inff();
+                if (i < Sf) {  // wave-uniform
+                    int k;
+                    float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
+                    tf[i] = v;
+                    if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
+                    if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
                 }
-                int k = lo;
-                int below = k - 1 > 0 ? k - 1 : 0;
-                int above = k < Ns ? k : Ns;
-                float cb = wcA[below * 32 + j], ca = wcA[above * 32 + j];
-                float den = ca - cb;
-                if (den < 1e-5f) den = 1.0f;
-                float bb = 0.5f * (tcA[below * 32 + j] + tcA[(below + 1) * 32 + j]);
-                float ba = 0.5f * (tcA[above * 32 + j] + tcA[(above + 1) * 32 + j]);
-                float tf = bb + ((ui - cb) / den) * (ba - bb);
-                tfA[i * 32 + j] = tf;
-                if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = tf;
+            }
+            p3d_sort_network<NF>(tf);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (i < Sf) tfA[i * 32 + j] = tf[i];  // over the cdf rows: every search is done
+        } else {
+            for (int i = 0; i < Sf; ++i) {
+                int k;
+                float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
+                tfA[i * 32 + j] = v;
+                if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
                 if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
             }
+            p3d_lds_insertion_sort(tfA, Sf, j);
         }
-        // ---- unify_samples depths: sort fine (insertion), then stable merge with the coarse list: renderer.py:289-301
-        for (int i = 1; i < Sf; ++i) {
-            float key = tfA[i * 32 + j];
-            int q = i - 1;
-            while (q >= 0) {
-                float v = tfA[q * 32 + j];
-                if (!(v > key)) break;
-                tfA[(q + 1) * 32 + j] = v;
-                --q;
-            }
-            tfA[(q + 1) * 32 + j] = key;
-        }
-        {
-            // the coarse list is sorted unless rounding reversed two neighbours; insertion-sort it too (no-op when sorted)
-            for (int i = 1; i < Sc; ++i) {
-                float key = tcA[i * 32 + j];
-                int q = i - 1;
-                while (q >= 0) {
-                    float v = tcA[q * 32 + j];
-                    if (!(v > key)) break;
-                    tcA[(q + 1) * 32 + j] = v;
-                    --q;
-                }
-                tcA[(q + 1) * 32 + j] = key;
-            }
-            // backward merge into rows [0, S) (S <= 2*Sc rows are reserved): the write row m = ci + fi + 1 is never below
-            // an unread coarse row.  Ties: the coarse sample goes first (stable), i.e. the fine one is taken first here.
-            int ci = Sc - 1, fi = Sf - 1;
-            for (int m = S - 1; m >= 0; --m) {
-                float a = ci >= 0 ? tcA[ci * 32 + j] : -__builtin_inff();
-                float bq = fi >= 0 ? tfA[fi * 32 + j] : -__builtin_inff();
-                bool take_f = (fi >= 0) && (ci < 0 || bq >= a);
-                mgA[m * 32 + j] = take_f ? bq : a;
-                fi -= take_f ? 1 : 0;
-                ci -= take_f ? 0 : 1;
-            }
-        }
-        mg = mgA;
-        Sm = S;
+        // unify_samples (renderer.py:289-301) merges two sorted lists; the stratified list is sorted unless rounding
+        // reversed two neighbours (practically never) — then sort it too.
+        if (__builtin_amdgcn_ballot_w64(unsorted) != 0) p3d_lds_insertion_sort(tcA, Sc, j);
     }
-    // ---- final pass: decode every merged sample + composite [rgb | xyz]: renderer.py:243-259, ray_marcher.py:25-57
+    // ---- final pass: merge on the fly (ties: coarse first = stable), decode every sample, composite [rgb | xyz]:
+    //      renderer.py:243-259, ray_marcher.py:25-57
     MarchState st;
     st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
     f32x16 C, prev_rgb;
     float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
-    for (int m = 0; m < Sm; ++m) {
-        float t = mg[m * 32 + j];
+    int ci = 0, fi = 0;
+    float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
+    for (int m = 0; m < S; ++m) {
+        bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+        float t = take_c ? ta : tb;
+        ci += take_c ? 1 : 0;
+        fi += take_c ? 0 : 1;
+        if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
+        else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
         tmin = __builtin_fminf(tmin, t);
         tmax = __builtin_fmaxf(tmax, t);
         float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
         float sigma;
         f32x16 rgb;
         p3d_decode_wave<true>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
-        if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * Sm + m] = t;
-        if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * Sm + m] = sigma;
+        if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
+        if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * S + m] = sigma;
         if (m > 0) {
             float tm;
             float w = p3d_march_weight(st, t, sigma, tm);
@@ -625,8 +666,9 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         p.tiles_per_img = (R + 31) / 32;
     }
     p.ntiles = p.tiles_per_img * N;
-    // per-wave LDS rows: [tc | wc] (2*Sc, later the merged list of Sc+Sf) and tf (Sf)
-    p.lds_rows = (Sc + Sf > 2 * Sc ? Sc + Sf : 2 * Sc) + Sf;
+    // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
+    const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
+    p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0);
     int nwaves = P3D_WAVES_PER_WG;
     size_t lds_bytes;
     for (;; nwaves >>= 1) {
@@ -635,10 +677,14 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         if (nwaves == 1) return P3D_E_RANGE;
     }
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
-    hipError_t e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const void* kfn = nf == 64 ? (const void*)k_render<64> : nf == 128 ? (const void*)k_render<128> : (const void*)k_render<0>;
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return (int)e;
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
-    hipLaunchKernelGGL(k_render, dim3((unsigned)blocks), dim3(64 * nwaves), lds_bytes, st, p);
+    dim3 grid((unsigned)blocks), blk(64 * nwaves);
+    if (nf == 64) hipLaunchKernelGGL(k_render<64>, grid, blk, lds_bytes, st, p);
+    else if (nf == 128) hipLaunchKernelGGL(k_render<128>, grid, blk, lds_bytes, st, p);
+    else hipLaunchKernelGGL(k_render<0>, grid, blk, lds_bytes, st, p);
     int rc = p3d_check_launch();
     if (rc) return rc;
     long long NR = (long long)N * R;
