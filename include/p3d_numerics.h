@@ -27,13 +27,13 @@
 #define P3D_NUMERICS_H
 
 /* ---- p3d_exp(x) ---------------------------------------------------------------------------
- *   x != x            -> x
- *   x <  P3D_EXP_LO   -> 0
+ *   x <  P3D_EXP_LO   -> 0          (the ldexp below would give 0 anyway; stated so that (int)n never overflows)
  *   x >  P3D_EXP_HI   -> +inf
  *   n = rint(x * P3D_LOG2E);  r = fma(n, -P3D_LN2_HI, x);  r = fma(n, -P3D_LN2_LO, r);
- *   p = C6; p = fma(p,r,C5); ... p = fma(p,r,C0);   result = p * 2^n   (2^n built from bits)
- * max error ~1.2 ulp. */
-#define P3D_EXP_LO   (-87.0f)
+ *   p = C6; p = fma(p,r,C5); ... p = fma(p,r,C0);   result = ldexp(p, (int)n)
+ *   (ldexp = exact scaling by 2^n with IEEE round-to-nearest-even into the subnormal range: C ldexpf, v_ldexp_f32)
+ *   NaN in -> NaN out.   max error ~1.2 ulp. */
+#define P3D_EXP_LO   (-200.0f)
 #define P3D_EXP_HI   (88.0f)
 #define P3D_LOG2E    0x1.715476p+0f   /* 1.44269502 */
 #define P3D_LN2_HI   0x1.63p-1f       /* 0.693359375 */

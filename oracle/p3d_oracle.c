@@ -49,9 +49,7 @@ static inline float or_exp(float x) {
     p = fmaf(p, r, P3D_EXP_C2);
     p = fmaf(p, r, P3D_EXP_C1);
     p = fmaf(p, r, P3D_EXP_C0);
-    union { uint32_t u; float f; } s;
-    s.u = (uint32_t)((int)n + 127) << 23;
-    return p * s.f;
+    return ldexpf(p, (int)n);
 }
 
 static inline float or_log1p01(float z) {

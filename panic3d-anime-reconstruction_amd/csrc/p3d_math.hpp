@@ -16,8 +16,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 P3D_DEV float p3d_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// exp(x): range reduction by ln2 (two-part constant) + degree-6 polynomial, result scaled by 2^n built from bits.
-P3D_DEV float p3d_exp(float x) {
+// exp(x): range reduction by ln2 (two-part constant) + degree-6 polynomial, scaled by v_ldexp_f32 (exact 2^n scaling,
+// IEEE rounding into subnormals, saturating integer conversion) — no clamps needed for x <= 0: the result underflows to 0.
+P3D_DEV float p3d_exp_core(float x) {
     float n = __builtin_rintf(x * P3D_LOG2E);
     float r = p3d_fma(n, -P3D_LN2_HI, x);
     r = p3d_fma(n, -P3D_LN2_LO, r);
@@ -28,30 +29,21 @@ P3D_DEV float p3d_exp(float x) {
     p = p3d_fma(p, r, P3D_EXP_C2);
     p = p3d_fma(p, r, P3D_EXP_C1);
     p = p3d_fma(p, r, P3D_EXP_C0);
-    float s = __builtin_bit_cast(float, (uint32_t)((int)n + 127) << 23);
-    float y = p * s;
-    y = (x < P3D_EXP_LO) ? 0.0f : y;
-    y = (x > P3D_EXP_HI) ? __builtin_inff() : y;
-    return (x != x) ? x : y;
+    return __builtin_ldexpf(p, (int)n);
 }
 
-// exp(x) for x known to be <= 0 and not NaN-sensitive beyond propagation (softplus / sigmoid / alpha paths):
-// identical value to p3d_exp on that domain (the x > HI select can never fire).
-P3D_DEV float p3d_exp_nonpos(float x) {
-    float n = __builtin_rintf(x * P3D_LOG2E);
-    float r = p3d_fma(n, -P3D_LN2_HI, x);
-    r = p3d_fma(n, -P3D_LN2_LO, r);
-    float p = P3D_EXP_C6;
-    p = p3d_fma(p, r, P3D_EXP_C5);
-    p = p3d_fma(p, r, P3D_EXP_C4);
-    p = p3d_fma(p, r, P3D_EXP_C3);
-    p = p3d_fma(p, r, P3D_EXP_C2);
-    p = p3d_fma(p, r, P3D_EXP_C1);
-    p = p3d_fma(p, r, P3D_EXP_C0);
-    float s = __builtin_bit_cast(float, (uint32_t)((int)n + 127) << 23);
-    float y = p * s;
+// general argument (the alpha path: -(rho*dl) can be positive when depths are not sorted)
+P3D_DEV float p3d_exp(float x) {
+    float y = p3d_exp_core(x);
     y = (x < P3D_EXP_LO) ? 0.0f : y;
-    return (x != x) ? x : y;
+    return (x > P3D_EXP_HI) ? __builtin_inff() : y;
+}
+
+// x <= 0 (or NaN, which propagates): softplus / sigmoid / cull paths.  For x < P3D_EXP_LO the ldexp underflows to 0, which
+// is the contract's value, so no select is needed; x = -inf is the one input that needs it (inf - inf in the reduction).
+P3D_DEV float p3d_exp_nonpos(float x) {
+    float y = p3d_exp_core(x);
+    return (x < P3D_EXP_LO) ? 0.0f : y;
 }
 
 P3D_DEV float p3d_log1p01(float z) {

@@ -109,6 +109,7 @@ def test_contract_math_accuracy(oracle):
     assert (np.abs(oracle.math_fn("softplus", x) - sp) / np.maximum(1, sp)).max() < 3e-7
     assert np.abs(oracle.math_fn("sigmoid", x) - 1 / (1 + np.exp(-x.astype(np.float64)))).max() < 2e-7
     # special values of the contract
-    sv = oracle.math_fn("exp", np.array([-1000.0, -87.5, 0.0, 89.0, np.nan], np.float32))
-    assert sv[0] == 0 and sv[1] == 0 and sv[2] == 1 and np.isinf(sv[3]) and np.isnan(sv[4])
+    sv = oracle.math_fn("exp", np.array([-1000.0, -87.5, 0.0, 89.0, np.nan, -150.0], np.float32))
+    assert sv[0] == 0 and sv[2] == 1 and np.isinf(sv[3]) and np.isnan(sv[4]) and sv[5] == 0
+    assert abs(float(sv[1]) / np.exp(-87.5) - 1) < 1e-5  # gradual underflow through ldexp (subnormal result)
     assert oracle.math_fn("softplus", np.array([25.0], np.float32))[0] == 25.0
