@@ -11,11 +11,13 @@
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see panic3d-anime-reconstruction_amd/_build.py).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "p3d_decode.hpp"
 
 #define P3D_WAVES_PER_WG 4
+#define P3D_RENDER_WAVES 4  // k_render workgroup (two workgroups per CU -> two waves per SIMD)
 #define P3D_WG (64 * P3D_WAVES_PER_WG)
 
 // =====================================================================================================================
@@ -207,8 +209,10 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 }
 
 // NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
-template <int NF>
-__global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
+// PIPE: 0 = two waves per SIMD (<= 256 VGPRs), 1 = one software-pipelined wave per SIMD (p3d_decode_stream).
+// DUMP: per-stage dumps (parity tests).
+template <int NF, int PIPE, bool DUMP>
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_render(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
     __syncthreads();
@@ -228,7 +232,10 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
     long long r;
     if (p.tile_w > 0) {
         long long ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
-        r = (ty * 4 + (j >> 3)) * p.tile_w + tx * 8 + (j & 7);
+        // 8x4 pixel tile in Morton-like lane order: every lane quad is a 2x2 pixel block, so the quad's four gathers of a
+        // tap fall into 1-2 cache lines (the L1 coalesces within a quad; rocprof: TCP accesses/instr 48 -> see DESIGN.md)
+        const int lx = (j & 1) | ((j >> 1) & 6), ly = ((j >> 1) & 1) | ((j >> 3) & 2);
+        r = (ty * 4 + ly) * p.tile_w + tx * 8 + lx;
     } else {
         r = tl * 32 + j;
     }
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
     unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
     const float* pbase = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
+    const P3dDecodeCfg cfg = p.cfg;
 
     const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
     const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
     float* tcA = wl;             // [Sc]            coarse depths
     float* wcA = tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
     float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;  // [Sf] sorted fine depths
-    const bool dump = active && h == 0;
+    const bool dump = DUMP && active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
     bool unsorted = false;
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
             tcA[i * 32 + j] = t;
             unsorted |= (t < prev);
             prev = t;
-            if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
+            if constexpr (DUMP) if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
         }
     }
     float tmin = __builtin_inff(), tmax = -__builtin_inff();
@@ -272,21 +280,21 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
         // ---- coarse pass, densities only -> ray-marcher weights: renderer.py:179-211
         MarchState st;
         st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
-        for (int i = 0; i < Sc; ++i) {
-            float t = tcA[i * 32 + j];
-            float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
-            float sigma;
-            f32x16 dummy;
-            p3d_decode_wave<false>(lds, rs, g, p.cfg, px, py, pz, sigma, dummy);
-            if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
-            if (i > 0) {
-                float tm;
-                float w = p3d_march_weight(st, t, sigma, tm);
-                wcA[(i - 1) * 32 + j] = w;
-                if (dump && p.dumps.weights_coarse) p.dumps.weights_coarse[ray * (Sc - 1) + i - 1] = w;
-            }
+        int ci = 0;
+        auto next_t = [&]() { float t = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j]; ++ci; return t; };
+        auto consume = [&](int i, float t, float px, float py, float pz, float sigma, const f32x16& rgb) {
+            (void)px; (void)py; (void)pz; (void)rgb;
+            if constexpr (DUMP) if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
+            // interval (i-1, i); for i == 0 the state holds dummies: the weight lands in row 0 and is overwritten by i == 1
+            float tm;
+            MarchState s2 = st;
+            float w = p3d_march_weight(s2, t, sigma, tm);
+            st.Td = (i > 0) ? s2.Td : st.Td;
+            wcA[(i > 0 ? i - 1 : 0) * 32 + j] = w;
+            if constexpr (DUMP) if (dump && i > 0 && p.dumps.weights_coarse) p.dumps.weights_coarse[ray * (Sc - 1) + i - 1] = w;
             st.prev_t = t; st.prev_sigma = sigma;
-        }
+        };
+        p3d_decode_stream<false, PIPE>(lds, rs, g, cfg, ox, oy, oz, dx, dy, dz, Sc, next_t, consume);
         // ---- sample_importance / sample_pdf: renderer.py:328-387 (per ray; both lanes of a pair compute the same)
         const int Ns = Sc - 3;
         {
@@ -320,8 +328,10 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
                     int k;
                     float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
                     tf[i] = v;
-                    if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
-                    if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+                    if constexpr (DUMP) {
+                        if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
+                        if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+                    }
                 }
             }
             p3d_sort_network<NF>(tf);
@@ -333,8 +343,10 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
                 int k;
                 float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
                 tfA[i * 32 + j] = v;
-                if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
-                if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+                if constexpr (DUMP) {
+                    if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
+                    if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+                }
             }
             p3d_lds_insertion_sort(tfA, Sf, j);
         }
@@ -350,37 +362,45 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
     float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
-    int ci = 0, fi = 0;
-    float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
-    for (int m = 0; m < S; ++m) {
-        bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
-        float t = take_c ? ta : tb;
-        ci += take_c ? 1 : 0;
-        fi += take_c ? 0 : 1;
-        if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
-        else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
-        tmin = __builtin_fminf(tmin, t);
-        tmax = __builtin_fmaxf(tmax, t);
-        float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
-        float sigma;
-        f32x16 rgb;
-        p3d_decode_wave<true>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
-        if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
-        if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * S + m] = sigma;
-        if (m > 0) {
+    {
+        int ci = 0, fi = 0;
+        float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
+        auto next_t = [&]() {
+            bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+            float t = take_c ? ta : tb;
+            ci += take_c ? 1 : 0;
+            fi += take_c ? 0 : 1;
+            float na = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
+            float nb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
+            ta = take_c ? na : ta;
+            tb = take_c ? tb : nb;
+            return t;
+        };
+        auto consume = [&](int m, float t, float px, float py, float pz, float sigma, const f32x16& rgb) {
+            tmin = __builtin_fminf(tmin, t);
+            tmax = __builtin_fmaxf(tmax, t);
+            if constexpr (DUMP) {
+                if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
+                if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * S + m] = sigma;
+            }
+            // interval (m-1, m); m == 0 has no interval: its weight is forced to 0 and the transmittance kept
             float tm;
-            float w = p3d_march_weight(st, t, sigma, tm);
+            MarchState s2 = st;
+            float w = p3d_march_weight(s2, t, sigma, tm);
+            w = (m > 0) ? w : 0.0f;
+            st.Td = (m > 0) ? s2.Td : st.Td;
 #pragma unroll
             for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
             Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
             Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
             Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
             st.W = st.W + w;
-            st.D = p3d_fma(w, tm, st.D);
-        }
-        st.prev_t = t; st.prev_sigma = sigma;
-        prev_rgb = rgb;
-        ppx = px; ppy = py; ppz = pz;
+            st.D = p3d_fma(w, (m > 0) ? tm : 0.0f, st.D);
+            st.prev_t = t; st.prev_sigma = sigma;
+            prev_rgb = rgb;
+            ppx = px; ppy = py; ppz = pz;
+        };
+        p3d_decode_stream<true, PIPE>(lds, rs, g, cfg, ox, oy, oz, dx, dy, dz, S, next_t, consume);
     }
     // ---- outputs.  white_back and the [-1,1] rescale are per ray (ray_marcher.py:52-55); the depth clamp is global.
     {
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_render(RenderParams p) {
                 p.out_depth[ray] = d;  // clamped by k_render_finish
                 p.out_wsum[ray] = Wt;  // weights.sum(2): renderer.py:264
                 p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz;
-                if (p.dumps.depth_unclamped) p.dumps.depth_unclamped[ray] = st.D / Wt;
+                if constexpr (DUMP) if (p.dumps.depth_unclamped) p.dumps.depth_unclamped[ray] = st.D / Wt;
             }
         }
     }
@@ -669,7 +689,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
     const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
     p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0);
-    int nwaves = P3D_WAVES_PER_WG;
+    int nwaves = P3D_RENDER_WAVES;
     size_t lds_bytes;
     for (;; nwaves >>= 1) {
         lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
@@ -677,14 +697,33 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         if (nwaves == 1) return P3D_E_RANGE;
     }
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
-    const void* kfn = nf == 64 ? (const void*)k_render<64> : nf == 128 ? (const void*)k_render<128> : (const void*)k_render<0>;
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return (int)e;
+    // PIPE = 1 (one software-pipelined wave per SIMD, p3d_decode_stream) measured 11.1 ms vs 5.6 ms for PIPE = 0 on
+    // MI355X (the compiler spills and does not interleave one wave's MFMA and VALU streams); build with
+    // -DP3D_ENABLE_PIPE1 to instantiate it again and select it with P3D_PIPE=1.
+#ifdef P3D_ENABLE_PIPE1
+    const char* pe = getenv("P3D_PIPE");
+    const int pipe = pe ? atoi(pe) : 0;
+#endif
+    const bool dmp = dumps != nullptr;
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
     dim3 grid((unsigned)blocks), blk(64 * nwaves);
-    if (nf == 64) hipLaunchKernelGGL(k_render<64>, grid, blk, lds_bytes, st, p);
-    else if (nf == 128) hipLaunchKernelGGL(k_render<128>, grid, blk, lds_bytes, st, p);
-    else hipLaunchKernelGGL(k_render<0>, grid, blk, lds_bytes, st, p);
+    hipError_t e = hipSuccess;
+#define P3D_LAUNCH(NFV, PV, DV)                                                                                      \
+    do {                                                                                                             \
+        e = hipFuncSetAttribute((const void*)k_render<NFV, PV, DV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)lds_bytes);                                                                     \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, PV, DV>), grid, blk, lds_bytes, st, p);              \
+    } while (0)
+#define P3D_LAUNCH_D(NFV, PV) do { if (dmp) P3D_LAUNCH(NFV, PV, true); else P3D_LAUNCH(NFV, PV, false); } while (0)
+#ifdef P3D_ENABLE_PIPE1
+#define P3D_LAUNCH_P(NFV) do { if (pipe) P3D_LAUNCH_D(NFV, 1); else P3D_LAUNCH_D(NFV, 0); } while (0)
+#else
+#define P3D_LAUNCH_P(NFV) P3D_LAUNCH_D(NFV, 0)
+#endif
+    if (nf == 64) P3D_LAUNCH_P(64);
+    else if (nf == 128) P3D_LAUNCH_P(128);
+    else P3D_LAUNCH_P(0);
+    if (e != hipSuccess) return (int)e;
     int rc = p3d_check_launch();
     if (rc) return rc;
     long long NR = (long long)N * R;

@@ -61,12 +61,18 @@ P3D_DEV float p3d_log1p01(float z) {
 
 // torch Softplus(beta=1, threshold=20)
 P3D_DEV float p3d_softplus(float x) {
+#ifdef P3D_ABL_NOTRANS  // timing experiment: no transcendental polynomials
+    return __builtin_fmaxf(x, 0.0f);
+#endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
     float y = __builtin_fmaxf(x, 0.0f) + p3d_log1p01(z);
     return (x > P3D_SOFTPLUS_THRESHOLD) ? x : y;
 }
 
 P3D_DEV float p3d_sigmoid(float x) {
+#ifdef P3D_ABL_NOTRANS
+    return x * 0.25f + 0.5f;
+#endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
     float d = 1.0f + z;
     float num = (x >= 0.0f) ? 1.0f : z;
