@@ -114,6 +114,31 @@ int p3d_importance_f32(const float* depths, const float* weights, int64_t NR, in
 int p3d_unify_perm_f32(const float* depths_coarse, const float* depths_fine, int64_t NR, int Sc, int Sf, int32_t* perm,
                        void* stream);
 
+/* ---- StyleGAN2 synthesis operators of the triplane backbone (training/networks_stylegan2.py) ------------------------ */
+
+/* modulated_conv2d (networks_stylegan2.py:40-97) + the bias_act that follows it in SynthesisLayer.forward (:350-352) /
+ * ToRGBLayer.forward (:376-380), fused.  x [N][I][H][W]; w [O][I][ks][ks] (ks 3 or 1); styles [N][I];
+ * demodulate: multiply the output by rsqrt(sum (w*s)^2 + 1e-8) (:70-73); noise: NULL, [OH*OW] (noise_const * strength)
+ * or [N][OH*OW] (noise_per_sample = 1), added before the bias (:95-96); bias [O] or NULL; up 1 or 2 (up = 2: stride-2
+ * transposed conv + 4x4 FIR `fir` = setup_filter([1,3,3,1]) flipped and multiplied by up^2, conv2d_resample.py:114-128);
+ * act 0 linear / 1 lrelu(alpha); then *gain and clamp (< 0: none) as bias_act.py:93-122.  y [N][O][H*up][W*up]. */
+size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up);
+int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
+                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
+                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
+ * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by
+ * `down`.  x [NC][H][W] -> y [NC][(H*up+pady0+pady1-fh)/down+1][(W*up+padx0+padx1-fw)/down+1]. */
+int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,
+                      int padx1, int pady0, int pady1, float* y, void* stream);
+
+/* bias_act (torch_utils/ops/bias_act.py:54-88; plugin signature bias_act.cpp:36): y = clamp(act(x + b[c]) * gain), x viewed
+ * as [outer][C][inner]; act 0 linear / 1 lrelu(alpha); b may be NULL; clamp < 0: none. */
+int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64_t inner, int act, float alpha, float gain,
+                     float clamp, float* y, void* stream);
+
 /* Library / build identification ("gfx950"). */
 const char* p3d_build_info(void);
 

@@ -1,0 +1,312 @@
+// p3d_synthesis.hip — StyleGAN2 synthesis operators of the triplane backbone on gfx950 (MI355X).
+//
+//   k_modconv<MODE>   modulated convolution as an implicit GEMM on the matrix cores (v_mfma_f32_32x32x2_f32; exact f32):
+//                     D[o][pixel] = sum_k W[o][k] * (s[n,i(k)] * x[n,i(k),y+dy(k),x+dx(k)])
+//                     A = weights (LDS tile [k][64 o]), B = modulated input patch (LDS tile [8 ic][10][18] with halo),
+//                     4 waves = 2 (32-channel halves) x 2 (64-pixel halves), 2 accumulators per wave.
+//                     MODE 0: 3x3 / pad 1 correlation   (conv1 of every block, networks_stylegan2.py:93 -> conv2d_resample.py:136)
+//                     MODE 1: 1x1                       (ToRGB, networks_stylegan2.py:378)
+//                     MODE 2-5: the four output phases of the stride-2 transposed 3x3 conv (conv0, conv2d_resample.py:114-127);
+//                               only the taps that meet non-zero inputs are multiplied (4/2/2/1 of 9), i.e. no zero-insertion.
+//                     The per-sample weights w*s*d of the reference's fused path (networks_stylegan2.py:68-73) are refactored
+//                     into shared weights, input scaling by s and output scaling by d (its own non-fused path, :76-85).
+//   k_demod           d[n,o] = rsqrt(sum_{i,t} (w[o,i,t] s[n,i])^2 + 1e-8)              (networks_stylegan2.py:70-71)
+//   k_upfirdn2d       zero-insert x up, pad/crop, FIR, with an optional fused epilogue d*v + noise -> +bias -> act*gain -> clamp
+//                     (upfirdn2d.py:169-213 _upfirdn2d_ref; bias_act.py:93-122 _bias_act_ref)
+//   k_bias_act        clamp(act(x + b) * gain)                                            (bias_act.py:93-122)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/panic3d_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define DEV __device__ __forceinline__
+
+#define CONV_TH 8
+#define CONV_TW 16
+#define CONV_IC 8
+#define CONV_OT 64
+#define XS_ROW (CONV_TW + 2)
+#define XS_PLANE ((CONV_TH + 2) * XS_ROW)
+#define WS_ROW (CONV_OT + 1)
+
+template <int MODE> struct ConvTaps;
+// dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
+template <> struct ConvTaps<0> { static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
+template <> struct ConvTaps<1> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
+// transposed conv, out (2y+py, 2x+px) = sum over (ky,kx) with ky == py, kx == px (mod 2) of w[ky][kx] * x[y - ky/2][x - kx/2]
+template <> struct ConvTaps<2> { static constexpr int N = 4; static constexpr int dy[4] = {0,0,-1,-1}; static constexpr int dx[4] = {0,-1,0,-1}; static constexpr int kidx[4] = {0,2,6,8}; static constexpr int py = 0, px = 0, ostride = 2; };
+template <> struct ConvTaps<3> { static constexpr int N = 2; static constexpr int dy[2] = {0,-1}; static constexpr int dx[2] = {0,0}; static constexpr int kidx[2] = {1,7}; static constexpr int py = 0, px = 1, ostride = 2; };
+template <> struct ConvTaps<4> { static constexpr int N = 2; static constexpr int dy[2] = {0,0}; static constexpr int dx[2] = {0,-1}; static constexpr int kidx[2] = {3,5}; static constexpr int py = 1, px = 0, ostride = 2; };
+template <> struct ConvTaps<5> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {4}; static constexpr int py = 1, px = 1, ostride = 2; };
+
+struct ConvParams {
+    const float* x;       // [N][I][H][W]
+    const float* w;       // [O][I][ks][ks]
+    const float* styles;  // [N][I]
+    const float* dcoef;   // [N][O] or null
+    const float* noise;   // [OH*OW] (shared) or [N][OH*OW] or null; already multiplied by noise_strength
+    const float* bias;    // [O] or null
+    float* y;             // [N][O][OH][OW]
+    int N, I, O, H, W;    // input dims
+    int GH, GW;           // output grid of this launch (phase grid for MODE >= 2)
+    int OH, OW;           // output tensor dims
+    int ks;               // kernel size of w (1 or 3)
+    int noise_per_sample;
+    int act;              // 0 linear, 1 lrelu
+    float alpha, gain, clamp;
+    int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
+};
+
+DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
+    if (act == 1) v = v < 0.0f ? v * alpha : v;
+    v = v * gain;
+    if (clamp >= 0.0f) v = __builtin_fminf(__builtin_fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
+    using T = ConvTaps<MODE>;
+    constexpr int NT = T::N;
+    constexpr int KC = CONV_IC * NT;  // k values per chunk
+    __shared__ float xs[CONV_IC * XS_PLANE];
+    __shared__ float ws[KC * WS_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * CONV_OT, n = blockIdx.z;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+    const int kk9 = p.ks * p.ks;
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    // this lane's pixel inside the tile for the two N tiles: rows 4wp + 2t + (j>>4), col j & 15
+    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
+    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;          // N tile 0 (halo origin at +1,+1)
+    const int pix1 = pix0 + 2 * XS_ROW;                        // N tile 1 (two rows below)
+    const int wcol = wc * 32 + j;
+
+    for (int ic0 = 0; ic0 < p.I; ic0 += CONV_IC) {
+        __syncthreads();
+        // ---- stage the modulated input patch: xs[ic][r][c] = s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c]  (zero outside)
+        for (int idx = tid; idx < CONV_IC * XS_PLANE; idx += 256) {
+            int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
+            int r = rem / XS_ROW, c = rem - r * XS_ROW;
+            int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
+            float v = 0.0f;
+            if (ci < p.I && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
+            xs[idx] = v;
+        }
+        // ---- stage the weights: ws[k][o] = w[o0+o][ic0 + k/NT][kidx[k%NT]]
+        for (int idx = tid; idx < KC * CONV_OT; idx += 256) {
+            int o = idx / KC, k = idx - o * KC;
+            int ic = k / NT, t = k - ic * NT;
+            int ci = ic0 + ic, oo = o0 + o;
+            float v = 0.0f;
+            if (ci < p.I && oo < p.O) v = p.w[((size_t)oo * p.I + ci) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])];
+            ws[k * WS_ROW + o] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KC / 2; ++q) {
+            // lanes 0-31 take k = 2q, lanes 32-63 take k = 2q+1  (A[i][k], B[k][j] operand layout of 32x32x2)
+            const int k0 = 2 * q, k1 = 2 * q + 1;
+            const int xo0 = (k0 / NT) * XS_PLANE + T::dy[k0 % NT] * XS_ROW + T::dx[k0 % NT];
+            const int xo1 = (k1 / NT) * XS_PLANE + T::dy[k1 % NT] * XS_ROW + T::dx[k1 % NT];
+            const int xo = half ? xo1 : xo0;
+            const int kk = half ? k1 : k0;
+            float a = ws[kk * WS_ROW + wcol];
+            float b0 = xs[xo + pix0];
+            float b1 = xs[xo + pix1];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+        if (gy >= p.GH || gx >= p.GW) continue;
+        const int oy = gy * T::ostride + T::py, ox = gx * T::ostride + T::px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ch >= p.O) continue;
+            float v = t ? acc1[r] : acc0[r];
+            if (p.epilogue) {
+                if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
+                if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)oy * p.OW + ox];
+                if (p.bias) v = v + p.bias[ch];
+                v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+            }
+            p.y[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
+        }
+    }
+}
+
+// d[n,o] = rsqrt(sum_i (sum_t w[o,i,t]^2) * s[n,i]^2 + 1e-8).  One wave per (n,o).
+__global__ void k_demod(const float* __restrict__ w, const float* __restrict__ s, int N, int O, int I, int kk, float* d) {
+    int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= N * O) return;
+    int n = wid / O, o = wid - n * O;
+    float acc = 0.0f;
+    for (int i = lane; i < I; i += 64) {
+        float sv = s[(size_t)n * I + i];
+        const float* wp = w + ((size_t)o * I + i) * kk;
+        float q = 0.0f;
+        for (int t = 0; t < kk; ++t) { float v = wp[t] * sv; q = __builtin_fmaf(v, v, q); }
+        acc += q;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) d[wid] = 1.0f / __builtin_sqrtf(acc + 1e-8f);
+}
+
+struct FirParams {
+    const float* x;  // [NC][H][W]
+    const float* f;  // [fh][fw], already flipped for convolution and multiplied by gain
+    float* y;        // [NC][OH][OW]
+    const float* dcoef;  // [NC] (= [N][C]) or null
+    const float* noise;  // [OH*OW] or [N][OH*OW] or null
+    const float* bias;   // [C] or null
+    long long NC;
+    int C, H, W, OH, OW, fh, fw, up, down, padx0, pady0;
+    int noise_per_sample, act, epilogue;
+    float alpha, gain, clamp;
+};
+
+// y[Y][X] = sum_{fy,fx} f[fy][fx] * xz[Y*down + fy - pady0][X*down + fx - padx0],  xz = zero-inserted x (xz[u*up][v*up] = x[u][v])
+__global__ void k_upfirdn2d(FirParams p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = p.NC * p.OH * p.OW;
+    if (idx >= total) return;
+    int X = (int)(idx % p.OW);
+    int Y = (int)((idx / p.OW) % p.OH);
+    long long nc = idx / ((long long)p.OW * p.OH);
+    const float* xc = p.x + nc * p.H * p.W;
+    float acc = 0.0f;
+    for (int fy = 0; fy < p.fh; ++fy) {
+        int u = Y * p.down + fy - p.pady0;
+        if (u < 0 || u % p.up) continue;
+        u /= p.up;
+        if (u >= p.H) continue;
+        for (int fx = 0; fx < p.fw; ++fx) {
+            int v = X * p.down + fx - p.padx0;
+            if (v < 0 || v % p.up) continue;
+            v /= p.up;
+            if (v >= p.W) continue;
+            acc = __builtin_fmaf(p.f[fy * p.fw + fx], xc[(size_t)u * p.W + v], acc);
+        }
+    }
+    if (p.epilogue) {
+        int c = (int)(nc % p.C);
+        long long n = nc / p.C;
+        if (p.dcoef) acc = acc * p.dcoef[nc];
+        if (p.noise) acc = acc + p.noise[(p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + X];
+        if (p.bias) acc = acc + p.bias[c];
+        acc = act_apply(acc, p.act, p.alpha, p.gain, p.clamp);
+    }
+    p.y[idx] = acc;
+}
+
+// x viewed as [outer][C][inner]
+__global__ void k_bias_act(const float* __restrict__ x, const float* __restrict__ b, long long total, int C, long long inner,
+                           int act, float alpha, float gain, float clamp, float* __restrict__ y) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float v = x[idx];
+    if (b) v = v + b[(idx / inner) % C];
+    y[idx] = act_apply(v, act, alpha, gain, clamp);
+}
+
+static inline int chk() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? P3D_OK : (int)e;
+}
+
+template <int MODE>
+static void launch_conv(ConvParams p, hipStream_t st) {
+    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + CONV_OT - 1) / CONV_OT, p.N);
+    hipLaunchKernelGGL(k_modconv<MODE>, grid, dim3(256), 0, st, p);
+}
+
+extern "C" {
+
+size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) {
+    (void)I;
+    size_t b = (size_t)N * O * 4 + 256;  // demodulation coefficients
+    if (up == 2) b += (size_t)N * O * (2 * H + 1) * (2 * W + 1) * 4;  // transposed-conv intermediate
+    return b;
+}
+
+int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
+                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
+                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!x || !w || !styles || !y || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if (!((ks == 3 && (up == 1 || up == 2)) || (ks == 1 && up == 1))) return P3D_E_RANGE;
+    if (up == 2 && !fir) return P3D_E_ARG;
+    if (workspace_bytes < p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)) return P3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* dco = (float*)workspace;
+    float* tmp = dco + (((size_t)N * O + 63) / 64) * 64;
+    if (demodulate) {
+        int waves = N * O;
+        hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
+    }
+    ConvParams p;
+    p.x = x; p.w = w; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias; p.y = y;
+    p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    if (up == 1) {
+        p.GH = H; p.GW = W; p.OH = H; p.OW = W; p.epilogue = 1;
+        if (ks == 3) launch_conv<0>(p, st); else launch_conv<1>(p, st);
+        return chk();
+    }
+    // up == 2: stride-2 transposed conv into tmp [N][O][2H+1][2W+1] (4 phases), then FIR (pad 1, gain) + epilogue
+    p.y = tmp; p.OH = 2 * H + 1; p.OW = 2 * W + 1; p.epilogue = 0;
+    p.GH = H + 1; p.GW = W + 1; launch_conv<2>(p, st);
+    p.GH = H + 1; p.GW = W;     launch_conv<3>(p, st);
+    p.GH = H;     p.GW = W + 1; launch_conv<4>(p, st);
+    p.GH = H;     p.GW = W;     launch_conv<5>(p, st);
+    FirParams q;
+    q.x = tmp; q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
+    q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
+    q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
+    q.alpha = alpha; q.gain = gain; q.clamp = clamp;
+    // the caller passes the 4x4 filter already flipped and multiplied by up^2 (upfirdn2d.py:193-196)
+    long long total = q.NC * q.OH * q.OW;
+    hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
+    return chk();
+}
+
+int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,
+                      int padx1, int pady0, int pady1, float* y, void* stream) {
+    if (!x || !f || !y || NC <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if (up < 1 || down < 1 || fh < 1 || fw < 1 || fh > 32 || fw > 32) return P3D_E_RANGE;
+    FirParams q;
+    q.x = x; q.f = f; q.y = y; q.dcoef = nullptr; q.noise = nullptr; q.bias = nullptr;
+    q.NC = NC; q.C = 1; q.H = H; q.W = W;
+    q.OH = (H * up + pady0 + pady1 - fh) / down + 1;
+    q.OW = (W * up + padx0 + padx1 - fw) / down + 1;
+    if (q.OH <= 0 || q.OW <= 0) return P3D_E_RANGE;
+    q.fh = fh; q.fw = fw; q.up = up; q.down = down; q.padx0 = padx0; q.pady0 = pady0;
+    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1;
+    long long total = q.NC * q.OH * q.OW;
+    hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
+    return chk();
+}
+
+int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64_t inner, int act, float alpha, float gain,
+                     float clamp, float* y, void* stream) {
+    if (!x || !y || outer <= 0 || C <= 0 || inner <= 0) return P3D_E_ARG;
+    if (act != 0 && act != 1) return P3D_E_RANGE;
+    long long total = outer * C * inner;
+    hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, b, total, C,
+                       (long long)inner, act, alpha, gain, clamp, y);
+    return chk();
+}
+
+}  // extern "C"

@@ -229,3 +229,118 @@ def unify_perm(depths_coarse, depths_fine):
         rc = _lib.lib().p3d_unify_perm_f32(_p(dc), _p(df), NR, Sc, Sf, _p(perm), _stream())
     _lib.check(rc, "p3d_unify_perm_f32")
     return perm
+
+
+# ======================================================================================================================
+# StyleGAN2 synthesis operators (torch_utils/ops/{bias_act,upfirdn2d,conv2d_resample}.py, networks_stylegan2.py:40-97)
+# ======================================================================================================================
+_ACTS = {"linear": (0, 0.0, 1.0), "lrelu": (1, 0.2, float(np.sqrt(2)))}  # bias_act.py:23-33: index, def_alpha, def_gain
+
+
+def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None):
+    """bias_act.bias_act (bias_act.py:54-88): clamp(act(x + b) * gain).  Only 'linear' and 'lrelu' are on the hot path."""
+    x = _chk(x, "x")
+    if act not in _ACTS:
+        raise NotImplementedError(f"activation {act!r} is not used by the PAniC-3D generator")
+    assert clamp is None or clamp >= 0  # bias_act.py:98
+    idx, da, dg = _ACTS[act]
+    alpha = float(alpha if alpha is not None else da)
+    gain = float(gain if gain is not None else dg)
+    clamp = float(clamp if clamp is not None else -1)
+    if b is not None:
+        b = _chk(b, "b")
+        assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]  # bias_act.py:105-107
+    C = x.shape[dim]
+    outer = int(np.prod(x.shape[:dim])) if dim > 0 else 1
+    inner = int(np.prod(x.shape[dim + 1:])) if dim + 1 < x.ndim else 1
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().p3d_bias_act_f32(_p(x), _p(b), outer, C, inner, idx, alpha, gain, clamp, _p(y), _stream())
+    _lib.check(rc, "p3d_bias_act_f32")
+    return y
+
+
+def setup_filter(f=(1, 3, 3, 1), device=None):
+    """upfirdn2d.setup_filter (upfirdn2d.py:72-117) for the non-separable case: outer product, normalised to DC gain 1."""
+    f = torch.as_tensor(f, dtype=torch.float32)
+    if f.ndim == 1:
+        f = f.ger(f)
+    f = f / f.sum()
+    return f.to(device) if device is not None else f
+
+
+def _parse_padding(padding):
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    padding = list(padding)
+    if len(padding) == 2:
+        padding = [padding[0], padding[0], padding[1], padding[1]]
+    return [int(v) for v in padding]
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.upfirdn2d (upfirdn2d.py:120-167), 2-D filter, same up/down factor in x and y."""
+    x = _chk(x, "x")
+    if x.ndim != 4 or f is None or f.ndim != 2:
+        raise NotImplementedError("upfirdn2d: [N,C,H,W] input and a 2-D filter are what the generator uses")
+    px0, px1, py0, py1 = _parse_padding(padding)
+    ff = (f.to(x.device, torch.float32) * float(gain))
+    if not flip_filter:
+        ff = ff.flip([0, 1])
+    ff = ff.contiguous()
+    N, Cc, H, W = x.shape
+    fh, fw = ff.shape
+    OH = (H * up + py0 + py1 - fh) // down + 1
+    OW = (W * up + px0 + px1 - fw) // down + 1
+    y = torch.empty((N, Cc, OH, OW), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().p3d_upfirdn2d_f32(_p(x), N * Cc, H, W, _p(ff), fh, fw, int(up), int(down), px0, px1, py0, py1, _p(y), _stream())
+    _lib.check(rc, "p3d_upfirdn2d_f32")
+    return y
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
+    """upfirdn2d.upsample2d (upfirdn2d.py:315-350)."""
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fh, fw = f.shape
+    p = [px0 + (fw + up - 1) // 2, px1 + (fw - up) // 2, py0 + (fh + up - 1) // 2, py1 + (fh - up) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * up * up)
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
+                     bias=None, act="linear", gain=None, clamp=None):
+    """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
+    (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
+    noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength)."""
+    x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
+    N, I, H, W = x.shape
+    O, I2, kh, kw = weight.shape
+    if I2 != I or tuple(styles.shape) != (N, I):
+        raise RuntimeError("modulated_conv2d: x [N,I,H,W], weight [O,I,k,k], styles [N,I]")
+    if not ((kh == kw == 3 and padding == 1 and up in (1, 2)) or (kh == kw == 1 and padding == 0 and up == 1)):
+        raise NotImplementedError("modulated_conv2d: only 3x3/pad 1/up 1|2 and 1x1 are on the hot path")
+    idx, da, dg = _ACTS[act]
+    gain = float(gain if gain is not None else dg)
+    clampv = float(clamp if clamp is not None else -1)
+    nps = 0
+    if noise is not None:
+        noise = _chk(noise, "noise")
+        nps = 1 if noise.numel() == N * H * up * W * up and noise.ndim == 4 and N > 1 else 0
+        if noise.numel() not in (H * up * W * up, N * H * up * W * up):
+            raise RuntimeError("noise must be [H*up, W*up] or [N,1,H*up,W*up]")
+    fir = None
+    if up == 2:
+        fir = (resample_filter.to(x.device, torch.float32) * 4.0).flip([0, 1]).contiguous()  # upfirdn2d.py:193-196, gain = up^2
+        if tuple(fir.shape) != (4, 4):
+            raise NotImplementedError("resample_filter must be the 4x4 [1,3,3,1] filter")
+    if bias is not None:
+        bias = _chk(bias, "bias")
+    y = torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(noise), nps,
+                                 _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
+    _lib.check(rc, "p3d_modconv2d_f32")
+    return y

@@ -1,0 +1,292 @@
+"""StyleGAN2 mapping + synthesis host modules of the triplane backbone, on the HIP operators.
+
+Mirrors the module tree and parameter names of training/networks_stylegan2.py (FullyConnectedLayer :102-133,
+MappingNetwork :199-296, SynthesisLayer :299-360, ToRGBLayer :363-383, SynthesisBlock :388-487, SynthesisNetwork
+:492-725, Generator :729-757) so that `misc.copy_params_and_buffers(..., require_all=True)` / `load_state_dict` of a
+PAniC-3D checkpoint works unchanged.  Inference only, fp32 only (the backbone runs with num_fp16_res=0:
+trainers/train_eclustrousC.py:253,553).  All convolution-shaped work runs in libpanic3d_hip.so: each SynthesisLayer /
+ToRGBLayer is ONE fused call (modulation, conv on the matrix cores, demodulation, noise, bias, lrelu, gain, clamp);
+the tiny fully-connected layers (w -> styles, mapping) stay on torch matmul.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+SQRT2 = float(np.sqrt(2))
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):  # networks_stylegan2.py:33-35
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    def __init__(self, in_features, out_features, bias=True, activation="linear", lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.in_features, self.out_features, self.activation = in_features, out_features, activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == "linear" and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return ops.bias_act(x.matmul(w.t()).contiguous(), b, act=self.activation)
+
+
+class MappingNetwork(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, cond_mode, num_layers=8, embed_features=None, layer_features=None,
+                 activation="lrelu", lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
+        self.w_avg_beta, self.cond_mode = w_avg_beta, cond_mode
+        self.resnet_cond = 0
+        for m in cond_mode.split("."):  # 'resnetcond_<k>': first k resnet features join the camera label
+            if m.startswith("resnetcond_"):
+                self.resnet_cond = int(m.split("_")[-1])
+                assert c_dim > 0
+                break
+        embed_features = (w_dim if embed_features is None else embed_features) if c_dim > 0 else 0
+        layer_features = w_dim if layer_features is None else layer_features
+        feats = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim + self.resnet_cond, embed_features)
+        for i in range(num_layers):
+            setattr(self, f"fc{i}", FullyConnectedLayer(feats[i], feats[i + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer("w_avg", torch.zeros([w_dim]))
+
+    def forward(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        assert not update_emas, "inference only"
+        x = None
+        if self.z_dim > 0:
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            if self.resnet_cond > 0:
+                c = torch.cat([c, cond["resnet_feats"][:, :self.resnet_cond]], dim=1)
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for i in range(self.num_layers):
+            x = getattr(self, f"fc{i}")(x)
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
+                 activation="lrelu", resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.resolution = in_channels, out_channels, w_dim, resolution
+        self.up, self.use_noise, self.activation, self.conv_clamp = up, use_noise, activation, conv_clamp
+        self.register_buffer("resample_filter", ops.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = SQRT2 if activation == "lrelu" else 1.0  # bias_act.py:23-33 def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        if use_noise:
+            self.register_buffer("noise_const", torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
+        assert noise_mode in ["random", "const", "none"]
+        styles = self.affine(w)
+        noise = None
+        if self.use_noise and noise_mode == "random":
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == "const":
+            noise = self.noise_const * self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
+                                    resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
+                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        return ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
+                                    clamp=self.conv_clamp)
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture="skip",
+                 resample_filter=(1, 3, 3, 1), conv_clamp=256, use_fp16=False, fp16_channels_last=False,
+                 fused_modconv_default=True, **layer_kwargs):
+        super().__init__()
+        if architecture != "skip":
+            raise NotImplementedError("the triplane backbone uses the 'skip' architecture (networks_stylegan2.py:396)")
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture = is_last, architecture
+        self.register_buffer("resample_filter", ops.setup_filter(resample_filter))
+        self.num_conv = self.num_torgb = 0
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                        resample_filter=resample_filter, conv_clamp=conv_clamp, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp,
+                                    **layer_kwargs)
+        self.num_conv += 1
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+        self.num_torgb += 1
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+        w_iter = iter(ws.unbind(dim=1))
+        if self.in_channels == 0:
+            x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.conv1(x, next(w_iter), **layer_kwargs)
+        else:
+            x = self.conv0(x.to(torch.float32), next(w_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), **layer_kwargs)
+        if img is not None:
+            img = ops.upsample2d(img, self.resample_filter)
+        y = self.torgb(x, next(w_iter))
+        img = img.add_(y) if img is not None else y
+        return x, img
+
+
+def _pixel_unshuffle(t, f):
+    """einops 'bs ch (h i) (w j) -> bs (i j ch) h w' (networks_stylegan2.py:632)."""
+    b, ch, H, W = t.shape
+    t = t.reshape(b, ch, H // f, f, W // f, f).permute(0, 3, 5, 1, 2, 4)
+    return t.reshape(b, f * f * ch, H // f, W // f)
+
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, cond_mode, channel_base=32768, channel_max=512,
+                 num_fp16_res=4, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        if num_fp16_res != 0:
+            raise NotImplementedError("the triplane backbone is fp32 (num_fp16_res=0, trainers/train_eclustrousC.py:253)")
+        self.cond_mode, self.w_dim, self.img_resolution, self.img_channels = cond_mode, w_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.num_fp16_res = num_fp16_res
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        ch = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisBlock(ch[res // 2] if res > 4 else 0, ch[res], w_dim=w_dim, resolution=res,
+                                   img_channels=img_channels, is_last=(res == img_resolution), **block_kwargs)
+            self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
+            setattr(self, f"b{res}", block)
+
+    # ---- PAniC-3D conditioning between blocks (networks_stylegan2.py:551-694): cheap element-wise glue on x / img
+    def _condition(self, lvl, res, x, img, cond, cm, chonkadd):
+        if self.cond_mode == "none":
+            return x, img
+        if res == 8 and chonkadd > 0:  # resnet "chonk" added to the first channels of the 8x8 activations (:554-560)
+            k = chonkadd
+            return torch.cat([x[:, :k] + cond["resnet_chonk"][:, :k], x[:, k:]], dim=1), img
+        interp = torch.nn.functional.interpolate
+        if self.cond_mode.startswith("ortho_front."):
+            cimg = cond["image_ortho_front"].flip(dims=(-2,))
+            if "gt_sides" in cm:
+                cimg = torch.cat([cimg, cond["image_ortho_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
+                                  cond["image_ortho_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
+            if "dorthoA" in cm:
+                cimg = torch.cat([cimg, cond["image_dorthoA_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
+                                  cond["image_dorthoA_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
+            cimg = cimg * 2 - 1
+            if "cond_img_norm_4" in cm:
+                cimg = 4 * cimg
+            if "add_4" in cm:
+                t = interp(cimg, size=x.shape[-2:], mode="bilinear")
+                t = t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1)
+                k = t.shape[1]
+                x = torch.cat([x[:, :-k], x[:, -k:] + t], dim=1)
+            if "concatfront" in cm:
+                t = interp(cimg, size=x.shape[-2:], mode="bilinear")
+                x = torch.cat([x[:, :-t.shape[1]], t], dim=1)
+            if "add_shuffle2_4" in cm or "mult_shuffle2_4" in cm:
+                if lvl < len(self.block_resolutions) - 2:
+                    t = interp(cimg, size=x.shape[-2:], mode="bilinear")
+                else:
+                    t = _pixel_unshuffle(cimg, cimg.shape[-1] // x.shape[-1])
+                t = t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1)
+                k = t.shape[1]
+                x = torch.cat([x[:, :-k], (x[:, -k:] + t) if "add_shuffle2_4" in cm else (x[:, -k:] * t)], dim=1)
+            if "inj_6b_4" in cm and res == self.block_resolutions[-1]:
+                t = (cond["image_ortho_front"].flip(dims=(-2,)) * 2 - 1) * 4
+                t = interp(t, size=img.shape[-2:], mode="bilinear")
+                img = torch.cat([img[:, :t.shape[1]] + t, img[:, t.shape[1]:]], dim=1)
+        if "crossavg_4" in cm:
+            k = int(x.shape[1] // 8)
+            h, v = x[:, 0:k], x[:, k:2 * k]
+            x = torch.cat([h.mean(dim=-1, keepdim=True).expand(h.shape), v.mean(dim=-2, keepdim=True).expand(v.shape),
+                           x[:, 2 * k:]], dim=1)
+        elif "crossavgt_38" in cm:
+            k = int(x.shape[1] // 8)
+            h, v, t = x[:, 0:k], x[:, k:2 * k], x[:, 2 * k:3 * k]
+            x = torch.cat([h.mean(dim=-1, keepdim=True).expand(h.shape), v.mean(dim=-2, keepdim=True).expand(v.shape),
+                           t.permute(0, 1, 3, 2), x[:, 3 * k:]], dim=1)
+        return x, img
+
+    def forward(self, ws, cond, latent_injection=None, stop_level=None, return_more=False, **block_kwargs):
+        ws = ws.to(torch.float32)
+        block_ws, w_idx = [], 0
+        for res in self.block_resolutions:  # a block's ToRGB shares the next block's first w (:534-537)
+            block = getattr(self, f"b{res}")
+            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+            w_idx += block.num_conv
+        cm = set(self.cond_mode.split("."))
+        chonk = [int(c.split("_")[-1]) for c in cm if c.startswith("reschonk_add_")]
+        chonk = chonk[0] if chonk else 0
+        x = img = None
+        ximgs = []
+        for lvl, (res, cur_ws) in enumerate(zip(self.block_resolutions, block_ws)):
+            x, img = getattr(self, f"b{res}")(x, img, cur_ws, **block_kwargs)
+            x, img = self._condition(lvl, res, x, img, cond, cm, chonk)
+            x, img = x.contiguous(), img.contiguous()
+            ximgs.append((x, img))
+            if latent_injection is not None:
+                if f"da_{lvl}" in latent_injection:
+                    x = x + latent_injection[f"da_{lvl}"]
+                if f"db_{lvl}" in latent_injection:
+                    img = img + latent_injection[f"db_{lvl}"]
+        if stop_level is None:
+            ret = img
+        else:
+            ret = ximgs[stop_level][1]
+            for i in range(stop_level + 1, len(self.block_resolutions)):
+                ret = ops.upsample2d(ret, getattr(self, f"b{self.block_resolutions[i]}").resample_filter)
+        return (ret, {"ximgs": ximgs, "block_ws": block_ws}) if return_more else ret
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, cond_mode, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels, self.cond_mode = img_resolution, img_channels, cond_mode
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
+                                          cond_mode=cond_mode, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, cond_mode=cond_mode,
+                                      **mapping_kwargs)
+
+    def forward(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, cond, **synthesis_kwargs)

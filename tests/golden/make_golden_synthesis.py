@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Golden vectors for the StyleGAN2 synthesis operators / networks, produced by the REFERENCE ITSELF on CPU
+(/root/reference imported unmodified; only runs in the build container).  Outputs: tests/golden/syn_*.npz.
+
+    python tests/golden/make_golden_synthesis.py
+"""
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("PROJECT_DN", "/root/reference")
+os.environ.setdefault("PROJECT_NAME", "x")
+sys.path[:0] = ["/root/reference"]
+sys.path.append("/root/reference/_train/eg3dc/src")
+sys.modules.setdefault("kornia", types.ModuleType("kornia"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from training import networks_stylegan2 as ns  # noqa: E402
+from torch_utils.ops import upfirdn2d, bias_act  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def sd_np(mod, prefix=""):
+    return {prefix + k.replace(".", "__"): v.numpy() for k, v in mod.state_dict().items()}
+
+
+def layer_cases():
+    g = torch.Generator().manual_seed(1234)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    out = {}
+    # SynthesisLayer up=1 (conv1): 16 -> 24 channels at 20x20 (tile-ragged sizes), batch 2
+    for tag, (cin, cout, res, up) in {"conv1": (16, 24, 20, 1), "conv0": (16, 40, 24, 2), "conv0b": (8, 72, 34, 2)}.items():
+        lay = ns.SynthesisLayer(cin, cout, w_dim=32, resolution=res, up=up, conv_clamp=None).eval()
+        lay.weight.copy_(rn(*lay.weight.shape))
+        lay.bias.copy_(rn(cout) * 0.3)
+        lay.noise_strength.copy_(torch.tensor(0.7))
+        lay.noise_const.copy_(rn(res, res))
+        lay.affine.weight.copy_(rn(*lay.affine.weight.shape))
+        x = rn(2, cin, res // up, res // up)
+        w = rn(2, 32)
+        y = lay(x, w, noise_mode="const", fused_modconv=True)
+        y_nf = lay(x, w, noise_mode="const", fused_modconv=False)
+        assert (y - y_nf).abs().max() < 1e-3
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_w": w.numpy(), f"{tag}_y": y.numpy(), f"{tag}_ynf": y_nf.numpy(),
+                    f"{tag}_cfg": np.array([cin, cout, res, up])})
+        out.update(sd_np(lay, f"{tag}_sd_"))
+        if tag == "conv1":  # clamp + gain variant (SR blocks use conv_clamp 256; use a small clamp so that it bites)
+            lay.conv_clamp = 0.8
+            out[f"{tag}_y_clamp"] = lay(x, w, noise_mode="const", gain=0.5).numpy()
+            lay.conv_clamp = None
+            out[f"{tag}_y_nonoise"] = lay(x, w, noise_mode="none").numpy()
+    rgb = ns.ToRGBLayer(16, 96, w_dim=32, conv_clamp=None).eval()
+    rgb.weight.copy_(rn(*rgb.weight.shape))
+    rgb.bias.copy_(rn(96) * 0.3)
+    rgb.affine.weight.copy_(rn(*rgb.affine.weight.shape))
+    x = rn(2, 16, 20, 20)
+    w = rn(2, 32)
+    out.update({"torgb_x": x.numpy(), "torgb_w": w.numpy(), "torgb_y": rgb(x, w).numpy()})
+    out.update(sd_np(rgb, "torgb_sd_"))
+    # upsample2d of the skip image, bias_act, upfirdn2d with odd padding
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    img = rn(2, 5, 9, 11)
+    out.update({"fir_f": f.numpy(), "up_x": img.numpy(), "up_y": upfirdn2d.upsample2d(img, f).numpy(),
+                "ufd_y": upfirdn2d.upfirdn2d(img, f, up=1, padding=[1, 1, 1, 1], gain=4).numpy(),
+                "ufd2_y": upfirdn2d.upfirdn2d(img, f, up=2, down=1, padding=[3, 0, 1, 2], flip_filter=True, gain=2).numpy()})
+    xb = rn(3, 7, 4, 5)
+    bb = rn(7)
+    out.update({"ba_x": xb.numpy(), "ba_b": bb.numpy(), "ba_lrelu": bias_act.bias_act(xb, bb, act="lrelu").numpy(),
+                "ba_lin_clamp": bias_act.bias_act(xb, bb, act="linear", gain=2.0, clamp=1.5).numpy(),
+                "ba_fc": bias_act.bias_act(xb.reshape(3, -1)[:, :7].contiguous(), bb, act="lrelu").numpy()})
+    save("syn_layers.npz", **out)
+
+
+GEN_KW = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+
+
+def generator_cases():
+    for tag, cond_mode in (("none", "none"), ("cond", "ortho_front.add_shuffle2_4.inj_6b_4.crossavg_4.reschonk_add_8.resnetcond_16")):
+        torch.manual_seed(77)
+        G = ns.Generator(cond_mode=cond_mode, **GEN_KW).eval()
+        gg = torch.Generator().manual_seed(78)
+        for n, p in G.named_parameters():  # make every path matter: non-zero biases / noise strengths
+            if n.endswith("noise_strength"):
+                p.copy_(torch.rand((), generator=gg) * 0.5)
+            elif n.endswith(".bias") and "affine" not in n:
+                p.copy_(torch.randn(p.shape, generator=gg) * 0.2)
+        z = torch.randn(2, 64, generator=gg)
+        c = torch.randn(2, 25, generator=gg)
+        cond = {"image_ortho_front": torch.rand(2, 4, 32, 32, generator=gg), "resnet_feats": torch.randn(2, 32, generator=gg),
+                "resnet_chonk": torch.randn(2, 8, 8, 8, generator=gg)}
+        ws = G.mapping(z, c, cond, truncation_psi=0.7, truncation_cutoff=4)
+        img = G.synthesis(ws, cond, noise_mode="const")
+        ws1 = G.mapping(z, c, cond)
+        out = {"z": z.numpy(), "c": c.numpy(), "ws": ws.numpy(), "ws_psi1": ws1.numpy(), "img": img.numpy(),
+               "cond_mode": np.array(cond_mode)}
+        out.update({"cond_" + k: v.numpy() for k, v in cond.items()})
+        out.update(sd_np(G, "sd_"))
+        save(f"syn_generator_{tag}.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    layer_cases()
+    generator_cases()

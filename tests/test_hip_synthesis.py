@@ -1,0 +1,138 @@
+"""GPU: StyleGAN2 synthesis operators / networks on the HIP path vs (a) the REFERENCE's own outputs (tests/golden/syn_*.npz,
+produced by tests/golden/make_golden_synthesis.py) and (b) a plain PyTorch fp32 restatement of the same op on CPU at
+hot-path shapes.  Floating-point convolutions: tolerance, stated per test (different summation order: the reference sums
+in oneDNN/cuDNN order, the HIP kernel in MFMA k-order; K up to 4608 terms)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import p3d_testing as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import panic3d_amd
+    assert torch.cuda.is_available()
+    panic3d_amd._lib.lib()
+    return panic3d_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def load_sd(mod, g, prefix):
+    sd = {k[len(prefix):].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+    missing, unexpected = mod.load_state_dict(sd, strict=True), None
+    return mod.cuda().eval()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("tag", ["conv1", "conv0", "conv0b"])
+def test_synthesis_layer_vs_reference(hip, tag):
+    from panic3d_amd import stylegan2 as sg
+    g = T.load_golden("syn_layers.npz")
+    cin, cout, res, up = (int(v) for v in g[f"{tag}_cfg"])
+    lay = load_sd(sg.SynthesisLayer(cin, cout, w_dim=32, resolution=res, up=up, conv_clamp=None), g, f"{tag}_sd_")
+    with torch.no_grad():
+        y = lay(dev(g[f"{tag}_x"]), dev(g[f"{tag}_w"]), noise_mode="const").cpu().numpy()
+        assert rel_err(y, g[f"{tag}_y"]) < 2e-6 * np.sqrt(cin * 9) + 1e-6  # fp32 dot products of 9*cin terms
+        if tag == "conv1":
+            lay.conv_clamp = 0.8
+            yc = lay(dev(g[f"{tag}_x"]), dev(g[f"{tag}_w"]), noise_mode="const", gain=0.5).cpu().numpy()
+            assert np.abs(yc - g[f"{tag}_y_clamp"]).max() < 1e-5 and np.abs(yc).max() <= 0.4 + 1e-7
+            lay.conv_clamp = None
+            yn = lay(dev(g[f"{tag}_x"]), dev(g[f"{tag}_w"]), noise_mode="none").cpu().numpy()
+            assert rel_err(yn, g[f"{tag}_y_nonoise"]) < 3e-5
+
+
+def test_torgb_vs_reference(hip):
+    from panic3d_amd import stylegan2 as sg
+    g = T.load_golden("syn_layers.npz")
+    rgb = load_sd(sg.ToRGBLayer(16, 96, w_dim=32, conv_clamp=None), g, "torgb_sd_")
+    with torch.no_grad():
+        y = rgb(dev(g["torgb_x"]), dev(g["torgb_w"])).cpu().numpy()
+    assert rel_err(y, g["torgb_y"]) < 1e-5
+
+
+def test_fir_and_bias_act_vs_reference(hip):
+    g = T.load_golden("syn_layers.npz")
+    f = dev(g["fir_f"])
+    assert np.array_equal(hip.ops.setup_filter([1, 3, 3, 1]).numpy(), g["fir_f"])
+    x = dev(g["up_x"])
+    assert np.abs(hip.ops.upsample2d(x, f).cpu().numpy() - g["up_y"]).max() < 2e-6
+    assert np.abs(hip.ops.upfirdn2d(x, f, up=1, padding=[1, 1, 1, 1], gain=4).cpu().numpy() - g["ufd_y"]).max() < 2e-6
+    y2 = hip.ops.upfirdn2d(x, f, up=2, down=1, padding=[3, 0, 1, 2], flip_filter=True, gain=2).cpu().numpy()
+    assert y2.shape == g["ufd2_y"].shape and np.abs(y2 - g["ufd2_y"]).max() < 2e-6
+    xb, bb = dev(g["ba_x"]), dev(g["ba_b"])
+    assert np.array_equal(hip.ops.bias_act(xb, bb, act="lrelu").cpu().numpy(), g["ba_lrelu"])  # same fp32 ops: exact
+    assert np.array_equal(hip.ops.bias_act(xb, bb, act="linear", gain=2.0, clamp=1.5).cpu().numpy(), g["ba_lin_clamp"])
+    assert np.array_equal(hip.ops.bias_act(xb.reshape(3, -1)[:, :7].contiguous(), bb, act="lrelu").cpu().numpy(), g["ba_fc"])
+
+
+def torch_modconv_ref(x, w, s, noise, up, demod, bias, f):
+    """Plain PyTorch fp32 (CPU) restatement of modulated_conv2d + bias/lrelu: per-sample weights, grouped conv."""
+    N, I, H, W = x.shape
+    O, _, k, _ = w.shape
+    ww = w.unsqueeze(0) * s.reshape(N, 1, I, 1, 1)
+    if demod:
+        ww = ww * (ww.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
+    ys = []
+    for n in range(N):
+        if up == 1:
+            y = F.conv2d(x[n:n + 1], ww[n], padding=k // 2)
+        else:
+            y = F.conv_transpose2d(x[n:n + 1], ww[n].transpose(0, 1), stride=2)
+            ff = (f * 4).flip([0, 1])[None, None].repeat(O, 1, 1, 1)
+            y = F.conv2d(F.pad(y, [1, 1, 1, 1]), ff, groups=O)
+        ys.append(y)
+    y = torch.cat(ys)
+    if noise is not None:
+        y = y + noise
+    if bias is not None:
+        y = y + bias.reshape(1, -1, 1, 1)
+    return y
+
+
+@pytest.mark.parametrize("I,O,H,up,ks", [(512, 512, 16, 1, 3), (512, 512, 8, 2, 3), (256, 128, 32, 2, 3), (128, 96, 64, 1, 1),
+                                         (40, 72, 13, 1, 3)])
+def test_modconv_hot_path_shapes_vs_torch_fp32(hip, I, O, H, up, ks):
+    g = torch.Generator().manual_seed(I + O + H)
+    N = 2
+    x = torch.randn(N, I, H, H, generator=g)
+    w = torch.randn(O, I, ks, ks, generator=g)
+    s = torch.randn(N, I, generator=g) * 0.5 + 1.0
+    noise = torch.randn(H * up, H * up, generator=g) * 0.3
+    bias = torch.randn(O, generator=g) * 0.2
+    f = hip.ops.setup_filter([1, 3, 3, 1])
+    demod = ks == 3
+    ref = torch_modconv_ref(x, w, s, noise, up, demod, bias, f)
+    ref = F.leaky_relu(ref, 0.2) * np.sqrt(2) if ks == 3 else ref
+    y = hip.ops.modulated_conv2d(x.cuda(), w.cuda(), s.cuda(), noise=noise.cuda(), up=up, padding=ks // 2,
+                                 resample_filter=f.cuda(), demodulate=demod, bias=bias.cuda(),
+                                 act="lrelu" if ks == 3 else "linear")
+    err = rel_err(y.cpu().numpy(), ref.numpy())
+    assert err < 3e-6 * np.sqrt(I * ks * ks), err  # ~2e-4 at K = 4608
+
+
+@pytest.mark.parametrize("tag", ["none", "cond"])
+def test_generator_vs_reference(hip, tag):
+    from panic3d_amd import stylegan2 as sg
+    g = T.load_golden(f"syn_generator_{tag}.npz")
+    kw = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+    G = load_sd(sg.Generator(cond_mode=str(g["cond_mode"]), **kw), g, "sd_")
+    cond = {k[5:]: dev(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+    with torch.no_grad():
+        ws = G.mapping(dev(g["z"]), dev(g["c"]), cond, truncation_psi=0.7, truncation_cutoff=4)
+        assert np.abs(ws.cpu().numpy() - g["ws"]).max() < 1e-5
+        assert np.abs(G.mapping(dev(g["z"]), dev(g["c"]), cond).cpu().numpy() - g["ws_psi1"]).max() < 1e-5
+        img = G.synthesis(dev(g["ws"]), cond, noise_mode="const").cpu().numpy()
+    assert img.shape == g["img"].shape
+    assert rel_err(img, g["img"]) < 1e-4

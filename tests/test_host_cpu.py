@@ -145,3 +145,22 @@ def test_view_sharding_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_stylegan2_state_dict_matches_reference_names(P):
+    """Drop-in requirement (eg3dc_v0.py:49 copy_params_and_buffers(require_all=True)): identical parameter / buffer names
+    and shapes as the reference's Generator — checked against the state_dict the reference itself produced."""
+    from panic3d_amd import stylegan2 as sg
+    kw = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+    for tag in ("none", "cond"):
+        g = T.load_golden(f"syn_generator_{tag}.npz")
+        G = sg.Generator(cond_mode=str(g["cond_mode"]), **kw)
+        ref = {k[3:].replace("__", "."): v.shape for k, v in g.items() if k.startswith("sd_")}
+        mine = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        assert set(mine) == set(ref)
+        assert all(tuple(ref[k]) == mine[k] for k in ref)
+    # full-size backbone of the released configuration: 14 ws, 96-channel 256^2 output (SURVEY.md Appendix A)
+    G = sg.Generator(z_dim=512, c_dim=25, w_dim=512, img_resolution=256, img_channels=96, cond_mode="none",
+                     mapping_kwargs={"num_layers": 2}, channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None)
+    assert G.num_ws == 14 and G.synthesis.b256.conv1.weight.shape == (128, 128, 3, 3)
