@@ -1,0 +1,244 @@
+"""TriPlaneGenerator on the MI355X path — same constructor arguments, sub-module / parameter names, method signatures and
+return dictionaries as training/triplane.py:30-513 (so `_train/eg3dc/util/eg3dc_v0.py:47-52` can re-instantiate it from a
+checkpoint's init kwargs and copy the parameters by name), with the backbone on the HIP synthesis operators
+(stylegan2.py), the volumetric renderer on the fused HIP kernel (renderer.py) and the super-resolution blocks on the same
+modulated-conv kernel.
+
+Inference only.  Not mirrored: `sample` (broken in the reference, triplane.py:254-271) and the `paste_front`
+post-process (triplane.py:555-691, next row of SURVEY.md §8f) — `f()` raises if `paste_params` is given.
+"""
+import numpy as np
+import torch
+
+from . import cameras, stylegan2
+from .renderer import ImportanceRenderer
+
+
+class OSGDecoder(torch.nn.Module):
+    """Parameter container of the tiny decoder MLP (triplane.py:516-547); it is evaluated inside the fused HIP kernels."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        self.hidden_dim = 64
+        self.force_sigmoid = False
+        lr = options["decoder_lr_mul"]
+        self.net = torch.nn.Sequential(stylegan2.FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr),
+                                       torch.nn.Softplus(),
+                                       stylegan2.FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=lr))
+
+    def set_force_sigmoid(self, state):
+        self.force_sigmoid = state
+        return self.force_sigmoid
+
+
+class SuperresolutionHybrid8XDC(torch.nn.Module):
+    """128^2 x 32ch -> 512^2 RGB with two StyleGAN2 blocks (superresolution.py:264-293), fp32 on the HIP conv kernel."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, channels_hidden=256, num_fp16_res=4,
+                 conv_clamp=None, channel_base=None, channel_max=None, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 512
+        self.input_resolution = 128
+        self.sr_antialias = sr_antialias
+        clamp = 256 if sr_num_fp16_res > 0 else None  # the reference clamps only its fp16 blocks (superresolution.py:277-280)
+        self.block0 = stylegan2.SynthesisBlock(channels, channels_hidden, w_dim=512, resolution=256, img_channels=3,
+                                               is_last=False, conv_clamp=clamp, **block_kwargs)
+        self.block1 = stylegan2.SynthesisBlock(channels_hidden, channels_hidden // 2, w_dim=512, resolution=512,
+                                               img_channels=3, is_last=True, conv_clamp=clamp, **block_kwargs)
+
+    def forward(self, rgb, x, ws, **block_kwargs):
+        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        if x.shape[-1] != self.input_resolution:
+            size = (self.input_resolution, self.input_resolution)
+            x = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=self.sr_antialias)
+            rgb = torch.nn.functional.interpolate(rgb, size=size, mode="bilinear", align_corners=False, antialias=self.sr_antialias)
+        x, rgb = self.block0(x.contiguous(), rgb.contiguous(), ws, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        return rgb
+
+
+_SR_MODULES = {"training.superresolution.SuperresolutionHybrid8XDC": SuperresolutionHybrid8XDC}
+
+
+class TriPlaneGenerator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={},
+                 rendering_kwargs={}, sr_kwargs={}, cond_mode=None, triplane_width=32, sr_channels_hidden=256,
+                 backbone_resolution=256, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        if rendering_kwargs.get("triplane_depth", 1) != 1:
+            raise NotImplementedError("triplane_depth != 1")
+        self.renderer = ImportanceRenderer(use_triplane=rendering_kwargs.get("use_triplane", False))
+        self.triplane_width, self.backbone_resolution = triplane_width, backbone_resolution
+        self.backbone = stylegan2.Generator(z_dim, c_dim, w_dim, img_resolution=backbone_resolution,
+                                            img_channels=triplane_width * 3, cond_mode=cond_mode,
+                                            mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+        sr_name = rendering_kwargs["superresolution_module"]
+        if sr_name not in _SR_MODULES:
+            raise NotImplementedError(f"{sr_name}: only the 512^2 module of the released model is mirrored")
+        self.superresolution = _SR_MODULES[sr_name](channels=32, channels_hidden=sr_channels_hidden,
+                                                    img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
+                                                    sr_antialias=rendering_kwargs["sr_antialias"], **sr_kwargs)
+        self.decoder = OSGDecoder(triplane_width, {"decoder_lr_mul": rendering_kwargs.get("decoder_lr_mul", 1),
+                                                   "decoder_output_dim": 32})
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self.cond_mode = cond_mode
+        self._last_planes = None
+        self._inject_draws = None  # tests: (jitter, u) for the renderer instead of device RNG
+
+    # ---- latents ------------------------------------------------------------------------------------------------
+    def mapping(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        rk = self.rendering_kwargs
+        if rk["c_gen_conditioning_zero"]:
+            c = torch.zeros_like(c)
+        if rk.get("c_gen_conditioning_force_ffhq", False):
+            raise NotImplementedError("c_gen_conditioning_force_ffhq (fine-tuning hack, triplane.py:97-121)")
+        return self.backbone.mapping(z, c * rk.get("c_scale", 0), cond, truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff)
+
+    def mapping_zplus(self, zs, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        """One z per w slot (triplane.py:123-143): map every z, keep slot i of the i-th z's broadcast ws."""
+        bs, n, dim = zs.shape
+        c_new = c[:, None, :].repeat(1, n, 1).reshape(bs * n, -1)
+        cond_new = cond
+        if "resnet_feats" in cond:
+            cond_new = {**cond, "resnet_feats": cond["resnet_feats"][:, None, :].repeat(1, n, 1).reshape(bs * n, -1)}
+        ans = self.mapping(zs.reshape(bs * n, dim), c_new, cond_new, truncation_psi=truncation_psi,
+                           truncation_cutoff=truncation_cutoff)
+        ans = ans.view(bs, n, n, -1)
+        idx = torch.arange(n, device=ans.device)
+        return ans[:, idx, idx]
+
+    # ---- planes -------------------------------------------------------------------------------------------------
+    def _planes(self, ws, cond, latent_injection=None, stop_level=None, **synthesis_kwargs):
+        planes = self.backbone.synthesis(ws, cond, latent_injection=latent_injection, stop_level=stop_level, **synthesis_kwargs)
+        return planes.view(len(planes), 3, self.triplane_width, planes.shape[-2], planes.shape[-1])
+
+    def synthesis(self, ws, c, cond, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
+                  use_cached_backbone=False, latent_injection=None, stop_level=None, force_rays=None, triplane_crop=None,
+                  cull_clouds=None, binarize_clouds=None, normalize_images=True, return_more=False, **synthesis_kwargs):
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        res = neural_rendering_resolution
+        if force_rays is None:
+            ray_origins, ray_directions = cameras.perspective_rays(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
+        elif isinstance(force_rays, dict):
+            ro, rd = force_rays["ray_origins"], force_rays["ray_directions"]
+            assert ro.shape == rd.shape == (len(ws), 3, res, res)
+            ray_origins = ro.permute(0, 2, 3, 1).reshape(len(ws), res * res, 3)
+            ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ws), res * res, 3)
+        else:
+            assert False, "force_rays not understood"
+        N = ray_origins.shape[0]
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
+        else:
+            planes = self._planes(ws, cond, latent_injection, stop_level, **synthesis_kwargs)
+        if cache_backbone:
+            self._last_planes = planes
+        draws = self._inject_draws or (None, None)
+        feat, depth, wsum, xyz = self.renderer(planes, self.decoder, ray_origins.contiguous(), ray_directions.contiguous(),
+                                               self.rendering_kwargs, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
+                                               binarize_clouds=binarize_clouds, jitter=draws[0], u=draws[1])
+        H = W = res
+        feature_image = feat.permute(0, 2, 1).reshape(N, feat.shape[-1], H, W).contiguous()
+        xyz_image = xyz.permute(0, 2, 1).reshape(N, 3, H, W).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(N, 1, H, W)
+        weights_image = wsum.permute(0, 2, 1).reshape(N, 1, H, W)
+        xyz_image = 0.5 * (xyz_image + 1) * torch.tensor([-1, 1, -1], device=xyz_image.device)[None, :, None, None]
+        rgb_image = feature_image[:, :3]
+        sr_kw = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
+        sr_image = self.superresolution(rgb_image, feature_image, ws,
+                                        noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kw)
+        ans = {"image": sr_image, "image_raw": rgb_image, "image_depth": depth_image, "triplane": planes,
+               "image_weights": weights_image, "image_xyz": xyz_image}
+        if self.rendering_kwargs.get("tanh_rgb_output", False):
+            ans["image"], ans["image_raw"] = torch.tanh(ans["image"]), torch.tanh(ans["image_raw"])
+        if not normalize_images:
+            ans["image"], ans["image_raw"] = 0.5 * ans["image"] + 0.5, 0.5 * ans["image_raw"] + 0.5
+        return ans
+
+    def sample_mixed(self, coordinates, directions, ws, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False,
+                     **synthesis_kwargs):
+        """triplane.py:273-298 (the density-grid query of _util/eg3d_metrics3d.py:140).  The reference re-runs the backbone
+        on every call; pass use_cached_backbone=True to reuse the planes of the previous call with the same ws."""
+        reuse = synthesis_kwargs.pop("use_cached_backbone", False)
+        if reuse and self._last_planes is not None:
+            planes = self._last_planes
+        else:
+            planes = self._planes(ws, cond, **synthesis_kwargs)
+            self._last_planes = planes if reuse else self._last_planes
+        return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
+
+    def forward(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None,
+                update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, c, cond, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
+
+    # ---- the dict-in / dict-out API of PAniC-3D (triplane.py:313-508) -----------------------------------------
+    def f(self, x, truncation_psi=1, truncation_cutoff=None, latent_injection=None, force_rays=None, stop_level=None,
+          normalize_images=False, return_more=False):
+        emb = self.backbone.mapping.embed.weight
+        device, dtype = emb.device, emb.dtype
+        for key in ("ws", "camera_params", "elevations", "zs", "z"):
+            if key in x:
+                device = x[key].device
+                break
+        if "latent_injection" in x:
+            latent_injection = {**(latent_injection or {}), **x["latent_injection"]}
+        if "zs" not in x and "ws" not in x:
+            if "z" not in x:
+                x["z"] = torch.tensor(np.stack([np.random.RandomState(s).randn(self.z_dim) for s in x["seeds"]]),
+                                      device=device, dtype=dtype)
+            x["zs"] = x["z"][:, None, :].expand(-1, self.backbone.num_ws, -1)
+        if "camera_params" not in x:
+            if "distances" not in x:
+                x["distances"] = torch.ones_like(x["elevations"])
+            if "fovs" not in x:
+                x["fovs"] = 30 * torch.ones_like(x["elevations"])
+            x["camera_params"] = torch.stack([
+                cameras.camera_label(e, a, d, fv)
+                for e, a, d, fv in zip(x["elevations"], x["azimuths"], x["distances"], x["fovs"])]).to(dtype).to(device)
+        force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
+        res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
+        if force_rays is None:
+            cp = x["camera_params"]
+            intr = cp[:, 16:25].view(-1, 3, 3)
+            ro, rd = cameras.perspective_rays(cp[:, :16].view(-1, 4, 4), intr, res)
+            ro = ro.reshape(len(cp), res, res, 3).permute(0, 3, 1, 2).contiguous()
+            rd = rd.reshape(len(cp), res, res, 3).permute(0, 3, 1, 2).contiguous()
+            for i in range(len(cp)):  # negative fov = orthographic view (triplane.py:402-414)
+                if intr[i, 0, 0] < 0:
+                    r = cameras.ortho_rays(x["elevations"][i], x["azimuths"][i], x["distances"][i],
+                                           self.rendering_kwargs["box_warp"], res, device=device)
+                    ro[i], rd[i] = r["ray_origins"], r["ray_directions"]
+            x["force_rays"] = force_rays = {"ray_origins": ro, "ray_directions": rd}
+        x["conditioning_params"] = x["camera_params"]
+        if "ws" not in x:
+            x["ws"] = self.mapping_zplus(x["zs"], x["conditioning_params"], x["cond"], truncation_psi=truncation_psi,
+                                         truncation_cutoff=truncation_cutoff)
+        _ws = x["ws"]
+        if latent_injection is not None:
+            for k in ("dw", "dws"):
+                if k in latent_injection:
+                    _ws = _ws + latent_injection[k]
+        normalize_images = x["normalize_images"] if "normalize_images" in x else normalize_images
+        synth = self.synthesis(_ws, x["camera_params"], x["cond"], latent_injection=latent_injection,
+                               triplane_crop=x.get("triplane_crop"), cull_clouds=x.get("cull_clouds"),
+                               binarize_clouds=x.get("binarize_clouds"), force_rays=force_rays, stop_level=stop_level,
+                               normalize_images=normalize_images, neural_rendering_resolution=res,
+                               **({"noise_mode": x["noise_mode"]} if "noise_mode" in x else {}))
+        ret = {k: synth[k] for k in ("image", "image_raw", "image_depth", "image_weights", "triplane", "image_xyz")}
+        ret["normalize_images"] = normalize_images
+        x.update(ret)
+        if x.get("paste_params") is not None:
+            raise NotImplementedError("paste_front (triplane.py:555-691) is the next row of the build plan (SURVEY.md §8f-4)")
+        return ret
+
+    def set_force_sigmoid(self, state):
+        return self.decoder.set_force_sigmoid(state)

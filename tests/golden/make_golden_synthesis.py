@@ -109,7 +109,69 @@ def generator_cases():
         save(f"syn_generator_{tag}.npz", **out)
 
 
+
+
+# ---- TriPlaneGenerator.f end to end (tiny backbone / SR widths; released rendering_kwargs) --------------------------
+TRI_RK = {"image_resolution": 512, "disparity_space_sampling": False, "clamp_mode": "softplus",
+          "superresolution_module": "training.superresolution.SuperresolutionHybrid8XDC", "c_gen_conditioning_zero": False,
+          "gpc_reg_prob": 0.5, "c_scale": 1.0, "superresolution_noise_mode": "none", "density_reg": 0.25,
+          "density_reg_p_dist": 0.004, "reg_type": "l1", "decoder_lr_mul": 1.0, "sr_antialias": True, "white_back": True,
+          "triplane_depth": 1, "use_triplane": 1, "tanh_rgb_output": False, "box_warp": 0.7, "ray_start": 0.5, "ray_end": 1.5,
+          "depth_resolution": 12, "depth_resolution_importance": 12, "avg_camera_radius": 1.0, "avg_camera_pivot": [0, 0, 0]}
+TRI_KW = dict(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, sr_num_fp16_res=0,
+              mapping_kwargs={"num_layers": 2}, rendering_kwargs=TRI_RK,
+              sr_kwargs={"channel_base": 32768, "channel_max": 512, "fused_modconv_default": "inference_only"},
+              cond_mode="none", triplane_width=32, sr_channels_hidden=16, backbone_resolution=32, channel_base=1024,
+              channel_max=32, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+
+
+def triplane_case():
+    from training.triplane import TriPlaneGenerator
+    torch.manual_seed(5)
+    G = TriPlaneGenerator(**TRI_KW).eval()
+    gg = torch.Generator().manual_seed(6)
+    for n, p in G.named_parameters():
+        if n.endswith(".bias") and "affine" not in n:
+            p.copy_(torch.randn(p.shape, generator=gg) * 0.2)
+    G.decoder.net[2].weight[0] *= 20.0  # solid-ish density field
+    G.set_force_sigmoid(True)
+    rec = {}
+    o_rl, o_r = torch.rand_like, torch.rand
+
+    def rand_like(t, *a, **k):
+        r = o_rl(t, *a, **k)
+        rec.setdefault("jitter", r.clone())
+        return r
+
+    def rand(*a, **k):
+        r = o_r(*a, **k)
+        rec.setdefault("u", r.clone())
+        return r
+
+    x = dict(elevations=torch.tensor([0.0, 10.0]), azimuths=torch.tensor([20.0, 200.0]), fovs=torch.tensor([30.0, -1.0]),
+             seeds=[3, 4], cond={}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16)
+    torch.rand_like, torch.rand = rand_like, rand
+    try:
+        torch.manual_seed(9)
+        out = G.f(x)
+    finally:
+        torch.rand_like, torch.rand = o_rl, o_r
+    arrs = {k: out[k].numpy() for k in ("image_raw", "image_depth", "image_weights", "image_xyz", "triplane")}
+    arrs["image_sub4"] = out["image"][..., ::4, ::4].contiguous().numpy()  # every 4th pixel of the 512^2 SR image (fixture size)
+    arrs.update(jitter=rec["jitter"].numpy(), u=rec["u"].numpy(), ws=x["ws"].numpy(), camera_params=x["camera_params"].numpy())
+    pts = (torch.rand(2, 500, 3, generator=gg) - 0.5) * 0.6
+    sm = G.sample_mixed(pts, None, x["ws"], {}, noise_mode="const")
+    arrs.update(sm_pts=pts.numpy(), sm_sigma=sm["sigma"].numpy(), sm_rgb=sm["rgb"].numpy())
+    arrs.update(sd_np(G, "sd_"))
+    save("syn_triplane_f.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    layer_cases()
-    generator_cases()
+    which = sys.argv[1:] or ["layers", "generator", "triplane"]
+    if "layers" in which:
+        layer_cases()
+    if "generator" in which:
+        generator_cases()
+    if "triplane" in which:
+        triplane_case()
