@@ -1,0 +1,90 @@
+"""Density-grid query for marching cubes — the hot loop of `_util/eg3d_metrics3d.py:94-183 get_eg3d_volume`
+(`_scripts/eval/generate.py:97`, BASELINE config c5), on the fused density-only decode kernel.
+
+Differences from the reference, all deliberate: the backbone is run ONCE (the reference re-synthesises the planes for
+every 100k-point chunk, eg3d_metrics3d.py:140 -> triplane.py:283), points are generated on the device, and nothing
+crosses PCIe until the caller asks for it.  Quirks that are kept because they change the numbers:
+  * create_samples uses float division, so the y / "x" coordinates carry a fractional part of the faster index
+    (eg3d_metrics3d.py:80-82);
+  * the cull mask is evaluated on the already-activated densities and writes -1e3 into them (eg3d_metrics3d.py:155-163).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .renderer import decoder_params
+
+
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None, lo=0, hi=None):
+    """Points [1, (hi-lo), 3] of the reference's N^3 grid, flat indices [lo, hi) (eg3d_metrics3d.py:70-92)."""
+    origin = np.array(voxel_origin) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    hi = N ** 3 if hi is None else hi
+    idx = torch.arange(lo, hi, 1, dtype=torch.long, device=device)
+    s = torch.zeros(hi - lo, 3, device=device)
+    s[:, 2] = idx % N
+    s[:, 1] = (idx.float() / N) % N
+    s[:, 0] = ((idx.float() / N) / N) % N
+    s[:, 0] = (s[:, 0] * voxel_size) + origin[2]
+    s[:, 1] = (s[:, 1] * voxel_size) + origin[1]
+    s[:, 2] = (s[:, 2] * voxel_size) + origin[0]
+    return s.unsqueeze(0), origin, voxel_size
+
+
+def sigma2density(sigma):  # eg3d_metrics3d.py:65-69
+    return 1 - torch.exp(-torch.nn.functional.softplus(sigma - 1))
+
+
+def density_grid(G, ws, cond, resolution=256, max_batch=1 << 24, triplane_crop=None, cull_clouds=None, lo=0, hi=None,
+                 planes=None, **synthesis_kwargs):
+    """sigma / density for flat grid indices [lo, hi) of the resolution^3 grid, on the device: dict(sigmas, densities)
+    of shape [1, hi-lo, 1].  `planes` (NCHW [1,3,32,H,W]) skips the backbone."""
+    rk = G.rendering_kwargs
+    dev = ws.device
+    if planes is None:
+        planes = G._planes(ws, cond, **({"noise_mode": "const"} | synthesis_kwargs))
+    hi = resolution ** 3 if hi is None else hi
+    opts = G.renderer._opts(rk, G.decoder)
+    mlp = decoder_params(G.decoder)
+    nhwc = G.renderer._nhwc(planes)
+    sig = torch.empty((1, hi - lo, 1), dtype=torch.float32, device=dev)
+    for a in range(lo, hi, max_batch):
+        b = min(a + max_batch, hi)
+        pts, _, _ = create_samples(resolution, cube_length=rk["box_warp"], device=dev, lo=a, hi=b)
+        sig[:, a - lo:b - lo], _ = ops.triplane_decode(nhwc, pts.contiguous(), mlp, opts, density_only=True)
+    dens = sigma2density(sig)
+    if triplane_crop is not None or cull_clouds is not None:
+        if triplane_crop is not None:  # triplane_crop_mask (renderer.py:138-149): |x| or |z| beyond box/2 - crop
+            lim = rk["box_warp"] / 2 - triplane_crop
+            for a in range(lo, hi, max_batch):
+                b = min(a + max_batch, hi)
+                pts, _, _ = create_samples(resolution, cube_length=rk["box_warp"], device=dev, lo=a, hi=b)
+                m = (pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)
+                dens[:, a - lo:b - lo][m] = -1e3
+        if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
+            dens[sigma2density(dens) < cull_clouds] = -1e3
+    return {"sigmas": sig, "densities": dens}
+
+
+def to_volume(t, resolution):
+    """The reference's final layout: [1, C, N, N, N] with the first grid axis flipped (eg3d_metrics3d.py:166-177)."""
+    return t.reshape(t.shape[0], resolution, resolution, resolution, t.shape[-1]).flip(dims=(1,)).permute(0, 4, 1, 2, 3)
+
+
+def density_grid_sharded(G, ws, cond, resolution=256, dst=0, **kw):
+    """c5 on N GPUs: each rank decodes a contiguous slab of the slowest grid axis; one gather of the sigma / density slabs."""
+    import torch.distributed as dist
+    from . import sharding
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    a, b = sharding.partition(resolution, world, rank)
+    out = density_grid(G, ws, cond, resolution, lo=a * resolution ** 2, hi=b * resolution ** 2, **kw)
+    if world == 1:
+        return out
+    counts = [sharding.partition(resolution, world, r)[1] - sharding.partition(resolution, world, r)[0] for r in range(world)]
+    res = {}
+    for k, v in out.items():
+        slabs = v.reshape(b - a, resolution * resolution)
+        g = sharding.gather_frames(slabs, counts, dst)
+        res[k] = g.reshape(1, -1, 1) if g is not None else None
+    return res

@@ -178,3 +178,26 @@ def test_triplane_generator_f_vs_reference(hip):
         assert rel_err(sm["sigma"].cpu().numpy(), g["sm_sigma"]) < 1e-3 and np.abs(sm["rgb"].cpu().numpy() - g["sm_rgb"]).max() < 1e-3
     with pytest.raises(NotImplementedError):
         G.f(dict(x, paste_params={"thresh": 0.5}))
+
+
+def test_density_grid(hip):
+    """volume.density_grid == get_eg3d_volume's loop (sample_mixed per chunk + sigma2density + crop/cull on densities)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    ws = dev(g["ws"])[:1]
+    N = 24
+    with torch.no_grad():
+        out = hip.volume.density_grid(G, ws, {}, resolution=N, max_batch=5000, triplane_crop=0.1, cull_clouds=0.5)
+        pts, _, _ = hip.volume.create_samples(N, cube_length=0.7, device="cuda")
+        ref = G.sample_mixed(pts.contiguous(), None, ws, {}, noise_mode="const")["sigma"]
+        assert torch.equal(out["sigmas"], ref)
+        dens = hip.volume.sigma2density(ref)
+        dens[(pts[..., 0].abs() > 0.25) | (pts[..., 2].abs() > 0.25)] = -1e3
+        dens[hip.volume.sigma2density(dens) < 0.5] = -1e3
+        assert torch.equal(out["densities"], dens) and (dens == -1e3).any()  # (the quirk culls all but saturated voxels)
+        vol = hip.volume.to_volume(out["densities"], N)
+        assert vol.shape == (1, 1, N, N, N)
+        half = hip.volume.density_grid(G, ws, {}, resolution=N, lo=0, hi=N ** 3 // 2)
+        assert torch.equal(half["sigmas"], out["sigmas"][:, :N ** 3 // 2])

@@ -164,3 +164,20 @@ def test_stylegan2_state_dict_matches_reference_names(P):
     G = sg.Generator(z_dim=512, c_dim=25, w_dim=512, img_resolution=256, img_channels=96, cond_mode="none",
                      mapping_kwargs={"num_layers": 2}, channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None)
     assert G.num_ws == 14 and G.synthesis.b256.conv1.weight.shape == (128, 128, 3, 3)
+
+
+def test_create_samples_matches_reference_formula(P):
+    """_util/eg3d_metrics3d.py:70-92 restated with the same float quirks; slab ranges concatenate to the full grid."""
+    N, L = 12, 0.7
+    full, origin, vs = P.volume.create_samples(N, cube_length=L)
+    idx = torch.arange(0, N ** 3, 1, out=torch.LongTensor())
+    ref = torch.zeros(N ** 3, 3)
+    ref[:, 2] = idx % N
+    ref[:, 1] = (idx.float() / N) % N
+    ref[:, 0] = ((idx.float() / N) / N) % N
+    o = np.array([0, 0, 0]) - L / 2
+    for k, j in ((0, 2), (1, 1), (2, 0)):
+        ref[:, k] = ref[:, k] * (L / (N - 1)) + o[j]
+    assert torch.equal(full[0], ref)
+    parts = [P.volume.create_samples(N, cube_length=L, lo=a, hi=b)[0] for a, b in ((0, 500), (500, 1000), (1000, N ** 3))]
+    assert torch.equal(torch.cat(parts, dim=1), full)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Timing of the StyleGAN2-256 triplane backbone (and the 512^2 super-resolution blocks) on the HIP synthesis operators.
+Secondary measurement (the contract benchmark is bench.py): ms per image and achieved fp32 MFMA TFLOP/s."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import panic3d_amd as P
+from panic3d_amd import stylegan2 as sg, generator as gen
+
+torch.manual_seed(0)
+dev = "cuda"
+
+
+def flops_backbone():
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128}
+    f = 0
+    for res, c in ch.items():
+        cin = ch[res // 2] if res > 4 else 0
+        if cin:
+            f += 2 * 9 * cin * c * (res // 2) ** 2  # transposed conv (useful MACs)
+        f += 2 * 9 * c * c * res * res
+        f += 2 * c * 96 * res * res
+    return f
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+G = sg.Generator(z_dim=512, c_dim=25, w_dim=512, img_resolution=256, img_channels=96, cond_mode="none",
+                 mapping_kwargs={"num_layers": 2}, channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None).to(dev).eval()
+out = {}
+with torch.no_grad():
+    for N in (1, 4):
+        ws = G.mapping(torch.randn(N, 512, device=dev), torch.zeros(N, 25, device=dev), {})
+        dt = timeit(lambda: G.synthesis(ws, {}, noise_mode="const"))
+        fl = flops_backbone() * N
+        out[f"backbone_N{N}"] = {"ms": dt * 1e3, "GFLOP": fl / 1e9, "TFLOP/s": fl / dt / 1e12, "frac_of_157.3": fl / dt / 157.3e12}
+    sr = gen.SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True, channels_hidden=256).to(dev).eval()
+    x = torch.randn(1, 32, 128, 128, device=dev); rgb = x[:, :3].contiguous(); ws = torch.randn(1, 14, 512, device=dev)
+    dt = timeit(lambda: sr(rgb, x, ws, noise_mode="none"))
+    fl = 2 * (9 * 32 * 256 * 128 ** 2 + 9 * 256 * 256 * 256 ** 2 + 256 * 3 * 256 ** 2 + 9 * 256 * 128 * 256 ** 2 + 9 * 128 * 128 * 512 ** 2 + 128 * 3 * 512 ** 2)
+    out["superres_N1"] = {"ms": dt * 1e3, "GFLOP": fl / 1e9, "TFLOP/s": fl / dt / 1e12, "frac_of_157.3": fl / dt / 157.3e12}
+print(json.dumps(out))
