@@ -11,7 +11,9 @@ A step = ImportanceRenderer.forward end to end on the HIP path: NCHW->NHWC plane
 gather of the final RGBA frames to rank 0.  Inputs (planes, rays, decoder) are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fused kernel against the HBM roofline using ALGORITHMIC bytes
-((Sc+Sf)*1536 + 172 bytes per ray); `cpu_baseline` times the CPU oracle (a port of the reference
+((Sc+Sf)*1536 + 172 bytes per ray — what the reference's algorithm touches per ray; the kernel's exact
+early-outs skip decodes whose result provably cannot change any output bit, `roofline.decode_steps_executed_frac` says
+how many it executed; --no-early-out measures without them); `cpu_baseline` times the CPU oracle (a port of the reference
 algorithm, OpenMP over rays) on a bounded sample of the same workload on the host cores.
 """
 import argparse
@@ -32,7 +34,8 @@ import torch.distributed as dist  # noqa: E402
 
 def make_scene(dev, seed, res, azim):
     """Synthetic subject: smooth blobs (16x16 noise upsampled) + 10% white noise, scale 4; decoder with a strong sigma
-    row so that rays hit surfaces (saturating weights) or stay empty — like a trained model's planes."""
+    row and a negative sigma bias so that about half of the rays hit an opaque surface and the rest stay empty — the
+    coverage of a character in front of a white background, like a trained model's planes."""
     import panic3d_amd as P
     g = torch.Generator().manual_seed(seed)
     low = torch.randn(3, 32, 16, 16, generator=g)
@@ -42,8 +45,8 @@ def make_scene(dev, seed, res, azim):
     b0 = torch.randn(64, generator=g) * 0.5
     w1 = torch.randn(33, 64, generator=g)
     b1 = torch.randn(33, generator=g) * 0.5
-    b1[0] += 1.0
     w1[0] *= 30.0
+    b1[0] = -45.0  # with the x30 sigma row: ~55 % of the rays hit a surface, the rest see empty space (character-like coverage)
     label = P.cameras.camera_label(0.0, azim, 1.0, 30.0)
     o, d = P.cameras.rays_from_label(label[None], res)
     return planes, (w0, b0, w1, b1), o, d
@@ -89,6 +92,7 @@ def main():
     ap.add_argument("--sc", type=int, default=48)
     ap.add_argument("--sf", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-early-out", action="store_true", help="decode every sample (disable the exact early-outs)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +117,7 @@ def main():
     planes_c, raw_c, o_c, d_c = make_scene(dev, 0, res, azim=20.0 + 360.0 * rank / max(world, 1))
     planes, o, d = planes_c.to(dev), o_c.to(dev), d_c.to(dev)
     mlp = ops.prescale_mlp(*(x.to(dev) for x in raw_c), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
-    opts = ops.make_opts(ro, **kw)
+    opts = ops.make_opts(ro, early_out=not a.no_early_out, **kw)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
@@ -149,6 +153,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    st = {}
+    ops.render(ops.planes_to_nhwc(planes), o, d, torch.rand((1, R, Sc, 1), device=dev), torch.rand((R, max(Sf, 1)), device=dev) if Sf > 0 else None,
+               mlp, opts, ray_tile_w=res, stats=st)  # untimed: decode-step statistics of one launch
     if rank == 0:
         rays = world * R * a.steps
         bytes_per_ray = (Sc + Sf) * 1536 + 172
@@ -171,8 +178,10 @@ def main():
                        "rays_per_step_per_gpu": R, "samples_per_ray": Sc + Sf, "parallelism": f"views x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "k_render (p3d_render_f32)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": R * bytes_per_ray},
-            "wsum_mean": float(ws.mean().item()),
+                         "algorithmic_bytes_per_launch": R * bytes_per_ray,
+                         "decode_steps_executed_frac": st["decode_steps"] / st["decode_steps_full"],
+                         "early_out": not a.no_early_out},
+            "wsum_mean": float(ws.mean().item()), "hit_fraction": float((ws > 0.5).float().mean().item()),
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(planes_c, raw_c, o_c, d_c, ro, kw, res)

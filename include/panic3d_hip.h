@@ -35,6 +35,7 @@ extern "C" {
 #define P3D_FLAG_BINARIZE 4      /* binarize_clouds given        (renderer.py:190-193) */
 #define P3D_FLAG_FORCE_SIGMOID 8 /* OSGDecoder.force_sigmoid     (training/triplane.py:539-542) */
 #define P3D_FLAG_WHITE_BACK 16   /* rendering_options.white_back (ray_marcher.py:52-53) */
+#define P3D_FLAG_NO_EARLY_OUT 32 /* p3d_render_f32: disable the exact early-outs (decode every sample; measurement / tests) */
 
 #define P3D_C 32        /* channels per plane (triplane_width, training/triplane.py:41) */
 #define P3D_HID 64      /* OSGDecoder hidden_dim (training/triplane.py:519) */
@@ -87,7 +88,8 @@ int p3d_triplane_decode_f32(const float* planes_nhwc, int N, int H, int W, const
  * torch.rand_like draw of renderer.py:324); u [N*R][Sf] (the torch.rand draw of :371; may be NULL when Sf == 0).
  * ray_tile_w: image width in rays if the R rays are a row-major ray_tile_w x (R/ray_tile_w) image (enables 8x4 screen
  * tiles per wavefront), 0 for an unstructured ray list.  Outputs feat [N][R][32], depth [N][R], wsum [N][R],
- * xyz [N][R][3].  workspace: p3d_render_workspace_bytes bytes of device memory (holds the global depth min/max). */
+ * xyz [N][R][3].  workspace: p3d_render_workspace_bytes bytes of device memory: u32[0..1] = order-mapped global depth
+ * min / max, u64 at byte 8 = number of wave-level decode steps the launch executed (statistics; 32 samples each). */
 size_t p3d_render_workspace_bytes(int N, int64_t R, int Sc, int Sf);
 int p3d_render_f32(const float* planes_nhwc, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
                    int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
@@ -100,7 +102,7 @@ int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta,
                               float* out_depths, void* stream);
 
 /* MipRayMarcher2.run_forward (ray_marcher.py:25-57).  colors [NR][S][K], sigma [NR][S], depths [NR][S] ->
- * out_rgb [NR][K], out_depth [NR], out_weights [NR][S-1] (may be NULL).  workspace: 8 bytes (global depth min/max). */
+ * out_rgb [NR][K], out_depth [NR], out_weights [NR][S-1] (may be NULL).  workspace: 16 bytes (global depth min/max). */
 int p3d_composite_f32(const float* colors, const float* sigma, const float* depths, int64_t NR, int S, int K,
                       int white_back, float* out_rgb, float* out_depth, float* out_weights, void* workspace,
                       void* stream);

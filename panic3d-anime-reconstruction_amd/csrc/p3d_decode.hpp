@@ -164,180 +164,6 @@ struct P3dDecodeCfg {
     int plane_mode, flags;
 };
 
-template <bool WANT_RGB, typename RSRC>
-P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
-                             float py, float pz, float& sigma_out, f32x16& rgb);
-
-// ---- the three stages of one decode ---------------------------------------------------------------------------------
-struct P3dTaps {
-    f32x16 v[12];  // plane p, tap q -> v[4p+q], this lane's 16 channels
-    float w[12];   // bilinear weights
-};
-
-// stage 1: addresses + 48 buffer_load_dwordx4 in flight (192 VGPRs of landing space)
-template <typename RSRC>
-P3D_DEV void p3d_gather_issue(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz,
-                              P3dTaps& T) {
-    const uint32_t chan_off = (uint32_t)(__lane_id() >> 5) * 64u;
-    float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
-    float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;                   // renderer.py:41-49
-    uint32_t of[12];
-    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of + 0, T.w + 0);
-    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of + 4, T.w + 4);
-    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of + 8, T.w + 8);
-#pragma unroll
-    for (int q = 0; q < 12; ++q) T.v[q] = p3d_load16(rs, of[q]);
-}
-
-// stage 2: bilinear interpolation + mean over the three planes (triplane.py:530)
-P3D_DEV f32x16 p3d_gather_finish(const P3dTaps& T) {
-    f32x16 f0 = p3d_bilerp(T.w + 0, T.v[0], T.v[1], T.v[2], T.v[3]);
-    f32x16 f1 = p3d_bilerp(T.w + 4, T.v[4], T.v[5], T.v[6], T.v[7]);
-    f32x16 f2 = p3d_bilerp(T.w + 8, T.v[8], T.v[9], T.v[10], T.v[11]);
-    f32x16 X;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) X[c] = ((f0[c] + f1[c]) + f2[c]) * P3D_THIRD;
-    return X;
-}
-
-// stage 3: OSGDecoder on the matrix cores + masks.  Branch-free (flags become selects) so that a caller's loop body stays
-// one basic block and the scheduler can interleave this stage with the next sample's stages 1-2.
-template <bool WANT_RGB>
-P3D_DEV void p3d_mlp(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
-                     f32x16& rgb) {
-    const int lane = __lane_id();
-    const int h = lane >> 5;
-    // ---- layer 1: acc[t][r] = b0[n] + sum_k w0[n][k] X[k], n = 32t + rowof(r) + 4h
-    const f32x4* b0p = (const f32x4*)(lds + P3D_LDS_B0P + h * 32);
-    f32x16 acc0, acc1;
-    {
-        f32x4 q0 = b0p[0], q1 = b0p[1], q2 = b0p[2], q3 = b0p[3];
-        f32x4 r0 = b0p[4], r1 = b0p[5], r2 = b0p[6], r3 = b0p[7];
-        acc0 = (f32x16){q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-        acc1 = (f32x16){r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-    }
-    const f32x4* w0a = (const f32x4*)(lds + P3D_LDS_W0A) + lane;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        f32x4 a0 = w0a[(0 * 4 + s4) * 64];
-        f32x4 a1 = w0a[(1 * 4 + s4) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc0 = P3D_MFMA(a0[e], X[4 * s4 + e], acc0);
-            acc1 = P3D_MFMA(a1[e], X[4 * s4 + e], acc1);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {  // Softplus: triplane.py:524
-        acc0[r] = p3d_softplus(acc0[r]);
-        acc1[r] = p3d_softplus(acc1[r]);
-    }
-    // ---- sigma row on the VALU: two half chains joined across the lane pair (triplane.py:543)
-    const f32x4* w1s = (const f32x4*)(lds + P3D_LDS_W1S + h * 32);
-    float sa = (h == 0) ? lds[P3D_LDS_B1S] : 0.0f;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        f32x4 w = w1s[s4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sa = p3d_fma(w[e], acc0[4 * s4 + e], sa);
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        f32x4 w = w1s[4 + s4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sa = p3d_fma(w[e], acc1[4 * s4 + e], sa);
-    }
-    float sigma = sa + p3d_partner(sa);
-    if (WANT_RGB) {  // ---- layer 2 rows 1..32 + sigmoid (triplane.py:539-542)
-        const f32x4* b1p = (const f32x4*)(lds + P3D_LDS_B1P + h * 16);
-        f32x4 q0 = b1p[0], q1 = b1p[1], q2 = b1p[2], q3 = b1p[3];
-        f32x16 o = (f32x16){q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-        const f32x4* w1a = (const f32x4*)(lds + P3D_LDS_W1A) + lane;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            f32x4 a = w1a[(0 * 4 + s4) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o = P3D_MFMA(a[e], acc0[4 * s4 + e], o);
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            f32x4 a = w1a[(1 * 4 + s4) * 64];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o = P3D_MFMA(a[e], acc1[4 * s4 + e], o);
-        }
-        const bool fs = (cfg.flags & P3D_FLAG_FORCE_SIGMOID) != 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float sg = p3d_sigmoid(o[r]);
-            float alt = sg * 1.002f - 0.001f;
-            rgb[r] = fs ? sg : alt;
-        }
-    }
-    // ---- masks on raw sigma: renderer.py:138-153,187-198
-    const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0, f_bin = (cfg.flags & P3D_FLAG_BINARIZE) != 0,
-               f_cull = (cfg.flags & P3D_FLAG_CULL) != 0;
-    bool outside = __builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit;
-    sigma = (f_crop && outside) ? P3D_SIGMA_MASKED : sigma;
-    float a = 1.0f - p3d_exp_nonpos(-p3d_softplus(sigma - 1.0f));
-    bool below = a < cfg.cull_thresh;
-    float sb = below ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
-    float sc = below ? P3D_SIGMA_MASKED : sigma;
-    sigma_out = f_bin ? sb : (f_cull ? sc : sigma);
-}
-
-// Decode a stream of `count` samples of this wave's rays: t = next_t() (called in order; it must stay callable past the
-// end of the stream, returning any finite depth),
-// p = o + t*d, consume(m, t, px, py, pz, sigma, rgb).
-//   PIPE == 0: gather -> MLP -> consume, one sample at a time with a plane-at-a-time gather (<= 256 VGPRs: two waves per
-//              SIMD overlap each other's phases).
-//   PIPE == 1: software pipeline for ONE wave per SIMD (512 VGPRs): while sample m runs through the MLP, the 48 tap loads
-//              of sample m+2 are in flight and sample m+1 is interpolated.
-template <bool WANT_RGB, int PIPE, typename RSRC, typename NextT, typename Consume>
-P3D_DEV void p3d_decode_stream(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float ox,
-                               float oy, float oz, float dx, float dy, float dz, int count, NextT next_t,
-                               Consume consume) {
-    if (PIPE == 0) {
-        for (int m = 0; m < count; ++m) {
-            float t = next_t();
-            float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
-            float sigma;
-            f32x16 rgb;
-            p3d_decode_wave<WANT_RGB>(lds, rs, g, cfg, px, py, pz, sigma, rgb);
-            consume(m, t, px, py, pz, sigma, rgb);
-        }
-    } else {
-        if (count <= 0) return;
-        P3dTaps T;
-        float t0 = next_t();
-        float p0x = ox + t0 * dx, p0y = oy + t0 * dy, p0z = oz + t0 * dz;
-        p3d_gather_issue(rs, g, cfg, p0x, p0y, p0z, T);
-        f32x16 X = p3d_gather_finish(T);
-        float t1 = next_t();
-        float p1x = ox + t1 * dx, p1y = oy + t1 * dy, p1z = oz + t1 * dz;
-        p3d_gather_issue(rs, g, cfg, p1x, p1y, p1z, T);
-        for (int m = 0; m < count; ++m) {
-            // sample m+1: taps were issued one iteration ago
-            f32x16 Xn = p3d_gather_finish(T);
-            // Only MFMA / LDS reads / SALU may move across this point: the interpolation VALU stays above it and the new
-            // loads below it, so the 48 new loads land in the registers the interpolation just freed (otherwise the
-            // scheduler hoists them and needs 2 x 192 landing registers -> spills).
-            __builtin_amdgcn_sched_barrier(0x10C);
-            // sample m+2: issue its loads into the registers just freed
-            float t2 = next_t();
-            float p2x = ox + t2 * dx, p2y = oy + t2 * dy, p2z = oz + t2 * dz;
-            p3d_gather_issue(rs, g, cfg, p2x, p2y, p2z, T);
-            // sample m: MLP + consumer (independent of the two stages above -> interleaved by the scheduler)
-            float sigma;
-            f32x16 rgb;
-            p3d_mlp<WANT_RGB>(lds, cfg, X, p0x, p0z, sigma, rgb);
-            consume(m, t0, p0x, p0y, p0z, sigma, rgb);
-            X = Xn;
-            t0 = t1; p0x = p1x; p0y = p1y; p0z = p1z;
-            t1 = t2; p1x = p2x; p1y = p2y; p1z = p2z;
-        }
-    }
-}
-
 // Decode one sample per lane pair.  All 64 lanes must be active.  lds = workgroup MLP image (p3d_load_mlp_to_lds).
 // Returns sigma (after masks) and, if WANT_RGB, this lane's 16 colour channels: register r holds channel
 // rowof(r) + 4h  (channels {0-3,8-11,16-19,24-27} for h = 0, {4-7,12-15,20-23,28-31} for h = 1).

@@ -209,10 +209,17 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 }
 
 // NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
-// PIPE: 0 = two waves per SIMD (<= 256 VGPRs), 1 = one software-pipelined wave per SIMD (p3d_decode_stream).
-// DUMP: per-stage dumps (parity tests).
-template <int NF, int PIPE, bool DUMP>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_render(RenderParams p) {
+// DUMP: per-stage dumps (parity tests; disables the early-outs so that every dumped density is a real decode).
+//
+// Exact early-outs (EARLY = !DUMP && !(flags & P3D_FLAG_NO_EARLY_OUT)), both decided per wavefront:
+//   * dead rays: once the binary64 transmittance of a ray is below 1e-60 every later weight alpha * (float)Td is exactly 0
+//     (alpha <= 1; Td can grow by at most (1 + 1e-10) per step), so its remaining samples cannot change any output;
+//   * cropped samples: triplane_crop masks by POSITION (renderer.py:138-149), so sigma = -1000 is known without a decode.
+//   A step whose 32 rays are all dead or cropped skips gather + MLP.  In the final pass a skipped sample's colour is
+//   needed only if one of its two interval weights is non-zero (sigma of the neighbour >= ~794); that is checked on the
+//   exact weights and, if it ever happens, the sample is decoded after all — results are bit-identical by construction.
+template <int NF, bool DUMP>
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
     __syncthreads();
@@ -250,6 +257,9 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_rende
     const float* pbase = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
     const P3dDecodeCfg cfg = p.cfg;
+    const bool early = !DUMP && !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);
+    const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0;
+    int ndec = 0;  // decode steps this wave executed (statistics)
 
     const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
     const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
@@ -280,21 +290,29 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_rende
         // ---- coarse pass, densities only -> ray-marcher weights: renderer.py:179-211
         MarchState st;
         st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
-        int ci = 0;
-        auto next_t = [&]() { float t = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j]; ++ci; return t; };
-        auto consume = [&](int i, float t, float px, float py, float pz, float sigma, const f32x16& rgb) {
-            (void)px; (void)py; (void)pz; (void)rgb;
+        for (int i = 0; i < Sc; ++i) {
+            float t = tcA[i * 32 + j];
+            float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
+            float sigma = P3D_SIGMA_MASKED;
+            bool skip = false;
+            if (early) {
+                bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+                skip = __builtin_amdgcn_ballot_w64(!(cropped || st.Td < 1e-60)) == 0;
+            }
+            if (!skip) {
+                f32x16 dummy;
+                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy);
+            }
             if constexpr (DUMP) if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
-            // interval (i-1, i); for i == 0 the state holds dummies: the weight lands in row 0 and is overwritten by i == 1
-            float tm;
-            MarchState s2 = st;
-            float w = p3d_march_weight(s2, t, sigma, tm);
-            st.Td = (i > 0) ? s2.Td : st.Td;
-            wcA[(i > 0 ? i - 1 : 0) * 32 + j] = w;
-            if constexpr (DUMP) if (dump && i > 0 && p.dumps.weights_coarse) p.dumps.weights_coarse[ray * (Sc - 1) + i - 1] = w;
+            if (i > 0) {
+                float tm;
+                float w = p3d_march_weight(st, t, sigma, tm);
+                wcA[(i - 1) * 32 + j] = w;
+                if constexpr (DUMP) if (dump && p.dumps.weights_coarse) p.dumps.weights_coarse[ray * (Sc - 1) + i - 1] = w;
+            }
             st.prev_t = t; st.prev_sigma = sigma;
-        };
-        p3d_decode_stream<false, PIPE>(lds, rs, g, cfg, ox, oy, oz, dx, dy, dz, Sc, next_t, consume);
+            if constexpr (!DUMP) ndec += skip ? 0 : 1;
+        }
         // ---- sample_importance / sample_pdf: renderer.py:328-387 (per ray; both lanes of a pair compute the same)
         const int Ns = Sc - 3;
         {
@@ -365,42 +383,64 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_rende
     {
         int ci = 0, fi = 0;
         float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
-        auto next_t = [&]() {
+        bool prev_skipped = false;
+        for (int m = 0; m < S; ++m) {
             bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
-            float t = take_c ? ta : tb;
+            const float t = take_c ? ta : tb;
             ci += take_c ? 1 : 0;
             fi += take_c ? 0 : 1;
-            float na = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
-            float nb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
-            ta = take_c ? na : ta;
-            tb = take_c ? tb : nb;
-            return t;
-        };
-        auto consume = [&](int m, float t, float px, float py, float pz, float sigma, const f32x16& rgb) {
+            if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
+            else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
             tmin = __builtin_fminf(tmin, t);
             tmax = __builtin_fmaxf(tmax, t);
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            float sigma = P3D_SIGMA_MASKED;
+            f32x16 rgb;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
+            bool skipped = false;
+            if (early) {
+                bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+                skipped = __builtin_amdgcn_ballot_w64(!(cropped || st.Td < 1e-60)) == 0;
+            }
+            if (!skipped) {
+                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb);
+                if constexpr (!DUMP) ndec += 1;
+            }
             if constexpr (DUMP) {
                 if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
                 if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * S + m] = sigma;
             }
-            // interval (m-1, m); m == 0 has no interval: its weight is forced to 0 and the transmittance kept
-            float tm;
-            MarchState s2 = st;
-            float w = p3d_march_weight(s2, t, sigma, tm);
-            w = (m > 0) ? w : 0.0f;
-            st.Td = (m > 0) ? s2.Td : st.Td;
+            if (m > 0) {
+                float tm;
+                float w = p3d_march_weight(st, t, sigma, tm);
+                if (early) {  // exactness guard: a skipped endpoint whose interval weight is non-zero needs its real colour
+                    if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
+                        float s2;
+                        f32x16 c2;
+                        p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        if (prev_skipped) prev_rgb = c2;
+                        prev_skipped = false;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(skipped && w != 0.0f) != 0) {
+                        float s2;
+                        p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        skipped = false;
+                    }
+                }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
-            Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
-            Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
-            Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
-            st.W = st.W + w;
-            st.D = p3d_fma(w, (m > 0) ? tm : 0.0f, st.D);
+                for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+                Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+                Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+                Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                st.W = st.W + w;
+                st.D = p3d_fma(w, tm, st.D);
+            }
             st.prev_t = t; st.prev_sigma = sigma;
             prev_rgb = rgb;
+            prev_skipped = skipped;
             ppx = px; ppy = py; ppz = pz;
-        };
-        p3d_decode_stream<true, PIPE>(lds, rs, g, cfg, ox, oy, oz, dx, dy, dz, S, next_t, consume);
+        }
     }
     // ---- outputs.  white_back and the [-1,1] rescale are per ray (ray_marcher.py:52-55); the depth clamp is global.
     {
@@ -437,12 +477,15 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, (PIPE ? 1 : 2)) void k_rende
     if (lane == 0) {
         atomicMin(p.gminmax, p3d_f2ord(tmin));
         atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+        if constexpr (!DUMP) atomicAdd((unsigned long long*)(p.gminmax + 2), (unsigned long long)ndec);  // wave-level decode steps
     }
 }
 
 __global__ void k_minmax_init(uint32_t* g) {
     g[0] = 0xffffffffu;
     g[1] = 0u;
+    g[2] = 0u;  // [2..3]: 64-bit count of wave-level decode steps of the launch (statistics for bench.py)
+    g[3] = 0u;
 }
 
 __global__ void k_render_finish(float* depth, long long n, const uint32_t* g, float* dump_tminmax) {
@@ -697,29 +740,17 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         if (nwaves == 1) return P3D_E_RANGE;
     }
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
-    // PIPE = 1 (one software-pipelined wave per SIMD, p3d_decode_stream) measured 11.1 ms vs 5.6 ms for PIPE = 0 on
-    // MI355X (the compiler spills and does not interleave one wave's MFMA and VALU streams); build with
-    // -DP3D_ENABLE_PIPE1 to instantiate it again and select it with P3D_PIPE=1.
-#ifdef P3D_ENABLE_PIPE1
-    const char* pe = getenv("P3D_PIPE");
-    const int pipe = pe ? atoi(pe) : 0;
-#endif
     const bool dmp = dumps != nullptr;
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
     dim3 grid((unsigned)blocks), blk(64 * nwaves);
     hipError_t e = hipSuccess;
-#define P3D_LAUNCH(NFV, PV, DV)                                                                                      \
+#define P3D_LAUNCH(NFV, DV)                                                                                          \
     do {                                                                                                             \
-        e = hipFuncSetAttribute((const void*)k_render<NFV, PV, DV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+        e = hipFuncSetAttribute((const void*)k_render<NFV, DV>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                 (int)lds_bytes);                                                                     \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, PV, DV>), grid, blk, lds_bytes, st, p);              \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, DV>), grid, blk, lds_bytes, st, p);                  \
     } while (0)
-#define P3D_LAUNCH_D(NFV, PV) do { if (dmp) P3D_LAUNCH(NFV, PV, true); else P3D_LAUNCH(NFV, PV, false); } while (0)
-#ifdef P3D_ENABLE_PIPE1
-#define P3D_LAUNCH_P(NFV) do { if (pipe) P3D_LAUNCH_D(NFV, 1); else P3D_LAUNCH_D(NFV, 0); } while (0)
-#else
-#define P3D_LAUNCH_P(NFV) P3D_LAUNCH_D(NFV, 0)
-#endif
+#define P3D_LAUNCH_P(NFV) do { if (dmp) P3D_LAUNCH(NFV, true); else P3D_LAUNCH(NFV, false); } while (0)
     if (nf == 64) P3D_LAUNCH_P(64);
     else if (nf == 128) P3D_LAUNCH_P(128);
     else P3D_LAUNCH_P(0);

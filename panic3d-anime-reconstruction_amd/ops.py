@@ -32,7 +32,8 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_clouds=None, force_sigmoid=False):
+def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_clouds=None, force_sigmoid=False,
+              early_out=True):
     """rendering_kwargs + ImportanceRenderer.forward arguments (renderer.py:162) -> p3d_opts.
     The double -> binary32 conversions are the ones include/p3d_numerics.h states."""
     ro = rendering_options
@@ -63,6 +64,8 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= _lib.P3D_FLAG_FORCE_SIGMOID
     if ro.get("white_back", False):
         flags |= _lib.P3D_FLAG_WHITE_BACK
+    if not early_out:  # decode every sample even where the result provably cannot matter (measurement / tests)
+        flags |= _lib.P3D_FLAG_NO_EARLY_OUT
     rs, re = float(ro["ray_start"]), float(ro["ray_end"])
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
@@ -123,10 +126,11 @@ DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "
              "depth_unclamped", "tminmax")
 
 
-def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False):
+def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None):
     """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
     jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
-    Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps)."""
+    Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps).
+    `stats`: pass a dict to receive the number of decode steps the launch executed (exact early-outs, see k_render)."""
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     rays_o, rays_d, jitter = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions"), _chk(jitter, "jitter")
     N, three, H, W, Cc = planes_nhwc.shape
@@ -166,6 +170,10 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
                               _p(w0), _p(b0), _p(w1), _p(b1), C.byref(opts), _p(feat), _p(depth), _p(wsum), _p(xyz),
                               _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
     _lib.check(rc, "p3d_render_f32")
+    if stats is not None:  # synchronises: wave-level decode steps executed (32 samples each) vs the full count
+        steps = int(ws[8:16].view(torch.int64).item())
+        tiles = -(-R // 32) * N if not (ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0) else (R // 32) * N
+        stats.update(decode_steps=steps, decode_steps_full=tiles * (Sc + Sc + Sf if Sf > 0 else Sc))
     return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)
 
 

@@ -93,6 +93,29 @@ def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
         assert int((hdm["inds"] != g["inds"]).sum()) == 0
 
 
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+@pytest.mark.parametrize("early_out", [True, False])
+def test_render_production_kernel_bit_exact(hip, oracle, name, early_out):
+    """The kernel variant that ships (no dumps; with and without the exact early-outs) against the oracle: outputs only."""
+    g = T.load_golden(name + ".npz")
+    inp = T.golden_render_inputs(g)
+    R = inp["rays_o"].shape[1]
+    side = int(round(R ** 0.5))
+    ref = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
+                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]))
+    opts = hip.ops.make_opts(inp["ro"], early_out=early_out, **inp["kw"])
+    planes = hip.ops.planes_to_nhwc(dev(inp["planes"]))
+    st = {}
+    out = hip.ops.render(planes, dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"]),
+                         hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"]), opts,
+                         ray_tile_w=side if (side * side == R and side % 8 == 0) else 0, stats=st)
+    for name_, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
+        assert np.array_equal(a.cpu().numpy(), b), name_
+    assert 0 < st["decode_steps"] <= st["decode_steps_full"]
+    if not early_out:
+        assert st["decode_steps"] == st["decode_steps_full"]
+
+
 @pytest.mark.parametrize("ut", [0, 1])
 def test_decode_points(hip, oracle, ut):
     g = T.load_golden(f"decode_points_ut{ut}.npz")
