@@ -102,7 +102,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # torch.distributed.run (also with one rank)
+    if launched:
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
     import panic3d_amd as P
     from panic3d_amd import ops, sharding
@@ -130,25 +131,25 @@ def main():
         feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
         if i is not None:
             ev[i][1].record()
-        if world > 1:
-            sharding.gather_frames(sharding.frames_rgba(feat, wsum, res), counts=[1] * world, dst=0)
+        if launched:  # the path's only collective: final RGBA frames to rank 0
+            sharding.gather_frames(sharding.frames_rgba(feat, wsum, res), counts=[1] * world, dst=0, force=True)
         return wsum
 
     for _ in range(a.warmup):
         ws = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         ws = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -174,7 +175,7 @@ def main():
             "config": {"workload": f"c3: {res}x{res} rays/view, {Sc}+{Sf} samples/ray, one view per GPU per step, synthetic "
                                    "triplanes [1,3,32,256,256], random OSGDecoder, crop=0.1 cull=0.5 white_back, "
                                    "step = transpose + rand draws + fused render + depth clamp" +
-                                   (" + RCCL gather of RGBA frames" if world > 1 else ""),
+                                   (" + RCCL gather of RGBA frames" if launched else ""),
                        "rays_per_step_per_gpu": R, "samples_per_ray": Sc + Sf, "parallelism": f"views x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "k_render (p3d_render_f32)", "kernel_ms": kern_ms,
@@ -188,7 +189,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

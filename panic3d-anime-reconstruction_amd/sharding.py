@@ -22,11 +22,11 @@ def frames_rgba(feat, wsum, res):
     return rgba.permute(0, 2, 1).reshape(N, 4, res, res).contiguous()
 
 
-def gather_frames(local, counts=None, dst=0):
+def gather_frames(local, counts=None, dst=0, force=False):
     """Gather per-rank frame stacks [n_r,4,H,W] to rank `dst` in rank order.  Every rank pads to max(counts) so a single
     fixed-size collective is issued per sweep (one large message per xGMI link rather than one per frame).
     Returns the concatenated [sum n_r,4,H,W] tensor on dst, None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     if counts is None:

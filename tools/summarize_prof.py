@@ -35,7 +35,7 @@ def main():
         for fn in glob.glob(os.path.join(d, "*counter_collection.csv")):
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(fn)):
-                if r["Kernel_Name"].startswith("k_render") and "finish" not in r["Kernel_Name"]:
+                if ("k_render<" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_render(")) and "finish" not in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
                                               "LDS_Block_Size", "Scratch_Size")}
