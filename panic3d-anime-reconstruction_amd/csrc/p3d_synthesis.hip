@@ -56,6 +56,7 @@ struct ConvParams {
     int act;              // 0 linear, 1 lrelu
     float alpha, gain, clamp;
     int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
+    int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
@@ -70,13 +71,17 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N;
     constexpr int KC = CONV_IC * NT;  // k values per chunk
+    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * CONV_OT + 255) / 256;  // staged values per thread
     __shared__ float xs[CONV_IC * XS_PLANE];
     __shared__ float ws[KC * WS_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
     const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
     const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
-    const int o0 = blockIdx.y * CONV_OT, n = blockIdx.z;
+    const int o0 = blockIdx.y * CONV_OT;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;  // split-K slice of the input channels
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + CONV_IC - 1) / CONV_IC * CONV_IC;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
     const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
     const float* sn = p.styles + (size_t)n * p.I;
     const int kk9 = p.ks * p.ks;
@@ -88,27 +93,55 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     const int pix1 = pix0 + 2 * XS_ROW;                        // N tile 1 (two rows below)
     const int wcol = wc * 32 + j;
 
-    for (int ic0 = 0; ic0 < p.I; ic0 += CONV_IC) {
-        __syncthreads();
-        // ---- stage the modulated input patch: xs[ic][r][c] = s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c]  (zero outside)
-        for (int idx = tid; idx < CONV_IC * XS_PLANE; idx += 256) {
+    float xr[XN], wr[WN];
+    // global -> registers: modulated input patch s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c] (zero outside) and the weight slice
+    auto gload = [&](int ic0) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));  // keep the index arithmetic inside the loop (hoisted, it pins ~100 VGPRs)
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            int idx = tid_ + u * 256;
             int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
             int r = rem / XS_ROW, c = rem - r * XS_ROW;
             int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
             float v = 0.0f;
-            if (ci < p.I && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
-            xs[idx] = v;
+            if (idx < CONV_IC * XS_PLANE && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
+            xr[u] = v;
         }
-        // ---- stage the weights: ws[k][o] = w[o0+o][ic0 + k/NT][kidx[k%NT]]
-        for (int idx = tid; idx < KC * CONV_OT; idx += 256) {
+#pragma unroll
+        for (int u = 0; u < WN; ++u) {
+            int idx = tid_ + u * 256;
             int o = idx / KC, k = idx - o * KC;
             int ic = k / NT, t = k - ic * NT;
             int ci = ic0 + ic, oo = o0 + o;
             float v = 0.0f;
-            if (ci < p.I && oo < p.O) v = p.w[((size_t)oo * p.I + ci) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])];
-            ws[k * WS_ROW + o] = v;
+            if (idx < KC * CONV_OT && ci < ic_end && oo < p.O)
+                v = p.w[((size_t)oo * p.I + ci) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])];
+            wr[u] = v;
         }
-        __syncthreads();
+    };
+    auto lstore = [&]() {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            int idx = tid_ + u * 256;
+            if (idx < CONV_IC * XS_PLANE) xs[idx] = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WN; ++u) {
+            int idx = tid_ + u * 256;
+            int o = idx / KC, k = idx - o * KC;
+            if (idx < KC * CONV_OT) ws[k * WS_ROW + o] = wr[u];
+        }
+    };
+    gload(ic_beg);
+    lstore();
+    __syncthreads();
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += CONV_IC) {
+        const bool more = ic0 + CONV_IC < ic_end;
+        if (more) gload(ic0 + CONV_IC);  // next chunk's global loads are in flight during this chunk's MFMAs
 #pragma unroll
         for (int q = 0; q < KC / 2; ++q) {
             // lanes 0-31 take k = 2q, lanes 32-63 take k = 2q+1  (A[i][k], B[k][j] operand layout of 32x32x2)
@@ -122,9 +155,15 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
             float b1 = xs[xo + pix1];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            // keep the LDS operand reads at most 4 steps ahead of their MFMAs (hoisting all 3*KC/2 reads costs ~100 VGPRs)
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
+        if (more) lstore();
+        __syncthreads();
     }
-    // ---- epilogue
+    // ---- epilogue (ksplit > 1: raw partial sums into slice kz of the partial buffer)
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
@@ -141,9 +180,33 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
                 if (p.bias) v = v + p.bias[ch];
                 v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
             }
-            p.y[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
+            yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
         }
     }
+}
+
+// sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
+struct ReduceParams {
+    const float* part; float* y; const float* dcoef; const float* noise; const float* bias;
+    long long per_slice;  // N*O*OH*OW
+    int ksplit, O, OHW, noise_per_sample, act, epilogue;
+    float alpha, gain, clamp;
+};
+__global__ void k_splitk_reduce(ReduceParams p) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.per_slice) return;
+    float v = p.part[idx];
+    for (int k = 1; k < p.ksplit; ++k) v += p.part[(size_t)k * p.per_slice + idx];
+    if (p.epilogue) {
+        long long no = idx / p.OHW;
+        int pix = (int)(idx - no * p.OHW), ch = (int)(no % p.O);
+        long long n = no / p.O;
+        if (p.dcoef) v = v * p.dcoef[no];
+        if (p.noise) v = v + p.noise[(p.noise_per_sample ? n * p.OHW : 0) + pix];
+        if (p.bias) v = v + p.bias[ch];
+        v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+    }
+    p.y[idx] = v;
 }
 
 // d[n,o] = rsqrt(sum_i (sum_t w[o,i,t]^2) * s[n,i]^2 + 1e-8).  One wave per (n,o).
@@ -228,17 +291,28 @@ static inline int chk() {
 
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
-    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + CONV_OT - 1) / CONV_OT, p.N);
+    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + CONV_OT - 1) / CONV_OT,
+              p.N * p.ksplit);
     hipLaunchKernelGGL(k_modconv<MODE>, grid, dim3(256), 0, st, p);
+}
+
+// split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
+static int choose_ksplit(int N, int I, int O, int GH, int GW) {
+    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + CONV_OT - 1) / CONV_OT) * N;
+    int ks = 1;
+    while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 2 * CONV_IC) ks *= 2;
+    return ks;
 }
 
 extern "C" {
 
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) {
-    (void)I;
     size_t b = (size_t)N * O * 4 + 256;  // demodulation coefficients
-    if (up == 2) b += (size_t)N * O * (2 * H + 1) * (2 * W + 1) * 4;  // transposed-conv intermediate
-    return b;
+    size_t out_elems = (up == 2) ? (size_t)N * O * (2 * H + 1) * (2 * W + 1) : (size_t)N * O * H * W;
+    if (up == 2) b += out_elems * 4;  // transposed-conv intermediate
+    int ks = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
+    if (ks > 1) b += (size_t)ks * out_elems * 4;  // split-K partial sums
+    return b + 256;
 }
 
 int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
@@ -252,31 +326,45 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     hipStream_t st = (hipStream_t)stream;
     float* dco = (float*)workspace;
     float* tmp = dco + (((size_t)N * O + 63) / 64) * 64;
+    const int OH = (up == 2) ? 2 * H + 1 : H, OW = (up == 2) ? 2 * W + 1 : W;
+    const size_t out_elems = (size_t)N * O * OH * OW;
+    float* part = (up == 2) ? tmp + ((out_elems + 63) / 64) * 64 : tmp;
     if (demodulate) {
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
+    const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
     ConvParams p;
-    p.x = x; p.w = w; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias; p.y = y;
+    p.x = x; p.w = w; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
-    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW;
+    // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
+    float* conv_dst = (ksplit > 1) ? part : (up == 2 ? tmp : y);
+    p.y = conv_dst;
+    p.epilogue = (up == 1 && ksplit == 1) ? 1 : 0;
     if (up == 1) {
-        p.GH = H; p.GW = W; p.OH = H; p.OW = W; p.epilogue = 1;
+        p.GH = H; p.GW = W;
         if (ks == 3) launch_conv<0>(p, st); else launch_conv<1>(p, st);
-        return chk();
+    } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1], one launch per output phase
+        p.GH = H + 1; p.GW = W + 1; launch_conv<2>(p, st);
+        p.GH = H + 1; p.GW = W;     launch_conv<3>(p, st);
+        p.GH = H;     p.GW = W + 1; launch_conv<4>(p, st);
+        p.GH = H;     p.GW = W;     launch_conv<5>(p, st);
     }
-    // up == 2: stride-2 transposed conv into tmp [N][O][2H+1][2W+1] (4 phases), then FIR (pad 1, gain) + epilogue
-    p.y = tmp; p.OH = 2 * H + 1; p.OW = 2 * W + 1; p.epilogue = 0;
-    p.GH = H + 1; p.GW = W + 1; launch_conv<2>(p, st);
-    p.GH = H + 1; p.GW = W;     launch_conv<3>(p, st);
-    p.GH = H;     p.GW = W + 1; launch_conv<4>(p, st);
-    p.GH = H;     p.GW = W;     launch_conv<5>(p, st);
+    if (ksplit > 1) {
+        ReduceParams r;
+        r.part = part; r.y = (up == 2) ? tmp : y; r.dcoef = p.dcoef; r.noise = noise; r.bias = bias;
+        r.per_slice = (long long)out_elems; r.ksplit = ksplit; r.O = O; r.OHW = OH * OW; r.noise_per_sample = noise_per_sample;
+        r.act = act; r.epilogue = (up == 1) ? 1 : 0; r.alpha = alpha; r.gain = gain; r.clamp = clamp;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, r);
+    }
+    if (up == 1) return chk();
+    // FIR (pad 1; the caller passes the 4x4 filter already flipped and multiplied by up^2, upfirdn2d.py:193-196) + epilogue
     FirParams q;
     q.x = tmp; q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
     q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
     q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
     q.alpha = alpha; q.gain = gain; q.clamp = clamp;
-    // the caller passes the 4x4 filter already flipped and multiplied by up^2 (upfirdn2d.py:193-196)
     long long total = q.NC * q.OH * q.OW;
     hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
     return chk();
