@@ -4,8 +4,8 @@ checkpoint's init kwargs and copy the parameters by name), with the backbone on 
 (stylegan2.py), the volumetric renderer on the fused HIP kernel (renderer.py) and the super-resolution blocks on the same
 modulated-conv kernel.
 
-Inference only.  Not mirrored: `sample` (broken in the reference, triplane.py:254-271) and the `paste_front`
-post-process (triplane.py:555-691, next row of SURVEY.md §8f) — `f()` raises if `paste_params` is given.
+Inference only.  Not mirrored: `sample` (broken in the reference, triplane.py:254-271).  The `paste_front`
+post-process (triplane.py:555-691) lives in paste.py.
 """
 import numpy as np
 import torch
@@ -141,6 +141,8 @@ class TriPlaneGenerator(torch.nn.Module):
         if cache_backbone:
             self._last_planes = planes
         draws = self._inject_draws or (None, None)
+        if isinstance(draws, list):  # tests: one (jitter, u) pair per renderer pass, consumed in call order
+            draws = draws.pop(0)
         feat, depth, wsum, xyz = self.renderer(planes, self.decoder, ray_origins.contiguous(), ray_directions.contiguous(),
                                                self.rendering_kwargs, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
                                                binarize_clouds=binarize_clouds, jitter=draws[0], u=draws[1])
@@ -236,8 +238,11 @@ class TriPlaneGenerator(torch.nn.Module):
         ret = {k: synth[k] for k in ("image", "image_raw", "image_depth", "image_weights", "triplane", "image_xyz")}
         ret["normalize_images"] = normalize_images
         x.update(ret)
-        if x.get("paste_params") is not None:
-            raise NotImplementedError("paste_front (triplane.py:555-691) is the next row of the build plan (SURVEY.md §8f-4)")
+        if x.get("paste_params") is not None:  # front-view paste post-process (triplane.py:497-502)
+            from .paste import paste_front
+            ret["image_prepaste"] = ret["image"]
+            ret["paste"] = paste_front(self, x, ret, **x["paste_params"])
+            ret["image"] = ret["paste"]["image"]
         return ret
 
     def set_force_sigmoid(self, state):

@@ -1,0 +1,67 @@
+"""`paste_front` — the front-view paste post-process of TriPlaneGenerator.f (training/triplane.py:553-691): where the
+rendered surface is visible from the orthographic front view, the super-resolved colour is replaced by the input
+illustration sampled at the rendered xyz.  Host glue on device tensors (bilinear resizes, Sobel, grid_sample, lerp) plus
+ONE extra pass through the fused renderer for the front-occlusion test (rays from the rendered surface points towards
+the front plane, triplane.py:565-578).
+
+kornia is not a dependency: `sobel_magnitude` restates kornia 0.6.5 `kornia.filters.sobel(x, normalized=True, eps=1e-6)`
+(3x3 Sobel kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + eps)).  `front_weight_erosion >= 1`
+(kornia.morphology.erosion; not used by _scripts/eval/generate.py:55-66) is not mirrored.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def sobel_magnitude(x, eps=1e-6):
+    b, c, h, w = x.shape
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=x.device, dtype=x.dtype) / 8.0
+    k = torch.stack([kx, kx.t()])[:, None]  # [2,1,3,3]: d/dx, d/dy
+    g = F.conv2d(F.pad(x.reshape(b * c, 1, h, w), [1, 1, 1, 1], mode="replicate"), k)
+    return torch.sqrt(g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1] + eps).reshape(b, c, h, w)
+
+
+def sample_orthofront(front_rgb, view_xyz, bw):
+    """Colour of the front illustration at the (x, y) of every rendered surface point (triplane.py:555-564)."""
+    vij = 1 - (view_xyz[:, [1, 0]] + bw / 2) / bw
+    return F.grid_sample(front_rgb.permute(0, 1, 3, 2), vij.permute(0, 2, 3, 1) * 2 - 1, padding_mode="border",
+                         mode="bilinear", align_corners=False)
+
+
+def front_occlusion(G, x, out, offset=0.01):
+    """Accumulated opacity between every rendered surface point and the front plane (triplane.py:565-578)."""
+    ro = out["image_xyz"] * torch.tensor([-1, 1, -1], device=out["image_xyz"].device)[None, :, None, None]
+    ro[:, 2, :, :] -= G.rendering_kwargs["ray_start"] - offset
+    rd = torch.zeros_like(out["image_xyz"])
+    rd[:, 2, :, :] = 1
+    xin = {**x, "paste_params": None, "force_rays": {"ray_origins": ro, "ray_directions": rd}}
+    return G.f(xin)["image_weights"]
+
+
+def xyz_discrepancy(xyz, rays):
+    """Distance of the rendered xyz from its own ray (triplane.py:600-605)."""
+    a, n = rays["ray_origins"], rays["ray_directions"]
+    p = xyz * torch.tensor([-1, 1, -1], device=xyz.device)[None, :, None, None]
+    return ((p - a) - ((p - a) * n).sum(dim=1, keepdim=True) * n).norm(2, dim=1, keepdim=True)
+
+
+def paste_front(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02, thresh_occ=0.05, offset_occ=0.01,
+                thresh_dxyz=0.01, front_weight_erosion=0, grad_sample=False, force_image=None, **kwargs):
+    if front_weight_erosion >= 1 or force_image is not None:
+        raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
+    view_xyz = out["image_xyz"]
+    front_rgb = x["cond"]["image_ortho_front"]
+    S = front_rgb.shape[-1]
+    with torch.no_grad():
+        wmask = (F.interpolate(out["image_weights"], S, mode="bilinear") > thresh_weight).float()
+        smask = sobel_magnitude(F.interpolate(view_xyz, S, mode="bilinear")).norm(2, dim=1, keepdim=True)
+        smask = (smask < thresh_edges).float()
+        fmask = (front_occlusion(G, x, out, offset=offset_occ) < thresh_occ).float()
+        fmask = F.interpolate(fmask, S, mode="bilinear")
+        dmask = F.interpolate(xyz_discrepancy(view_xyz, x["force_rays"]), S, mode="nearest")
+        dmask = (dmask < thresh_dxyz).float()
+        fwmask = torch.ones_like(dmask)
+        mask = wmask * smask * fmask * dmask * fwmask
+        tocopy = front_rgb if not x["normalize_images"] else front_rgb * 2 - 1
+        paste = sample_orthofront(tocopy, F.interpolate(view_xyz, S, mode="bilinear"), G.rendering_kwargs["box_warp"])
+    return {"image": torch.lerp(out["image"], paste, mask), "paste": paste, "mask": mask, "mask_weights": wmask,
+            "mask_edges": smask, "mask_occ": fmask, "mask_dxyz": dmask, "mask_frontweight": fwmask, "frontweight": None}

@@ -133,7 +133,11 @@ def triplane_case():
     for n, p in G.named_parameters():
         if n.endswith(".bias") and "affine" not in n:
             p.copy_(torch.randn(p.shape, generator=gg) * 0.2)
+    for n, p in G.backbone.synthesis.named_parameters():  # random-init ToRGB gives planes ~0: scale them to O(1) features
+        if n.endswith("torgb.weight"):
+            p.mul_(30.0)
     G.decoder.net[2].weight[0] *= 20.0  # solid-ish density field
+    G.decoder.net[2].bias[0] = 25.0
     G.set_force_sigmoid(True)
     rec = {}
     o_rl, o_r = torch.rand_like, torch.rand
@@ -159,6 +163,39 @@ def triplane_case():
     arrs = {k: out[k].numpy() for k in ("image_raw", "image_depth", "image_weights", "image_xyz", "triplane")}
     arrs["image_sub4"] = out["image"][..., ::4, ::4].contiguous().numpy()  # every 4th pixel of the 512^2 SR image (fixture size)
     arrs.update(jitter=rec["jitter"].numpy(), u=rec["u"].numpy(), ws=x["ws"].numpy(), camera_params=x["camera_params"].numpy())
+    # ---- the same call with the front-view paste (generate.py:55-66).  kornia is not installed: its Sobel filter is
+    # restated in the product (paste.sobel_magnitude, kornia 0.6.5 semantics) and injected here under kornia's name, so this
+    # fixture pins the paste GLUE (masks, second render pass, grid_sample, lerp), not kornia itself.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import panic3d_amd.paste as my_paste
+    import kornia
+    kornia.filters = types.SimpleNamespace(sobel=my_paste.sobel_magnitude)
+    front = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(11))
+    xp = dict(elevations=torch.tensor([0.0]), azimuths=torch.tensor([0.0]), fovs=torch.tensor([-1.0]), seeds=[3],
+              cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16,
+              paste_params={"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5,
+                            "offset_occ": 0.01, "thresh_dxyz": 0.05})
+    rec.clear()
+    draws = []
+    def rand_like2(t, *a, **k):
+        r = o_rl(t, *a, **k); draws.append(r.clone()); return r
+    def rand2(*a, **k):
+        r = o_r(*a, **k); draws.append(r.clone()); return r
+    torch.rand_like, torch.rand = rand_like2, rand2
+    try:
+        torch.manual_seed(10)
+        outp = G.f(xp)
+    finally:
+        torch.rand_like, torch.rand = o_rl, o_r
+    assert len(draws) == 4  # two renderer passes (view + front-occlusion), two draws each
+    print("paste fixture: weights mean %.3f; mask means:" % float(outp["image_weights"].mean()),
+          {k: round(float(v.mean()), 3) for k, v in outp["paste"].items() if k.startswith("mask")})
+    arrs.update({"paste_" + k: outp["paste"][k].numpy() for k in ("mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz")})
+    arrs["paste_image_sub4"] = outp["image"][..., ::4, ::4].contiguous().numpy()
+    arrs["paste_prepaste_sub4"] = outp["image_prepaste"][..., ::4, ::4].contiguous().numpy()
+    arrs["paste_paste_sub4"] = outp["paste"]["paste"][..., ::4, ::4].contiguous().numpy()
+    for i, dr in enumerate(draws):
+        arrs[f"paste_draw{i}"] = dr.numpy()
     pts = (torch.rand(2, 500, 3, generator=gg) - 0.5) * 0.6
     sm = G.sample_mixed(pts, None, x["ws"], {}, noise_mode="const")
     arrs.update(sm_pts=pts.numpy(), sm_sigma=sm["sigma"].numpy(), sm_rgb=sm["rgb"].numpy())

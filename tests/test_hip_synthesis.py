@@ -176,8 +176,34 @@ def test_triplane_generator_f_vs_reference(hip):
         assert out["image"].shape == (2, 3, 512, 512) and d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
         sm = G.sample_mixed(dev(g["sm_pts"]), None, dev(g["ws"]), {}, noise_mode="const")
         assert rel_err(sm["sigma"].cpu().numpy(), g["sm_sigma"]) < 1e-3 and np.abs(sm["rgb"].cpu().numpy() - g["sm_rgb"]).max() < 1e-3
-    with pytest.raises(NotImplementedError):
-        G.f(dict(x, paste_params={"thresh": 0.5}))
+
+
+def test_paste_front_vs_reference(hip):
+    """f() with paste_params (generate.py:55-66): masks, the extra front-occlusion render pass, grid_sample of the input
+    illustration and the final lerp, against the reference's paste_front (with kornia's Sobel restated, see paste.py)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    G._inject_draws = [(dev(g["paste_draw0"]), dev(g["paste_draw1"])), (dev(g["paste_draw2"]), dev(g["paste_draw3"]))]
+    front = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(11))
+    xp = dict(elevations=torch.tensor([0.0]).cuda(), azimuths=torch.tensor([0.0]).cuda(), fovs=torch.tensor([-1.0]).cuda(),
+              seeds=[3], cond={"image_ortho_front": front.cuda()}, triplane_crop=0.1, cull_clouds=0.5,
+              neural_rendering_resolution=16,
+              paste_params={"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5,
+                            "offset_occ": 0.01, "thresh_dxyz": 0.05})
+    with torch.no_grad():
+        out = G.f(xp)
+    assert G._inject_draws == []  # both renderer passes ran
+    for k in ("mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz"):
+        a, b = out["paste"][k].cpu().numpy(), g["paste_" + k]
+        assert a.shape == b.shape and (np.abs(a - b) > 1e-3).mean() < 0.01, k  # thresholded masks: <1 % boundary pixels
+    m = g["paste_mask"]
+    assert 0.01 < m.mean() < 0.99  # the fixture exercises both pasted and kept pixels
+    sub = lambda t: t[..., ::4, ::4].cpu().numpy()
+    assert np.abs(sub(out["paste"]["paste"]) - g["paste_paste_sub4"]).mean() < 2e-3
+    assert np.abs(sub(out["image_prepaste"]) - g["paste_prepaste_sub4"]).mean() < 2e-3
+    assert np.abs(sub(out["image"]) - g["paste_image_sub4"]).mean() < 5e-3
 
 
 def test_density_grid(hip):
