@@ -24,21 +24,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_TH 8
 #define CONV_TW 16
-#define CONV_IC 8
 #define CONV_OT 64
 #define XS_ROW (CONV_TW + 2)
 #define XS_PLANE ((CONV_TH + 2) * XS_ROW)
+// input channels staged per K chunk: ConvTaps<MODE>::IC, chosen so that a chunk holds 64-72 k values (MFMA work per staging round)
 #define WS_ROW (CONV_OT + 1)
 
 template <int MODE> struct ConvTaps;
 // dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
-template <> struct ConvTaps<0> { static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
-template <> struct ConvTaps<1> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
+template <> struct ConvTaps<0> { static constexpr int IC = 8; static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
+template <> struct ConvTaps<1> { static constexpr int IC = 32; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
 // transposed conv, out (2y+py, 2x+px) = sum over (ky,kx) with ky == py, kx == px (mod 2) of w[ky][kx] * x[y - ky/2][x - kx/2]
-template <> struct ConvTaps<2> { static constexpr int N = 4; static constexpr int dy[4] = {0,0,-1,-1}; static constexpr int dx[4] = {0,-1,0,-1}; static constexpr int kidx[4] = {0,2,6,8}; static constexpr int py = 0, px = 0, ostride = 2; };
-template <> struct ConvTaps<3> { static constexpr int N = 2; static constexpr int dy[2] = {0,-1}; static constexpr int dx[2] = {0,0}; static constexpr int kidx[2] = {1,7}; static constexpr int py = 0, px = 1, ostride = 2; };
-template <> struct ConvTaps<4> { static constexpr int N = 2; static constexpr int dy[2] = {0,0}; static constexpr int dx[2] = {0,-1}; static constexpr int kidx[2] = {3,5}; static constexpr int py = 1, px = 0, ostride = 2; };
-template <> struct ConvTaps<5> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {4}; static constexpr int py = 1, px = 1, ostride = 2; };
+template <> struct ConvTaps<2> { static constexpr int IC = 16; static constexpr int N = 4; static constexpr int dy[4] = {0,0,-1,-1}; static constexpr int dx[4] = {0,-1,0,-1}; static constexpr int kidx[4] = {0,2,6,8}; static constexpr int py = 0, px = 0, ostride = 2; };
+template <> struct ConvTaps<3> { static constexpr int IC = 32; static constexpr int N = 2; static constexpr int dy[2] = {0,-1}; static constexpr int dx[2] = {0,0}; static constexpr int kidx[2] = {1,7}; static constexpr int py = 0, px = 1, ostride = 2; };
+template <> struct ConvTaps<4> { static constexpr int IC = 32; static constexpr int N = 2; static constexpr int dy[2] = {0,0}; static constexpr int dx[2] = {0,-1}; static constexpr int kidx[2] = {3,5}; static constexpr int py = 1, px = 0, ostride = 2; };
+template <> struct ConvTaps<5> { static constexpr int IC = 32; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {4}; static constexpr int py = 1, px = 1, ostride = 2; };
 
 struct ConvParams {
     const float* x;       // [N][I][H][W]
@@ -70,6 +70,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N;
+    constexpr int CONV_IC = T::IC;
     constexpr int KC = CONV_IC * NT;  // k values per chunk
     constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * CONV_OT + 255) / 256;  // staged values per thread
     __shared__ float xs[CONV_IC * XS_PLANE];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
     const int o0 = blockIdx.y * CONV_OT;
     const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;  // split-K slice of the input channels
-    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + CONV_IC - 1) / CONV_IC * CONV_IC;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;  // multiple of every mode's IC
     const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
     const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
     const float* sn = p.styles + (size_t)n * p.I;
@@ -274,6 +275,59 @@ __global__ void k_upfirdn2d(FirParams p) {
     p.y[idx] = acc;
 }
 
+// 4x4 FIR without resampling (the filter pass after the stride-2 transposed conv), LDS-tiled: a 256-thread block produces
+// a 32x32 output tile of one (n,c) plane from a 35x35 input tile; each thread computes a 2x2 output block from a 5x5 LDS
+// window.  Every input element is read from HBM/L2 once (the generic kernel above re-reads each 16 times through L1).
+// y[Y][X] = sum_{fy,fx} f[fy][fx] * x[Y + fy - pady0][X + fx - padx0]
+__global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
+    __shared__ float tile[35 * 36];
+    __shared__ float fs[16];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.OW + 31) / 32;
+    const int X0 = (blockIdx.x % tiles_x) * 32, Y0 = (blockIdx.x / tiles_x) * 32;
+    const long long nc = blockIdx.y;
+    const float* xc = p.x + nc * p.H * p.W;
+    if (tid < 16) fs[tid] = p.f[tid];
+    for (int idx = tid; idx < 35 * 35; idx += 256) {
+        int r = idx / 35, c = idx - r * 35;
+        int u = Y0 + r - p.pady0, v = X0 + c - p.padx0;
+        tile[r * 36 + c] = (u >= 0 && u < p.H && v >= 0 && v < p.W) ? xc[(size_t)u * p.W + v] : 0.0f;
+    }
+    __syncthreads();
+    const int lx = (tid & 15) * 2, ly = (tid >> 4) * 2;
+    float win[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) win[r][c] = tile[(ly + r) * 36 + lx + c];
+    float dco = 1.0f, bias = 0.0f;
+    const int ch = (int)(nc % p.C);
+    const long long n = nc / p.C;
+    if (p.epilogue) {
+        if (p.dcoef) dco = p.dcoef[nc];
+        if (p.bias) bias = p.bias[ch];
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int Y = Y0 + ly + dy, X = X0 + lx + dx;
+            if (Y >= p.OH || X >= p.OW) continue;
+            float acc = 0.0f;
+#pragma unroll
+            for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+                for (int fx = 0; fx < 4; ++fx) acc = __builtin_fmaf(fs[fy * 4 + fx], win[dy + fy][dx + fx], acc);
+            if (p.epilogue) {
+                acc = acc * dco;
+                if (p.noise) acc = acc + p.noise[(p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + X];
+                acc = acc + bias;
+                acc = act_apply(acc, p.act, p.alpha, p.gain, p.clamp);
+            }
+            p.y[(nc * p.OH + Y) * p.OW + X] = acc;
+        }
+}
+
 // x viewed as [outer][C][inner]
 __global__ void k_bias_act(const float* __restrict__ x, const float* __restrict__ b, long long total, int C, long long inner,
                            int act, float alpha, float gain, float clamp, float* __restrict__ y) {
@@ -300,7 +354,7 @@ static void launch_conv(ConvParams p, hipStream_t st) {
 static int choose_ksplit(int N, int I, int O, int GH, int GW) {
     long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + CONV_OT - 1) / CONV_OT) * N;
     int ks = 1;
-    while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 2 * CONV_IC) ks *= 2;
+    while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 64) ks *= 2;
     return ks;
 }
 
@@ -365,8 +419,8 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
     q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
     q.alpha = alpha; q.gain = gain; q.clamp = clamp;
-    long long total = q.NC * q.OH * q.OW;
-    hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
+    dim3 grid(((q.OW + 31) / 32) * ((q.OH + 31) / 32), (unsigned)q.NC);
+    hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
     return chk();
 }
 
