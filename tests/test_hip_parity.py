@@ -174,3 +174,52 @@ def test_stratified_op(hip, S):
 def test_cpu_tensors_raise(hip):
     with pytest.raises(RuntimeError):
         hip.ops.planes_to_nhwc(torch.zeros(1, 3, 32, 8, 8))
+
+
+def test_error_behaviour(hip):
+    """Argument / range errors surface as RuntimeError (the reference's TORCH_CHECK convention, bias_act.cpp:39-55)."""
+    ro = dict(T.RENDERING_KWARGS)
+    planes = torch.zeros(1, 3, 8, 8, 32, device="cuda")
+    o = torch.zeros(1, 64, 3, device="cuda")
+    d = torch.ones(1, 64, 3, device="cuda")
+    mlp = (torch.zeros(64, 32, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(33, 64, device="cuda"), torch.zeros(33, device="cuda"))
+    opts = hip.ops.make_opts(ro)
+    good_j, good_u = torch.rand(1, 64, 48, device="cuda"), torch.rand(64, 48, device="cuda")
+    with pytest.raises(RuntimeError):  # wrong jitter size
+        hip.ops.render(planes, o, d, torch.rand(1, 64, 47, device="cuda"), good_u, mlp, opts)
+    with pytest.raises(RuntimeError):  # Sc below the supported range
+        hip.ops.render(planes, o, d, torch.rand(1, 64, 3, device="cuda"), good_u, mlp, hip.ops.make_opts(dict(ro, depth_resolution=3)))
+    with pytest.raises(RuntimeError):  # Sf above the supported range
+        hip.ops.render(planes, o, d, good_j, torch.rand(64, 500, device="cuda"), mlp, hip.ops.make_opts(dict(ro, depth_resolution_importance=500)))
+    with pytest.raises(RuntimeError):  # decoder of the wrong shape
+        hip.ops.render(planes, o, d, good_j, good_u, (torch.zeros(64, 16, device="cuda"),) + mlp[1:], opts)
+    with pytest.raises(RuntimeError):  # fp64 input
+        hip.ops.planes_to_nhwc(torch.zeros(1, 3, 32, 8, 8, device="cuda", dtype=torch.float64))
+    with pytest.raises(NotImplementedError):
+        hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto"))
+    # a valid call on the same inputs still works afterwards (no sticky error state), incl. the single-pass branch
+    out = hip.ops.render(planes, o, d, good_j, good_u, mlp, opts)
+    out0 = hip.ops.render(planes, o, d, good_j, None, mlp, hip.ops.make_opts(dict(ro, depth_resolution_importance=0)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out0[0]).all()
+    # large sample counts take the generic (LDS-sorted) path: 160 + 160
+    big = hip.ops.make_opts(dict(ro, depth_resolution=160, depth_resolution_importance=160))
+    outb = hip.ops.render(planes, o, d, torch.rand(1, 64, 160, device="cuda"), torch.rand(64, 160, device="cuda"), mlp, big)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outb[0]).all()
+
+
+def test_generic_sort_path_bit_exact(hip, oracle):
+    """Sf > 128 uses the LDS insertion-sort path (k_render<0>): check it against the oracle too."""
+    g = T.load_golden("render_32x32_16p16.npz")
+    inp = T.golden_render_inputs(g)
+    Sc, Sf = 20, 136
+    ro = dict(inp["ro"], depth_resolution=Sc, depth_resolution_importance=Sf)
+    R = 96
+    jit, u = T.make_random_draws(5, 2, R, Sc, Sf)
+    o_, d_ = inp["rays_o"][:, :R].copy(), inp["rays_d"][:, :R].copy()
+    ref = oracle.render(inp["planes"], o_, d_, jit, u, oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(ro, **inp["kw"]))
+    out = hip.ops.render(hip.ops.planes_to_nhwc(dev(inp["planes"])), dev(o_), dev(d_), dev(jit), dev(u),
+                         hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"]), hip.ops.make_opts(ro, **inp["kw"]))
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.cpu().numpy(), b)
