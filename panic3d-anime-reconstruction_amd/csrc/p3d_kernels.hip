@@ -64,7 +64,7 @@ struct DecodeParams {
 };
 
 template <bool WANT_RGB>
-__global__ __launch_bounds__(P3D_WG) void k_decode_points(DecodeParams p) {
+__global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
     __shared__ __attribute__((aligned(16))) float lds[P3D_LDS_MLP_FLOATS];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
     __syncthreads();
