@@ -24,11 +24,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CONV_TH 8
 #define CONV_TW 16
-#define CONV_OT 64
 #define XS_ROW (CONV_TW + 2)
 #define XS_PLANE ((CONV_TH + 2) * XS_ROW)
 // input channels staged per K chunk: ConvTaps<MODE>::IC, chosen so that a chunk holds 64-72 k values (MFMA work per staging round)
-#define WS_ROW (CONV_OT + 1)
 
 template <int MODE> struct ConvTaps;
 // dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
@@ -66,20 +64,24 @@ DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
     return v;
 }
 
-template <int MODE>
+// OT: output channels per workgroup (64: one 32-channel A tile per wave, 128: two).  Per k pair a wave issues OT/64 A reads,
+// 2 B reads and 2*OT/64 MFMAs.
+template <int MODE, int OT>
 __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N;
     constexpr int CONV_IC = T::IC;
     constexpr int KC = CONV_IC * NT;  // k values per chunk
-    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * CONV_OT + 255) / 256;  // staged values per thread
+    constexpr int NA = OT / 64;       // A tiles per wave
+    constexpr int WROW = OT + 1;
+    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * OT + 255) / 256;  // staged values per thread
     __shared__ float xs[CONV_IC * XS_PLANE];
-    __shared__ float ws[KC * WS_ROW];
+    __shared__ float ws[KC * WROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
     const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
     const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
-    const int o0 = blockIdx.y * CONV_OT;
+    const int o0 = blockIdx.y * OT;
     const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;  // split-K slice of the input channels
     const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;  // multiple of every mode's IC
     const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
@@ -87,12 +89,18 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     const float* sn = p.styles + (size_t)n * p.I;
     const int kk9 = p.ks * p.ks;
 
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
     // this lane's pixel inside the tile for the two N tiles: rows 4wp + 2t + (j>>4), col j & 15
     const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
     const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;          // N tile 0 (halo origin at +1,+1)
     const int pix1 = pix0 + 2 * XS_ROW;                        // N tile 1 (two rows below)
-    const int wcol = wc * 32 + j;
+    const int wcol = wc * (OT / 2) + j;
 
     float xr[XN], wr[WN];
     // global -> registers: modulated input patch s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c] (zero outside) and the weight slice
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
             int ic = k / NT, t = k - ic * NT;
             int ci = ic0 + ic, oo = o0 + o;
             float v = 0.0f;
-            if (idx < KC * CONV_OT && ci < ic_end && oo < p.O)
+            if (idx < KC * OT && ci < ic_end && oo < p.O)
                 v = p.w[((size_t)oo * p.I + ci) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])];
             wr[u] = v;
         }
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
         for (int u = 0; u < WN; ++u) {
             int idx = tid_ + u * 256;
             int o = idx / KC, k = idx - o * KC;
-            if (idx < KC * CONV_OT) ws[k * WS_ROW + o] = wr[u];
+            if (idx < KC * OT) ws[k * WROW + o] = wr[u];
         }
     };
     gload(ic_beg);
@@ -151,12 +159,15 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
             const int xo1 = (k1 / NT) * XS_PLANE + T::dy[k1 % NT] * XS_ROW + T::dx[k1 % NT];
             const int xo = half ? xo1 : xo0;
             const int kk = half ? k1 : k0;
-            float a = ws[kk * WS_ROW + wcol];
             float b0 = xs[xo + pix0];
             float b1 = xs[xo + pix1];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-            // keep the LDS operand reads at most 4 steps ahead of their MFMAs (hoisting all 3*KC/2 reads costs ~100 VGPRs)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                float av = ws[kk * WROW + wcol + 32 * a];
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
+            }
+            // keep the LDS operand reads at most 4 steps ahead of their MFMAs (hoisting all reads costs ~100 VGPRs)
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -171,18 +182,20 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
         if (gy >= p.GH || gx >= p.GW) continue;
         const int oy = gy * T::ostride + T::py, ox = gx * T::ostride + T::px;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (ch >= p.O) continue;
-            float v = t ? acc1[r] : acc0[r];
-            if (p.epilogue) {
-                if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
-                if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)oy * p.OW + ox];
-                if (p.bias) v = v + p.bias[ch];
-                v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = o0 + wc * (OT / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch >= p.O) continue;
+                float v = acc[a][t][r];
+                if (p.epilogue) {
+                    if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
+                    if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)oy * p.OW + ox];
+                    if (p.bias) v = v + p.bias[ch];
+                    v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+                }
+                yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
             }
-            yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
-        }
     }
 }
 
@@ -343,16 +356,22 @@ static inline int chk() {
     return e == hipSuccess ? P3D_OK : (int)e;
 }
 
+// output-channel tile.  The 128-channel variant (two A tiles per wave: half the LDS reads and staging per MFMA) measured
+// SLOWER on MI355X at every generator shape (e.g. 256->256 @256^2: 53 vs 66 TF) — fewer, fatter workgroups — so 64 is used.
+static int conv_ot(int O) { (void)O; return 64; }
+
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
-    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + CONV_OT - 1) / CONV_OT,
-              p.N * p.ksplit);
-    hipLaunchKernelGGL(k_modconv<MODE>, grid, dim3(256), 0, st, p);
+    const int ot = conv_ot(p.O);
+    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + ot - 1) / ot, p.N * p.ksplit);
+    if (ot == 128) hipLaunchKernelGGL((k_modconv<MODE, 128>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_modconv<MODE, 64>), grid, dim3(256), 0, st, p);
 }
 
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
 static int choose_ksplit(int N, int I, int O, int GH, int GW) {
-    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + CONV_OT - 1) / CONV_OT) * N;
+    const int ot = conv_ot(O);
+    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + ot - 1) / ot) * N;
     int ks = 1;
     while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 64) ks *= 2;
     return ks;
