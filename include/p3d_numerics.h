@@ -58,10 +58,19 @@
 #define P3D_L1P_C7 (-0x1.e4c732p-6f) /* -0.0295885075 */
 #define P3D_L1P_C8 0x1.584a66p-8f    /* 0.00525345793 */
 
-/* ---- p3d_softplus(x)  (torch Softplus beta=1 threshold=20: triplane.py:524, ray_marcher.py:33)
- *   x > 20 -> x ;  else  z = p3d_exp(-|x|);  result = max(x, 0) + p3d_log1p01(z)
+/* ---- p3d_exp_nonpos(x)  (arguments known to be <= 0: softplus / sigmoid / cull paths)
+ *   p3d_exp_nonpos(x) = the p3d_exp recipe applied to max(x, P3D_EXP_LO)   (fmaxf; the ldexp underflows to exactly 0 there,
+ *   so this equals p3d_exp(x) for every x <= 0 including -inf)
+ * ---- p3d_softplus(x)  (torch Softplus beta=1 threshold=20: triplane.py:524, ray_marcher.py:33)
+ *   z = p3d_exp_nonpos(-|x|);  result = max(x, 0) + p3d_log1p01(z)
+ *   (torch returns x itself above the threshold 20; the expression above already equals x there in binary32, because
+ *    log1p(exp(-20)) = 2.1e-9 is far below half an ulp of 20 — so no select is needed and none is specified)
+ * ---- p3d_rcp12(d), 1 <= d <= 2 : reciprocal by a fixed Newton sequence (cheaper than IEEE division, error <= ~1 ulp)
+ *   r = fma(d, -P3D_RCP_A, P3D_RCP_B);   then three times:  e = fma(-d, r, 1);  r = fma(r, e, r)
  * ---- p3d_sigmoid(x)   (triplane.py:540)
- *   z = p3d_exp(-|x|);  d = 1 + z;  result = (x >= 0) ? 1/d : z/d          (IEEE division) */
+ *   z = p3d_exp_nonpos(-|x|);  r = p3d_rcp12(1 + z);  result = (x >= 0) ? r : z * r */
+#define P3D_RCP_A 0x1.e1e1e2p-2f /* 8/17  */
+#define P3D_RCP_B 0x1.696968p+0f /* 24/17 */
 #define P3D_SOFTPLUS_THRESHOLD 20.0f
 
 /* ---- triplane sample (renderer.py:68-81; grid_sample bilinear / zeros / align_corners=False) ----

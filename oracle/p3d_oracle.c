@@ -65,18 +65,31 @@ static inline float or_log1p01(float z) {
     return q * z;
 }
 
-/* torch.nn.Softplus(beta=1, threshold=20): triplane.py:524; F.softplus: ray_marcher.py:33, renderer.py:151 */
+/* arguments known to be <= 0 */
+static inline float or_exp_nonpos(float x) { return or_exp(fmaxf(x, P3D_EXP_LO)); }
+
+/* torch.nn.Softplus(beta=1, threshold=20): triplane.py:524; F.softplus: ray_marcher.py:33, renderer.py:151.
+ * Above the threshold the expression equals x in binary32 (see include/p3d_numerics.h), so there is no branch. */
 static inline float or_softplus(float x) {
-    if (x > P3D_SOFTPLUS_THRESHOLD) return x;
-    float z = or_exp(-fabsf(x));
+    float z = or_exp_nonpos(-fabsf(x));
     return fmaxf(x, 0.0f) + or_log1p01(z);
+}
+
+/* reciprocal of d in [1,2] by the contract's fixed Newton sequence */
+static inline float or_rcp12(float d) {
+    float r = fmaf(d, -P3D_RCP_A, P3D_RCP_B);
+    for (int i = 0; i < 3; ++i) {
+        float e = fmaf(-d, r, 1.0f);
+        r = fmaf(r, e, r);
+    }
+    return r;
 }
 
 /* torch.sigmoid: triplane.py:540 */
 static inline float or_sigmoid(float x) {
-    float z = or_exp(-fabsf(x));
-    float d = 1.0f + z;
-    return (x >= 0.0f) ? 1.0f / d : z / d;
+    float z = or_exp_nonpos(-fabsf(x));
+    float r = or_rcp12(1.0f + z);
+    return (x >= 0.0f) ? r : z * r;
 }
 
 /* ------------------------------------------------------------------ triplane sample + decoder */
@@ -167,7 +180,7 @@ static void or_decode_point(const float* planes_n, int H, int W, float px, float
         if (fabsf(px) > crop_limit || fabsf(pz) > crop_limit) sigma = P3D_SIGMA_MASKED;
     }
     if (flags & (OR_FLAG_CULL | OR_FLAG_BINARIZE)) { /* cull_clouds_mask: renderer.py:150-153 */
-        float a = 1.0f - or_exp(-or_softplus(sigma - 1.0f));
+        float a = 1.0f - or_exp_nonpos(-or_softplus(sigma - 1.0f));
         if (flags & OR_FLAG_BINARIZE)
             sigma = (a < cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID; /* renderer.py:190-193 */
         else if (a < cull_thresh)

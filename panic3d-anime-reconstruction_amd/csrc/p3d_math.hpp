@@ -39,12 +39,9 @@ P3D_DEV float p3d_exp(float x) {
     return (x > P3D_EXP_HI) ? __builtin_inff() : y;
 }
 
-// x <= 0 (or NaN, which propagates): softplus / sigmoid / cull paths.  For x < P3D_EXP_LO the ldexp underflows to 0, which
-// is the contract's value, so no select is needed; x = -inf is the one input that needs it (inf - inf in the reduction).
-P3D_DEV float p3d_exp_nonpos(float x) {
-    float y = p3d_exp_core(x);
-    return (x < P3D_EXP_LO) ? 0.0f : y;
-}
+// x <= 0: softplus / sigmoid / cull paths.  The clamp makes -inf safe (inf - inf in the reduction); below P3D_EXP_LO the
+// ldexp underflows to exactly 0, so the value equals p3d_exp(x) on the whole domain.
+P3D_DEV float p3d_exp_nonpos(float x) { return p3d_exp_core(__builtin_fmaxf(x, P3D_EXP_LO)); }
 
 P3D_DEV float p3d_log1p01(float z) {
     float q = P3D_L1P_C8;
@@ -59,14 +56,24 @@ P3D_DEV float p3d_log1p01(float z) {
     return q * z;
 }
 
-// torch Softplus(beta=1, threshold=20)
+// torch Softplus(beta=1, threshold=20).  No threshold select: for x > 20 the sum already rounds to x (p3d_numerics.h).
 P3D_DEV float p3d_softplus(float x) {
 #ifdef P3D_ABL_NOTRANS  // timing experiment: no transcendental polynomials
     return __builtin_fmaxf(x, 0.0f);
 #endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
-    float y = __builtin_fmaxf(x, 0.0f) + p3d_log1p01(z);
-    return (x > P3D_SOFTPLUS_THRESHOLD) ? x : y;
+    return __builtin_fmaxf(x, 0.0f) + p3d_log1p01(z);
+}
+
+// 1/d for d in [1,2]: linear seed + three Newton steps, all fma (bit-reproducible; an IEEE division costs ~15 VALU slots)
+P3D_DEV float p3d_rcp12(float d) {
+    float r = p3d_fma(d, -P3D_RCP_A, P3D_RCP_B);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float e = p3d_fma(-d, r, 1.0f);
+        r = p3d_fma(r, e, r);
+    }
+    return r;
 }
 
 P3D_DEV float p3d_sigmoid(float x) {
@@ -74,9 +81,8 @@ P3D_DEV float p3d_sigmoid(float x) {
     return x * 0.25f + 0.5f;
 #endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
-    float d = 1.0f + z;
-    float num = (x >= 0.0f) ? 1.0f : z;
-    return num / d;
+    float r = p3d_rcp12(1.0f + z);
+    return (x >= 0.0f) ? r : z * r;
 }
 
 // order-preserving float <-> uint32 map (for atomic min/max over arbitrary-sign floats)
