@@ -56,10 +56,16 @@ struct DecodeParams {
     const float *w0, *b0, *w1, *b1;
     float* out_sigma;  // [N][M]
     float* out_rgb;    // [N][M][32] or null
+    float* out_points; // grid mode only: [M][3] generated points, or null
     long long M;
     long long tiles_per_img;  // ceil(M/32)
     long long ntiles;
     int H, W;
+    // coords == nullptr: points of the reference's regular grid (create_samples, _util/eg3d_metrics3d.py:70-92), flat index
+    // grid_lo + m: column 2 = idx % n, column 1 = fmod(float(idx) / n, n), column 0 = fmod(float(idx) / n / n, n), each * vsize + goff
+    int grid_n;
+    long long grid_lo;
+    float vsize, goff0, goff1, goff2;
     P3dDecodeCfg cfg;
 };
 
@@ -82,8 +88,23 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
         unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
         const float* base = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
         auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
-        const float* c = p.coords + ((size_t)n * p.M + mc) * 3;
-        float px = c[0], py = c[1], pz = c[2];
+        float px, py, pz;
+        if (p.coords) {
+            const float* c = p.coords + ((size_t)n * p.M + mc) * 3;
+            px = c[0]; py = c[1]; pz = c[2];
+        } else {  // the same float arithmetic as the reference's create_samples (float division: fractional carries are kept)
+            const long long idx = p.grid_lo + mc;
+            const float fn = (float)p.grid_n, f = (float)idx;
+            const float s2 = (float)(idx % p.grid_n);
+            const float q1 = f / fn;
+            const float s1 = __builtin_fmodf(q1, fn);
+            const float s0 = __builtin_fmodf(q1 / fn, fn);
+            px = s0 * p.vsize + p.goff0; py = s1 * p.vsize + p.goff1; pz = s2 * p.vsize + p.goff2;
+            if (p.out_points && active && h == 0) {
+                float* q = p.out_points + (size_t)m * 3;
+                q[0] = px; q[1] = py; q[2] = pz;
+            }
+        }
         float sigma;
         f32x16 rgb;
         p3d_decode_wave<WANT_RGB>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
@@ -689,12 +710,31 @@ int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const floa
     p.tiles_per_img = (M + 31) / 32;
     p.ntiles = p.tiles_per_img * N;
     p.cfg = make_cfg(opts);
+    p.grid_n = 0; p.grid_lo = 0; p.vsize = p.goff0 = p.goff1 = p.goff2 = 0.0f; p.out_points = nullptr;
     long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     if (out_rgb)
         hipLaunchKernelGGL(k_decode_points<true>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+    return p3d_check_launch();
+}
+
+int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t lo, int64_t hi, float voxel_size, float off0,
+                         float off1, float off2, const float* w0, const float* b0, const float* w1, const float* b1,
+                         const p3d_opts* opts, float* out_sigma, float* out_points, void* stream) {
+    if (!planes || !w0 || !b0 || !w1 || !b1 || !opts || !out_sigma || grid_n <= 1 || lo < 0 || hi <= lo) return P3D_E_ARG;
+    if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL || hi > (int64_t)grid_n * grid_n * grid_n) return P3D_E_RANGE;
+    DecodeParams p;
+    p.planes = planes; p.coords = nullptr; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
+    p.out_sigma = out_sigma; p.out_rgb = nullptr; p.out_points = out_points; p.M = hi - lo; p.H = H; p.W = W;
+    p.tiles_per_img = (p.M + 31) / 32;
+    p.ntiles = p.tiles_per_img;
+    p.cfg = make_cfg(opts);
+    p.grid_n = grid_n; p.grid_lo = lo; p.vsize = voxel_size; p.goff0 = off0; p.goff1 = off1; p.goff2 = off2;
+    long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
     return p3d_check_launch();
 }
 

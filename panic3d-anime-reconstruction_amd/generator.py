@@ -101,6 +101,8 @@ class TriPlaneGenerator(torch.nn.Module):
     def mapping_zplus(self, zs, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         """One z per w slot (triplane.py:123-143): map every z, keep slot i of the i-th z's broadcast ws."""
         bs, n, dim = zs.shape
+        if zs.stride(1) == 0:  # f() expands ONE z to all w slots (triplane.py:356): every slot maps the same z -> map it once
+            return self.mapping(zs[:, 0], c, cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
         c_new = c[:, None, :].repeat(1, n, 1).reshape(bs * n, -1)
         cond_new = cond
         if "resnet_feats" in cond:

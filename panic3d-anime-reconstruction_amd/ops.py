@@ -122,6 +122,24 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     return sigma, rgb
 
 
+def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, return_points=False):
+    """Density-only decode of flat indices [lo, hi) of the reference's grid_n^3 sample grid (create_samples), the points
+    generated inside the kernel.  planes_nhwc [1,3,H,W,32] -> sigma [1, hi-lo, 1]."""
+    planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
+    if planes_nhwc.shape[0] != 1:
+        raise RuntimeError("grid_density renders one subject at a time")
+    _, _, H, W, _ = planes_nhwc.shape
+    w0, b0, w1, b1 = _chk_mlp(mlp)
+    sigma = torch.empty((1, hi - lo, 1), dtype=torch.float32, device=planes_nhwc.device)
+    pts = torch.empty((1, hi - lo, 3), dtype=torch.float32, device=planes_nhwc.device) if return_points else None
+    with torch.cuda.device(planes_nhwc.device):
+        rc = _lib.lib().p3d_grid_density_f32(_p(planes_nhwc), H, W, int(grid_n), int(lo), int(hi), np.float32(voxel_size),
+                                              np.float32(offsets[0]), np.float32(offsets[1]), np.float32(offsets[2]), _p(w0),
+                                              _p(b0), _p(w1), _p(b1), C.byref(opts), _p(sigma), _p(pts), _stream())
+    _lib.check(rc, "p3d_grid_density_f32")
+    return (sigma, pts) if return_points else sigma
+
+
 DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "inds", "depths_sorted", "sigma_sorted",
              "depth_unclamped", "tminmax")
 

@@ -35,7 +35,7 @@ def sigma2density(sigma):  # eg3d_metrics3d.py:65-69
     return 1 - torch.exp(-torch.nn.functional.softplus(sigma - 1))
 
 
-def density_grid(G, ws, cond, resolution=256, max_batch=1 << 24, triplane_crop=None, cull_clouds=None, lo=0, hi=None,
+def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None, cull_clouds=None, lo=0, hi=None,
                  planes=None, **synthesis_kwargs):
     """sigma / density for flat grid indices [lo, hi) of the resolution^3 grid, on the device: dict(sigmas, densities)
     of shape [1, hi-lo, 1].  `planes` (NCHW [1,3,32,H,W]) skips the backbone."""
@@ -47,22 +47,18 @@ def density_grid(G, ws, cond, resolution=256, max_batch=1 << 24, triplane_crop=N
     opts = G.renderer._opts(rk, G.decoder)
     mlp = decoder_params(G.decoder)
     nhwc = G.renderer._nhwc(planes)
-    sig = torch.empty((1, hi - lo, 1), dtype=torch.float32, device=dev)
-    for a in range(lo, hi, max_batch):
-        b = min(a + max_batch, hi)
-        pts, _, _ = create_samples(resolution, cube_length=rk["box_warp"], device=dev, lo=a, hi=b)
-        sig[:, a - lo:b - lo], _ = ops.triplane_decode(nhwc, pts.contiguous(), mlp, opts, density_only=True)
+    # the grid points are generated inside the decode kernel with create_samples' float arithmetic (no points tensor)
+    origin = np.array([0, 0, 0]) - rk["box_warp"] / 2
+    vs = rk["box_warp"] / (resolution - 1)
+    res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts,
+                           return_points=triplane_crop is not None)
+    sig, pts = res if triplane_crop is not None else (res, None)
     dens = sigma2density(sig)
-    if triplane_crop is not None or cull_clouds is not None:
-        if triplane_crop is not None:  # triplane_crop_mask (renderer.py:138-149): |x| or |z| beyond box/2 - crop
-            lim = rk["box_warp"] / 2 - triplane_crop
-            for a in range(lo, hi, max_batch):
-                b = min(a + max_batch, hi)
-                pts, _, _ = create_samples(resolution, cube_length=rk["box_warp"], device=dev, lo=a, hi=b)
-                m = (pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)
-                dens[:, a - lo:b - lo][m] = -1e3
-        if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
-            dens[sigma2density(dens) < cull_clouds] = -1e3
+    if triplane_crop is not None:  # triplane_crop_mask (renderer.py:138-149) on the sample points: |x| or |z| beyond box/2 - crop
+        lim = rk["box_warp"] / 2 - triplane_crop
+        dens[(pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)] = -1e3
+    if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
+        dens[sigma2density(dens) < cull_clouds] = -1e3
     return {"sigmas": sig, "densities": dens}
 
 

@@ -215,8 +215,8 @@ def test_density_grid(hip):
     ws = dev(g["ws"])[:1]
     N = 24
     with torch.no_grad():
-        out = hip.volume.density_grid(G, ws, {}, resolution=N, max_batch=5000, triplane_crop=0.1, cull_clouds=0.5)
-        pts, _, _ = hip.volume.create_samples(N, cube_length=0.7, device="cuda")
+        out = hip.volume.density_grid(G, ws, {}, resolution=N, triplane_crop=0.1, cull_clouds=0.5)
+        pts = hip.volume.create_samples(N, cube_length=0.7)[0].cuda()  # the reference builds the grid on the CPU (eg3d_metrics3d.py:111)
         ref = G.sample_mixed(pts.contiguous(), None, ws, {}, noise_mode="const")["sigma"]
         assert torch.equal(out["sigmas"], ref)
         dens = hip.volume.sigma2density(ref)

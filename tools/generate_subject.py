@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The per-subject flow of _scripts/eval/generate.py:80-151 on the MI355X path, at the released model's sizes, with
+random-init weights and a synthetic illustration (the checkpoint and the AnimeRecon data are not in this environment):
+density grid 256^3 (get_eg3d_volume), then 4 orthographic + 12 perspective views through G.f with the front-view paste.
+Prints a timing breakdown (one JSON line)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import panic3d_amd as P
+from panic3d_amd.generator import TriPlaneGenerator
+from panic3d_amd import volume
+
+dev = torch.device("cuda")
+RK = {"image_resolution": 512, "disparity_space_sampling": False, "clamp_mode": "softplus",
+      "superresolution_module": "training.superresolution.SuperresolutionHybrid8XDC", "c_gen_conditioning_zero": False,
+      "gpc_reg_prob": 0.5, "c_scale": 1.0, "superresolution_noise_mode": "none", "density_reg": 0.25, "density_reg_p_dist": 0.004,
+      "reg_type": "l1", "decoder_lr_mul": 1.0, "sr_antialias": True, "white_back": True, "triplane_depth": 1, "use_triplane": 1,
+      "tanh_rgb_output": False, "box_warp": 0.7, "ray_start": 0.5, "ray_end": 1.5, "depth_resolution": 96,
+      "depth_resolution_importance": 96, "avg_camera_radius": 1.0, "avg_camera_pivot": [0, 0, 0]}  # 96/96: eg3dc_v0.py:55-56
+torch.manual_seed(0)
+G = TriPlaneGenerator(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, sr_num_fp16_res=0,
+                      mapping_kwargs={"num_layers": 2}, rendering_kwargs=RK,
+                      sr_kwargs={"channel_base": 32768, "channel_max": 512, "fused_modconv_default": "inference_only"},
+                      cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.reschonk_add_64", triplane_width=32, sr_channels_hidden=256,
+                      backbone_resolution=256, channel_base=32768, channel_max=512, fused_modconv_default="inference_only",
+                      num_fp16_res=0, conv_clamp=None).to(dev).eval()
+with torch.no_grad():
+    for n, p in G.backbone.synthesis.named_parameters():
+        if n.endswith("torgb.weight"):
+            p.mul_(30.0)  # random-init ToRGB gives planes ~0: scale to O(1) features so that there is a surface to render
+    G.decoder.net[2].weight[0] *= 20.0
+G.set_force_sigmoid(True)
+G.neural_rendering_resolution = 128
+cond = {"image_ortho_front": torch.rand(1, 3, 512, 512, device=dev), "resnet_chonk": torch.randn(1, 64, 8, 8, device=dev)}
+opts = {"triplane_crop": 0.1, "cull_clouds": 0.5,
+        "paste_params": {"mode": "default", "thresh_weight": 0.95, "thresh_edges": 0.02, "thresh_occ": 0.05, "offset_occ": 0.01,
+                         "thresh_dxyz": 0.000005}}
+cam60 = torch.tensor(np.stack(np.meshgrid(np.linspace(60, -20, 5), np.linspace(-180, 150, 12))).T.reshape(60, -1)).float()
+spin12 = [*range(42, 48), *range(36, 42)]
+views = [(0, 0, -1), (0, 90, -1), (0, -90, -1), (0, 180, -1)] + [(float(cam60[v][0]), float(cam60[v][1]), 30) for v in spin12]
+
+def sync():
+    torch.cuda.synchronize(); return time.perf_counter()
+
+with torch.no_grad():
+    x0 = {"elevations": torch.zeros(1, device=dev), "azimuths": torch.zeros(1, device=dev), "cond": cond, "seeds": [0], "noise_mode": "const",
+          "triplane_crop": 0.1, "cull_clouds": 0.5}
+    G.f(dict(x0))  # warm-up
+    t0 = sync()
+    out = G.f(x0)
+    t1 = sync()
+    vol = volume.density_grid(G, x0["ws"], cond, resolution=256, triplane_crop=0.1, cull_clouds=0.5)
+    dens = volume.to_volume(vol["densities"], 256)
+    t2 = sync()
+    imgs = []
+    for elev, azim, fov in views:
+        xin = {"elevations": elev * torch.ones(1, device=dev), "azimuths": azim * torch.ones(1, device=dev),
+               "fovs": fov * torch.ones(1, device=dev), "cond": cond, "seeds": [0], **opts}
+        o = G.f(xin)
+        imgs.append(o["image"])
+    t3 = sync()
+assert all(i.shape == (1, 3, 512, 512) and torch.isfinite(i).all() for i in imgs) and dens.shape == (1, 1, 256, 256, 256)
+print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "views": len(views),
+                  "views_with_paste_ms": (t3 - t2) * 1e3, "ms_per_view": (t3 - t2) * 1e3 / len(views),
+                  "subject_total_ms": (t3 - t0) * 1e3, "mean_alpha_last_view": float(o["image_weights"].mean()),
+                  "paste_mask_mean_last_view": float(o["paste"]["mask"].mean())}))
