@@ -32,13 +32,23 @@ def sample_orthofront(front_rgb, view_xyz, bw):
 
 
 def front_occlusion(G, x, out, offset=0.01):
-    """Accumulated opacity between every rendered surface point and the front plane (triplane.py:565-578)."""
+    """Accumulated opacity between every rendered surface point and the front plane (triplane.py:565-578): rays from the
+    surface points along +z.  The reference calls G.f again for this (backbone + renderer + super-resolution, and with its
+    default noise_mode='random' on different planes); only `image_weights` is used, so this renders the SAME planes
+    (`out['triplane']`) once more through the fused renderer and skips the rest."""
     ro = out["image_xyz"] * torch.tensor([-1, 1, -1], device=out["image_xyz"].device)[None, :, None, None]
     ro[:, 2, :, :] -= G.rendering_kwargs["ray_start"] - offset
     rd = torch.zeros_like(out["image_xyz"])
     rd[:, 2, :, :] = 1
-    xin = {**x, "paste_params": None, "force_rays": {"ray_origins": ro, "ray_directions": rd}}
-    return G.f(xin)["image_weights"]
+    N, _, H, W = ro.shape
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(N, H * W, 3).contiguous()
+    draws = G._inject_draws or (None, None)
+    if isinstance(draws, list):
+        draws = draws.pop(0)
+    _, _, wsum, _ = G.renderer(out["triplane"], G.decoder, flat(ro), flat(rd), G.rendering_kwargs,
+                               triplane_crop=x.get("triplane_crop"), cull_clouds=x.get("cull_clouds"),
+                               binarize_clouds=x.get("binarize_clouds"), jitter=draws[0], u=draws[1])
+    return wsum.permute(0, 2, 1).reshape(N, 1, H, W)
 
 
 def xyz_discrepancy(xyz, rays):

@@ -56,9 +56,9 @@ def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None
     dens = sigma2density(sig)
     if triplane_crop is not None:  # triplane_crop_mask (renderer.py:138-149) on the sample points: |x| or |z| beyond box/2 - crop
         lim = rk["box_warp"] / 2 - triplane_crop
-        dens[(pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)] = -1e3
+        dens.masked_fill_(((pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)).unsqueeze(-1), -1e3)
     if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
-        dens[sigma2density(dens) < cull_clouds] = -1e3
+        dens.masked_fill_(sigma2density(dens) < cull_clouds, -1e3)
     return {"sigmas": sig, "densities": dens}
 
 
