@@ -781,6 +781,8 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
     p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0);
     int nwaves = P3D_RENDER_WAVES;
+    // small ray counts (e.g. the pipeline's 128^2 rays = 512 tiles): shrink the workgroup so that every CU gets work
+    while (nwaves > 1 && p.ntiles / nwaves < 2 * 256) nwaves >>= 1;
     size_t lds_bytes;
     for (;; nwaves >>= 1) {
         lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
