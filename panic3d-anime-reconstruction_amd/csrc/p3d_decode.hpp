@@ -73,10 +73,12 @@ struct P3dPlaneGeom {
 
 // One plane, this lane's 16 channels: F.grid_sample(bilinear, zeros, align_corners=False) — renderer.py:80.
 P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t chan_off, float gx, float gy,
-                             uint32_t off[4], float wgt[4]) {
+                             uint32_t off[4], float wgt[4], bool live = true) {
     float ix = (gx + 1.0f) * g.halfW - 0.5f;
     float iy = (gy + 1.0f) * g.halfH - 0.5f;
-    bool inr = (ix > -1.0f) && (ix < g.fW) && (iy > -1.0f) && (iy < g.fH);
+    // !live: this lane's result is known not to matter (cropped / dead ray): give it out-of-bounds offsets so that it issues
+    // no L1 lookups (the gather rate is the kernel's binding limit) — it then decodes an all-zero feature vector
+    bool inr = live && (ix > -1.0f) && (ix < g.fW) && (iy > -1.0f) && (iy < g.fH);
     float fx0 = __builtin_floorf(ix), fy0 = __builtin_floorf(iy);
     float wx1 = ix - fx0, wy1 = iy - fy0;
     float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
@@ -167,9 +169,11 @@ struct P3dDecodeCfg {
 // Decode one sample per lane pair.  All 64 lanes must be active.  lds = workgroup MLP image (p3d_load_mlp_to_lds).
 // Returns sigma (after masks) and, if WANT_RGB, this lane's 16 colour channels: register r holds channel
 // rowof(r) + 4h  (channels {0-3,8-11,16-19,24-27} for h = 0, {4-7,12-15,20-23,28-31} for h = 1).
+// live = false on a lane: its gathers are suppressed (see p3d_tap_offsets) and its outputs are garbage except that the
+// position-only crop mask still applies.
 template <bool WANT_RGB, typename RSRC>
 P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
-                             float py, float pz, float& sigma_out, f32x16& rgb) {
+                             float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
     const int lane = __lane_id();
     const int h = lane >> 5;
     const uint32_t chan_off = (uint32_t)h * 64u;
@@ -180,9 +184,9 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
     float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
     uint32_t of0[4], of1[4], of2[4];
     float wg0[4], wg1[4], wg2[4];
-    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of0, wg0);
-    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of1, wg1);
-    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of2, wg2);
+    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of0, wg0, live);
+    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of1, wg1, live);
+    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of2, wg2, live);
     f32x16 a00 = p3d_load16(rs, of0[0]), a01 = p3d_load16(rs, of0[1]), a10 = p3d_load16(rs, of0[2]), a11 = p3d_load16(rs, of0[3]);
     f32x16 b00 = p3d_load16(rs, of1[0]), b01 = p3d_load16(rs, of1[1]), b10 = p3d_load16(rs, of1[2]), b11 = p3d_load16(rs, of1[3]);
     __builtin_amdgcn_sched_barrier(0);

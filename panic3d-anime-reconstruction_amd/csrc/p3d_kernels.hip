@@ -237,9 +237,11 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 //   * dead rays: once the binary64 transmittance of a ray is below 1e-60 every later weight alpha * (float)Td is exactly 0
 //     (alpha <= 1; Td can grow by at most (1 + 1e-10) per step), so its remaining samples cannot change any output;
 //   * cropped samples: triplane_crop masks by POSITION (renderer.py:138-149), so sigma = -1000 is known without a decode.
-//   A step whose 32 rays are all dead or cropped skips gather + MLP.  In the final pass a skipped sample's colour is
-//   needed only if one of its two interval weights is non-zero (sigma of the neighbour >= ~794); that is checked on the
-//   exact weights and, if it ever happens, the sample is decoded after all — results are bit-identical by construction.
+//   A step whose 32 rays are all dead or cropped skips gather + MLP; in a mixed step the dead / cropped LANES get
+//   out-of-bounds gather offsets, i.e. they issue no L1 lookups (the gather rate is the binding limit).
+//   In the final pass a skipped sample's colour is needed only if one of its two interval weights is non-zero (sigma of
+//   the neighbour >= ~794); that is checked on the exact weights and, if it ever happens, the sample is decoded after
+//   all — results are bit-identical by construction.
 template <int NF, bool DUMP>
 __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -323,14 +325,15 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
             float t = tcA[i * 32 + j];
             float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
             float sigma = P3D_SIGMA_MASKED;
-            bool skip = false;
+            bool skip = false, live = true;
             if (early) {
                 bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
-                skip = __builtin_amdgcn_ballot_w64(!(cropped || st.Td < 1e-60)) == 0;
+                live = !(cropped || st.Td < 1e-60);  // a cropped sample is -1000 by position; a dead ray's weights are 0
+                skip = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skip) {
                 f32x16 dummy;
-                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy);
+                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
             }
             if constexpr (DUMP) if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
             if (i > 0) {
@@ -427,14 +430,16 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
             f32x16 rgb;
 #pragma unroll
             for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
-            bool skipped = false;
+            bool skipped = false, live = true;
             if (early) {
                 bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
-                skipped = __builtin_amdgcn_ballot_w64(!(cropped || st.Td < 1e-60)) == 0;
+                live = !(cropped || st.Td < 1e-60);
+                skipped = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skipped) {
-                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb);
+                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
+                skipped = !live;  // per lane: a lane whose gathers were suppressed has no colour either
             }
             if constexpr (DUMP) {
                 if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
