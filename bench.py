@@ -7,8 +7,9 @@ Workload (config.workload): BASELINE config c3 with synthetic assets — one 512
 step, 48 coarse + 48 importance samples per ray (= 96 decoded samples/ray on the reference's path), synthetic
 spatially-coherent triplanes [1,3,32,256,256] (fp32), random OSGDecoder, triplane_crop=0.1, cull_clouds=0.5, white_back.
 A step = ImportanceRenderer.forward end to end on the HIP path: NCHW->NHWC plane transpose, the two random draws
-(torch.rand on device, renderer.py:324,371), the fused render kernel, the global depth clamp; for N > 1 also the RCCL
-gather of the final RGBA frames to rank 0.  Inputs (planes, rays, decoder) are resident in HBM before the timed region.
+(torch.rand on device, renderer.py:324,371), the fused render kernel, the global depth clamp.  Multi-GPU: every rank
+renders its own views of the sweep (no data-path collective); when launched by torch.distributed.run the K frames of all
+ranks are gathered to rank 0 with ONE RCCL collective at the end of the sweep, inside the timed region.  Inputs (planes, rays, decoder) are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fused kernel against the HBM roofline using ALGORITHMIC bytes
 ((Sc+Sf)*1536 + 172 bytes per ray — what the reference's algorithm touches per ray; the kernel's exact
@@ -121,6 +122,7 @@ def main():
     opts = ops.make_opts(ro, early_out=not a.no_early_out, **kw)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    frames = torch.empty((a.steps, res, res, 4), dtype=torch.float32, device=dev) if launched else None
 
     def step(i=None):
         nhwc = ops.planes_to_nhwc(planes)
@@ -131,12 +133,14 @@ def main():
         feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
         if i is not None:
             ev[i][1].record()
-        if launched:  # the path's only collective: final RGBA frames to rank 0
-            sharding.gather_frames(sharding.frames_rgba(feat, wsum, res), counts=[1] * world, dst=0, force=True)
+        if launched and i is not None:  # keep this rank's final RGBA frame (channels-last) for the sweep's single gather
+            sharding.frames_rgba(feat, wsum, res, out=frames[i:i + 1], channels_last=True)
         return wsum
 
     for _ in range(a.warmup):
         ws = step()
+    if launched:  # warm the collective too (communicator + buffer registration happen on first use)
+        sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
@@ -144,6 +148,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ws = step(i)
+    if launched:  # the path's only collective: ONE gather of the sweep's final RGBA frames to rank 0 (inside the timed region)
+        gathered = sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
+        if rank == 0:
+            assert gathered.shape == (world * a.steps, res, res, 4)
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
@@ -175,7 +183,7 @@ def main():
             "config": {"workload": f"c3: {res}x{res} rays/view, {Sc}+{Sf} samples/ray, one view per GPU per step, synthetic "
                                    "triplanes [1,3,32,256,256], random OSGDecoder, crop=0.1 cull=0.5 white_back, "
                                    "step = transpose + rand draws + fused render + depth clamp" +
-                                   (" + RCCL gather of RGBA frames" if launched else ""),
+                                   ("; after the K steps ONE RCCL gather of all ranks' RGBA frames to rank 0, inside the timed region" if launched else ""),
                        "rays_per_step_per_gpu": R, "samples_per_ray": Sc + Sf, "parallelism": f"views x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "k_render (p3d_render_f32)", "kernel_ms": kern_ms,

@@ -14,12 +14,23 @@ def partition(n_items, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def frames_rgba(feat, wsum, res):
+def frames_rgba(feat, wsum, res, out=None, channels_last=False):
     """Final RGBA frame of one render: RGB = first 3 feature channels (training/triplane.py:223 image_raw), A = weights
-    sum (generate.py:143-146).  feat [N,R,32], wsum [N,R,1] -> [N,4,res,res]."""
+    sum (generate.py:143-146).  feat [N,R,32], wsum [N,R,1] -> [N,4,res,res], or [N,res,res,4] with channels_last (no
+    transposition: two strided copies; the consumer permutes once after the gather).  `out`: preallocated destination."""
     N = feat.shape[0]
-    rgba = torch.cat([feat[..., :3], wsum], dim=-1)
-    return rgba.permute(0, 2, 1).reshape(N, 4, res, res).contiguous()
+    if channels_last:
+        if out is None:
+            out = torch.empty((N, res, res, 4), dtype=feat.dtype, device=feat.device)
+        flat = out.view(N, res * res, 4)
+        flat[..., :3] = feat[..., :3]
+        flat[..., 3:] = wsum
+        return out
+    rgba = torch.cat([feat[..., :3], wsum], dim=-1).permute(0, 2, 1).reshape(N, 4, res, res)
+    if out is None:
+        return rgba.contiguous()
+    out.copy_(rgba)
+    return out
 
 
 def gather_frames(local, counts=None, dst=0, force=False):
