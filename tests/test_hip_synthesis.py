@@ -174,6 +174,9 @@ def test_triplane_generator_f_vs_reference(hip):
             assert d.max() < 20 * tol and d.mean() < tol, (k, d.max(), d.mean())
         d = np.abs(out["image"][..., ::4, ::4].cpu().numpy() - g["image_sub4"])
         assert out["image"].shape == (2, 3, 512, 512) and d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
+        # PSNR of the final 512^2 image against the reference's G.f (images in [-1,1]: peak-to-peak 2)
+        mse = float(np.mean((out["image"][..., ::4, ::4].cpu().numpy().astype(np.float64) - g["image_sub4"]) ** 2))
+        assert 10 * np.log10(4.0 / mse) > 50.0, 10 * np.log10(4.0 / mse)
         sm = G.sample_mixed(dev(g["sm_pts"]), None, dev(g["ws"]), {}, noise_mode="const")
         assert rel_err(sm["sigma"].cpu().numpy(), g["sm_sigma"]) < 1e-3 and np.abs(sm["rgb"].cpu().numpy() - g["sm_rgb"]).max() < 1e-3
 
