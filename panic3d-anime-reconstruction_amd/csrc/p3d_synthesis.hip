@@ -6,8 +6,9 @@
 //                     4 waves = 2 (32-channel halves) x 2 (64-pixel halves), 2 accumulators per wave.
 //                     MODE 0: 3x3 / pad 1 correlation   (conv1 of every block, networks_stylegan2.py:93 -> conv2d_resample.py:136)
 //                     MODE 1: 1x1                       (ToRGB, networks_stylegan2.py:378)
-//                     MODE 2-5: the four output phases of the stride-2 transposed 3x3 conv (conv0, conv2d_resample.py:114-127);
-//                               only the taps that meet non-zero inputs are multiplied (4/2/2/1 of 9), i.e. no zero-insertion.
+//   k_modconv_up      the stride-2 transposed 3x3 conv of the up-sampling layer (conv0, conv2d_resample.py:114-127): the four
+//                     output phases in one workgroup; only the taps that meet non-zero inputs are multiplied (4/2/2/1 of 9),
+//                     i.e. no zero-insertion.
 //                     The per-sample weights w*s*d of the reference's fused path (networks_stylegan2.py:68-73) are refactored
 //                     into shared weights, input scaling by s and output scaling by d (its own non-fused path, :76-85).
 //   k_demod           d[n,o] = rsqrt(sum_{i,t} (w[o,i,t] s[n,i])^2 + 1e-8)              (networks_stylegan2.py:70-71)
@@ -32,11 +33,6 @@ template <int MODE> struct ConvTaps;
 // dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
 template <> struct ConvTaps<0> { static constexpr int IC = 8; static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
 template <> struct ConvTaps<1> { static constexpr int IC = 32; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
-// transposed conv, out (2y+py, 2x+px) = sum over (ky,kx) with ky == py, kx == px (mod 2) of w[ky][kx] * x[y - ky/2][x - kx/2]
-template <> struct ConvTaps<2> { static constexpr int IC = 16; static constexpr int N = 4; static constexpr int dy[4] = {0,0,-1,-1}; static constexpr int dx[4] = {0,-1,0,-1}; static constexpr int kidx[4] = {0,2,6,8}; static constexpr int py = 0, px = 0, ostride = 2; };
-template <> struct ConvTaps<3> { static constexpr int IC = 32; static constexpr int N = 2; static constexpr int dy[2] = {0,-1}; static constexpr int dx[2] = {0,0}; static constexpr int kidx[2] = {1,7}; static constexpr int py = 0, px = 1, ostride = 2; };
-template <> struct ConvTaps<4> { static constexpr int IC = 32; static constexpr int N = 2; static constexpr int dy[2] = {0,0}; static constexpr int dx[2] = {0,-1}; static constexpr int kidx[2] = {3,5}; static constexpr int py = 1, px = 0, ostride = 2; };
-template <> struct ConvTaps<5> { static constexpr int IC = 32; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {4}; static constexpr int py = 1, px = 1, ostride = 2; };
 
 struct ConvParams {
     const float* x;       // [N][I][H][W]
@@ -196,6 +192,140 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
                 }
                 yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
             }
+    }
+}
+
+// Stride-2 transposed 3x3 convolution with ALL FOUR output phases in one workgroup (conv0 of every block,
+// conv2d_resample.py:114-127).  T[o][2y+py][2x+px] = sum_i sum_{ky == py, kx == px (mod 2)} w[o][i][ky][kx] * x[i][y - ky/2][x - kx/2]:
+// the four phases read the same four input values x[y][x], x[y][x-1], x[y-1][x], x[y-1][x-1] with disjoint subsets of the 9 taps
+// (4 / 2 / 2 / 1).  One staging round (8 input channels: the 10x18 input patch and the [72][64] weight slice, exactly the
+// MODE 0 tiles) feeds 9 MFMAs per input-channel pair and N tile instead of 4 / 2 / 2 / 1 in four separate launches.
+// Grid positions: (H+1) x (W+1); 8 accumulators per wave (4 phases x 2 N tiles of 32 positions).  k pairs = two input channels.
+__global__ __launch_bounds__(256) void k_modconv_up(ConvParams p) {
+    constexpr int CONV_IC = 8, NT = 9, KC = CONV_IC * NT, OT = 64, WROW = OT + 1;
+    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * OT + 255) / 256;
+    __shared__ float xs[CONV_IC * XS_PLANE];
+    __shared__ float ws[KC * WROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * OT;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[4][2];  // [phase = 2*py + px][N tile]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
+    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
+    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;
+    const int pix1 = pix0 + 2 * XS_ROW;
+    const int wcol = wc * 32 + j;
+
+    float xr[XN], wr[WN];
+    auto gload = [&](int ic0) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            int idx = tid_ + u * 256;
+            int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
+            int r = rem / XS_ROW, c = rem - r * XS_ROW;
+            int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
+            float v = 0.0f;
+            if (idx < CONV_IC * XS_PLANE && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
+            xr[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < WN; ++u) {
+            int idx = tid_ + u * 256;
+            int o = idx / KC, k = idx - o * KC;  // k = ic*9 + (ky*3+kx): contiguous in memory
+            int ci = ic0 + k / NT, oo = o0 + o;
+            float v = 0.0f;
+            if (idx < KC * OT && ci < ic_end && oo < p.O) v = p.w[((size_t)oo * p.I + ic0) * 9 + k];
+            wr[u] = v;
+        }
+    };
+    auto lstore = [&]() {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            int idx = tid_ + u * 256;
+            if (idx < CONV_IC * XS_PLANE) xs[idx] = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WN; ++u) {
+            int idx = tid_ + u * 256;
+            int o = idx / KC, k = idx - o * KC;
+            if (idx < KC * OT) ws[k * WROW + o] = wr[u];
+        }
+    };
+    gload(ic_beg);
+    lstore();
+    __syncthreads();
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += CONV_IC) {
+        const bool more = ic0 + CONV_IC < ic_end;
+        if (more) gload(ic0 + CONV_IC);
+#pragma unroll
+        for (int q = 0; q < CONV_IC / 2; ++q) {
+            // this lane's input channel of the pair: lanes 0-31 -> 2q, lanes 32-63 -> 2q+1
+            const int icl = 2 * q + half;
+            const float* xp = xs + icl * XS_PLANE;
+            const float* wrow = ws + (icl * NT) * WROW + wcol;
+            // the four input values per N tile: [dy][dx] with dy, dx in {0, -1}
+            float b00[2], b01[2], b10[2], b11[2];
+            b00[0] = xp[pix0]; b01[0] = xp[pix0 - 1]; b10[0] = xp[pix0 - XS_ROW]; b11[0] = xp[pix0 - XS_ROW - 1];
+            b00[1] = xp[pix1]; b01[1] = xp[pix1 - 1]; b10[1] = xp[pix1 - XS_ROW]; b11[1] = xp[pix1 - XS_ROW - 1];
+            float a[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a[t] = wrow[t * WROW];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // phase (0,0): taps (0,0) (0,2) (2,0) (2,2)
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b00[t], acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b01[t], acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], b10[t], acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], b11[t], acc[0][t], 0, 0, 0);
+                // phase (0,1): taps (0,1) (2,1)
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b00[t], acc[1][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], b10[t], acc[1][t], 0, 0, 0);
+                // phase (1,0): taps (1,0) (1,2)
+                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b00[t], acc[2][t], 0, 0, 0);
+                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], b01[t], acc[2][t], 0, 0, 0);
+                // phase (1,1): tap (1,1)
+                acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], b00[t], acc[3][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (more) lstore();
+        __syncthreads();
+    }
+    // ---- raw store of the four phases (ksplit > 1: into slice kz of the partial buffer); the FIR pass applies the epilogue
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+            if (gy > p.H - py || gx > p.W - px) continue;  // phase grids: rows 0..H (py = 0) or 0..H-1 (py = 1)
+            const int oy = 2 * gy + py, ox = 2 * gx + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
+            }
+        }
     }
 }
 
@@ -418,11 +548,10 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     if (up == 1) {
         p.GH = H; p.GW = W;
         if (ks == 3) launch_conv<0>(p, st); else launch_conv<1>(p, st);
-    } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1], one launch per output phase
-        p.GH = H + 1; p.GW = W + 1; launch_conv<2>(p, st);
-        p.GH = H + 1; p.GW = W;     launch_conv<3>(p, st);
-        p.GH = H;     p.GW = W + 1; launch_conv<4>(p, st);
-        p.GH = H;     p.GW = W;     launch_conv<5>(p, st);
+    } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
+        p.GH = H + 1; p.GW = W + 1;
+        dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+        hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
     if (ksplit > 1) {
         ReduceParams r;
