@@ -60,23 +60,26 @@ DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
     return v;
 }
 
-// OT: output channels per workgroup (64: one 32-channel A tile per wave, 128: two).  Per k pair a wave issues OT/64 A reads,
-// 2 B reads and 2*OT/64 MFMAs.
-template <int MODE, int OT>
+// OT: output channels per workgroup (64: one 32-channel A tile per wave, 128: two).  TH: pixel-tile rows (8 or 16; 16 columns):
+// every wave owns TH/2 rows = TH/4 N tiles of 32 pixels.  Per k pair a wave issues OT/64 A reads, TH/4 B reads and
+// (OT/64)*(TH/4) MFMAs; a bigger tile amortises the staging round and its two barriers over more MFMA work.
+template <int MODE, int OT, int TH>
 __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N;
     constexpr int CONV_IC = T::IC;
     constexpr int KC = CONV_IC * NT;  // k values per chunk
     constexpr int NA = OT / 64;       // A tiles per wave
+    constexpr int NB = TH / 4;        // N tiles per wave
     constexpr int WROW = OT + 1;
-    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * OT + 255) / 256;  // staged values per thread
-    __shared__ float xs[CONV_IC * XS_PLANE];
+    constexpr int XPL = (TH + 2) * XS_ROW;  // patch plane: (TH+2) x 18
+    constexpr int XN = (CONV_IC * XPL + 255) / 256, WN = (KC * OT + 255) / 256;  // staged values per thread
+    __shared__ float xs[CONV_IC * XPL];
     __shared__ float ws[KC * WROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
     const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
-    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
     const int o0 = blockIdx.y * OT;
     const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;  // split-K slice of the input channels
     const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;  // multiple of every mode's IC
@@ -85,17 +88,16 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     const float* sn = p.styles + (size_t)n * p.I;
     const int kk9 = p.ks * p.ks;
 
-    f32x16 acc[NA][2];
+    f32x16 acc[NA][NB];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NB; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
-    // this lane's pixel inside the tile for the two N tiles: rows 4wp + 2t + (j>>4), col j & 15
-    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
-    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;          // N tile 0 (halo origin at +1,+1)
-    const int pix1 = pix0 + 2 * XS_ROW;                        // N tile 1 (two rows below)
+    // this lane's pixel inside the tile for N tile t: row (TH/2)*wp + 2t + (j>>4), col j & 15
+    const int prow0 = (TH / 2) * wp + (j >> 4), pcol = j & 15;
+    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;  // N tile 0 (halo origin at +1,+1); tile t is 2t rows below
     const int wcol = wc * (OT / 2) + j;
 
     float xr[XN], wr[WN];
@@ -106,11 +108,11 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
             int idx = tid_ + u * 256;
-            int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
+            int ic = idx / XPL, rem = idx - ic * XPL;
             int r = rem / XS_ROW, c = rem - r * XS_ROW;
             int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
             float v = 0.0f;
-            if (idx < CONV_IC * XS_PLANE && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+            if (idx < CONV_IC * XPL && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
                 v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
             xr[u] = v;
         }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
             int idx = tid_ + u * 256;
-            if (idx < CONV_IC * XS_PLANE) xs[idx] = xr[u];
+            if (idx < CONV_IC * XPL) xs[idx] = xr[u];
         }
 #pragma unroll
         for (int u = 0; u < WN; ++u) {
@@ -151,17 +153,18 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
         for (int q = 0; q < KC / 2; ++q) {
             // lanes 0-31 take k = 2q, lanes 32-63 take k = 2q+1  (A[i][k], B[k][j] operand layout of 32x32x2)
             const int k0 = 2 * q, k1 = 2 * q + 1;
-            const int xo0 = (k0 / NT) * XS_PLANE + T::dy[k0 % NT] * XS_ROW + T::dx[k0 % NT];
-            const int xo1 = (k1 / NT) * XS_PLANE + T::dy[k1 % NT] * XS_ROW + T::dx[k1 % NT];
+            const int xo0 = (k0 / NT) * XPL + T::dy[k0 % NT] * XS_ROW + T::dx[k0 % NT];
+            const int xo1 = (k1 / NT) * XPL + T::dy[k1 % NT] * XS_ROW + T::dx[k1 % NT];
             const int xo = half ? xo1 : xo0;
             const int kk = half ? k1 : k0;
-            float b0 = xs[xo + pix0];
-            float b1 = xs[xo + pix1];
+            float bv[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) bv[t] = xs[xo + pix0 + 2 * t * XS_ROW];
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 float av = ws[kk * WROW + wcol + 32 * a];
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[a][t], 0, 0, 0);
             }
             // keep the LDS operand reads at most 4 steps ahead of their MFMAs (hoisting all reads costs ~100 VGPRs)
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     // ---- epilogue (ksplit > 1: raw partial sums into slice kz of the partial buffer)
     float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NB; ++t) {
         const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
         if (gy >= p.GH || gx >= p.GW) continue;
         const int oy = gy * T::ostride + T::py, ox = gx * T::ostride + T::px;
@@ -486,22 +489,24 @@ static inline int chk() {
     return e == hipSuccess ? P3D_OK : (int)e;
 }
 
-// output-channel tile.  The 128-channel variant (two A tiles per wave: half the LDS reads and staging per MFMA) measured
-// SLOWER on MI355X at every generator shape (e.g. 256->256 @256^2: 53 vs 66 TF) — fewer, fatter workgroups — so 64 is used.
-static int conv_ot(int O) { (void)O; return 64; }
+// (A 128-channel output tile — two A tiles per wave — measured SLOWER on MI355X at every generator shape, e.g. 256->256 @256^2:
+// 53 vs 66 TF: fewer, fatter workgroups.  OT stays 64.)
+
+// pixel-tile rows.  16-row tiles (4 N tiles per wave) measured no better than 8 on MI355X (256->256 @256^2: 58.7 vs 66 TF;
+// 128->128 @512^2: 69 vs 67 TF), so 8 is used everywhere.
+static int conv_th(int N, int O, int GH, int GW) { (void)N; (void)O; (void)GH; (void)GW; return 8; }
 
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
-    const int ot = conv_ot(p.O);
-    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + ot - 1) / ot, p.N * p.ksplit);
-    if (ot == 128) hipLaunchKernelGGL((k_modconv<MODE, 128>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_modconv<MODE, 64>), grid, dim3(256), 0, st, p);
+    const int th = conv_th(p.N, p.O, p.GH, p.GW);
+    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + th - 1) / th), (p.O + 63) / 64, p.N * p.ksplit);
+    if (th == 16) hipLaunchKernelGGL((k_modconv<MODE, 64, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_modconv<MODE, 64, 8>), grid, dim3(256), 0, st, p);
 }
 
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
 static int choose_ksplit(int N, int I, int O, int GH, int GW) {
-    const int ot = conv_ot(O);
-    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + ot - 1) / ot) * N;
+    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
     while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 64) ks *= 2;
     return ks;
