@@ -12,6 +12,8 @@ Differences that are deliberate:
     OSGDecoder-shaped module: net[0] 32->64, Softplus, net[2] 64->33 (training/triplane.py:516-544);
   * CPU tensors raise: the product path has no CPU fallback.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -28,15 +30,18 @@ class ImportanceRenderer(torch.nn.Module):
     def __init__(self, use_triplane=False):
         super().__init__()
         self.use_triplane = bool(use_triplane)  # generate_planes(use_triplane): renderer.py:26-50
-        self._planes_cache = (None, None)
+        self._planes_cache = (None, None, None)
 
     def _nhwc(self, planes):
-        # planes arrive NCHW [N,3,32,H,W] (training/triplane.py:200-206).  Reuse the channels-last copy while the same
-        # tensor (same storage, same version) is rendered again — generate.py renders 16 views per subject.
-        key = (planes.data_ptr(), planes._version, tuple(planes.shape), planes.device)
-        if self._planes_cache[0] != key:
-            self._planes_cache = (key, ops.planes_to_nhwc(planes))
-        return self._planes_cache[1]
+        # planes arrive NCHW [N,3,32,H,W] (training/triplane.py:200-206).  Reuse the channels-last copy only while the very
+        # same tensor OBJECT (weak reference) at the same version is rendered again — generate.py renders 16 views per
+        # subject.  (Keying on data_ptr would alias a freed tensor whose storage the caching allocator handed out again.)
+        ref, version, cached = self._planes_cache
+        if ref is not None and ref() is planes and version == planes._version:
+            return cached
+        cached = ops.planes_to_nhwc(planes)
+        self._planes_cache = (weakref.ref(planes), planes._version, cached)
+        return cached
 
     def _opts(self, rendering_options, decoder, **kw):
         ro = dict(rendering_options)

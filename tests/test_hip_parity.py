@@ -243,3 +243,29 @@ def test_psnr_vs_reference_render(hip, name):
     img = out[0][..., :3].cpu().numpy() * 0.5 + 0.5
     ref = g["feat"][..., :3] * 0.5 + 0.5
     assert psnr(img, ref) > 80.0, psnr(img, ref)
+
+
+def test_renderer_plane_cache_is_not_fooled_by_reused_storage(hip):
+    """ImportanceRenderer caches the channels-last copy of the planes per tensor OBJECT; a new planes tensor that the caching
+    allocator places at the same address must not hit the cache."""
+    r = hip.ImportanceRenderer(use_triplane=True)
+
+    class FC:
+        def __init__(self, o, i, seed):
+            g = torch.Generator().manual_seed(seed)
+            self.weight, self.bias = torch.randn(o, i, generator=g).cuda(), torch.randn(o, generator=g).cuda()
+            self.weight_gain, self.bias_gain = 1 / np.sqrt(i), 1
+
+    class Dec:
+        force_sigmoid = True
+        net = [FC(64, 32, 1), None, FC(33, 64, 2)]
+
+    pts = torch.rand(1, 1000, 3).cuda() * 0.5 - 0.25
+    outs = []
+    for seed in (1, 2):
+        planes = torch.randn(1, 3, 32, 64, 64, generator=torch.Generator().manual_seed(seed)).cuda()
+        outs.append((r.run_model(planes, Dec(), pts, None, T.RENDERING_KWARGS)["sigma"].clone(), planes.data_ptr()))
+        same = r.run_model(planes, Dec(), pts, None, T.RENDERING_KWARGS)["sigma"]  # same object again: cache hit, same result
+        assert torch.equal(same, outs[-1][0])
+        del planes
+    assert not torch.equal(outs[0][0], outs[1][0])
