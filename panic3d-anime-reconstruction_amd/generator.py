@@ -88,6 +88,15 @@ class TriPlaneGenerator(torch.nn.Module):
         self._last_planes = None
         self._inject_draws = None  # tests: (jitter, u) for the renderer instead of device RNG
 
+    def _sign(self, device):
+        """(-1, 1, -1) on `device`, created once (a host->device copy is not allowed inside a hipGraph capture); a plain
+        attribute, not a buffer: the module's state_dict must stay identical to the reference's."""
+        t = self.__dict__.get("_sign_cache")
+        if t is None or t.device != device:
+            t = torch.tensor([-1.0, 1.0, -1.0], device=device)[None, :, None, None]
+            self.__dict__["_sign_cache"] = t
+        return t
+
     # ---- latents ------------------------------------------------------------------------------------------------
     def mapping(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         rk = self.rendering_kwargs
@@ -153,7 +162,7 @@ class TriPlaneGenerator(torch.nn.Module):
         xyz_image = xyz.permute(0, 2, 1).reshape(N, 3, H, W).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(N, 1, H, W)
         weights_image = wsum.permute(0, 2, 1).reshape(N, 1, H, W)
-        xyz_image = 0.5 * (xyz_image + 1) * torch.tensor([-1, 1, -1], device=xyz_image.device)[None, :, None, None]
+        xyz_image = 0.5 * (xyz_image + 1) * self._sign(xyz_image.device)
         rgb_image = feature_image[:, :3]
         sr_kw = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
         sr_image = self.superresolution(rgb_image, feature_image, ws,
