@@ -86,11 +86,13 @@ int p3d_triplane_decode_f32(const float* planes_nhwc, int N, int H, int W, const
 /* Density-only run_model on the reference's regular grid (create_samples + the chunk loop of get_eg3d_volume,
  * _util/eg3d_metrics3d.py:70-92,124-151) without materialising the points: flat grid indices [lo, hi) of a grid_n^3 grid;
  * column c of a point = index component * voxel_size + off_c (off0 = voxel_origin[2], off1 = [1], off2 = [0] there), computed
- * with the reference's float arithmetic.  planes_nhwc [1][3][H][W][32]; out_sigma [hi - lo]; out_points [hi - lo][3] or NULL
- * (the generated points, for the caller's crop mask). */
+ * with the reference's float arithmetic.  planes_nhwc [1][3][H][W][32]; out_sigma [hi - lo]; out_cropmask [hi - lo] bytes or
+ * NULL: 1 where |x| > mask_limit or |z| > mask_limit (triplane_crop_mask, renderer.py:138-149, which get_eg3d_volume applies
+ * to the densities AFTER activation, eg3d_metrics3d.py:158-160 — so it is returned, not applied). */
 int p3d_grid_density_f32(const float* planes_nhwc, int H, int W, int grid_n, int64_t lo, int64_t hi, float voxel_size,
                          float off0, float off1, float off2, const float* w0, const float* b0, const float* w1,
-                         const float* b1, const p3d_opts* opts, float* out_sigma, float* out_points, void* stream);
+                         const float* b1, const p3d_opts* opts, float* out_sigma, unsigned char* out_cropmask,
+                         float mask_limit, void* stream);
 
 /* ImportanceRenderer.forward (renderer.py:162-264), fused: stratified depths, coarse density pass, ray-marcher weights,
  * importance resampling, depth merge, final decode + compositing.  rays_o/rays_d [N][R][3]; jitter [N][R][Sc] (the

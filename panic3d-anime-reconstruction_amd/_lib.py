@@ -31,7 +31,7 @@ _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "p3d_planes_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "p3d_triplane_decode_f32": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P]),
-    "p3d_grid_density_f32": (_I, [_P, _I, _I, _I, _L, _L, _F, _F, _F, _F, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P]),
+    "p3d_grid_density_f32": (_I, [_P, _I, _I, _I, _L, _L, _F, _F, _F, _F, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _F, _P]),
     "p3d_render_workspace_bytes": (_Z, [_I, _L, _I, _I]),
     "p3d_render_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
                             _Z, C.POINTER(Dumps), _P]),

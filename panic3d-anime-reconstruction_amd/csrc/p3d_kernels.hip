@@ -56,7 +56,8 @@ struct DecodeParams {
     const float *w0, *b0, *w1, *b1;
     float* out_sigma;  // [N][M]
     float* out_rgb;    // [N][M][32] or null
-    float* out_points; // grid mode only: [M][3] generated points, or null
+    unsigned char* out_cropmask;  // grid mode only: [M] 1 where |x| or |z| > mask_limit (triplane_crop_mask), or null
+    float mask_limit;
     long long M;
     long long tiles_per_img;  // ceil(M/32)
     long long ntiles;
@@ -100,10 +101,8 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
             const float s1 = __builtin_fmodf(q1, fn);
             const float s0 = __builtin_fmodf(q1 / fn, fn);
             px = s0 * p.vsize + p.goff0; py = s1 * p.vsize + p.goff1; pz = s2 * p.vsize + p.goff2;
-            if (p.out_points && active && h == 0) {
-                float* q = p.out_points + (size_t)m * 3;
-                q[0] = px; q[1] = py; q[2] = pz;
-            }
+            if (p.out_cropmask && active && h == 0)
+                p.out_cropmask[m] = (__builtin_fabsf(px) > p.mask_limit || __builtin_fabsf(pz) > p.mask_limit) ? 1 : 0;
         }
         float sigma;
         f32x16 rgb;
@@ -715,7 +714,7 @@ int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const floa
     p.tiles_per_img = (M + 31) / 32;
     p.ntiles = p.tiles_per_img * N;
     p.cfg = make_cfg(opts);
-    p.grid_n = 0; p.grid_lo = 0; p.vsize = p.goff0 = p.goff1 = p.goff2 = 0.0f; p.out_points = nullptr;
+    p.grid_n = 0; p.grid_lo = 0; p.vsize = p.goff0 = p.goff1 = p.goff2 = 0.0f; p.out_cropmask = nullptr; p.mask_limit = 0.0f;
     long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     if (out_rgb)
@@ -727,12 +726,12 @@ int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const floa
 
 int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t lo, int64_t hi, float voxel_size, float off0,
                          float off1, float off2, const float* w0, const float* b0, const float* w1, const float* b1,
-                         const p3d_opts* opts, float* out_sigma, float* out_points, void* stream) {
+                         const p3d_opts* opts, float* out_sigma, unsigned char* out_cropmask, float mask_limit, void* stream) {
     if (!planes || !w0 || !b0 || !w1 || !b1 || !opts || !out_sigma || grid_n <= 1 || lo < 0 || hi <= lo) return P3D_E_ARG;
     if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL || hi > (int64_t)grid_n * grid_n * grid_n) return P3D_E_RANGE;
     DecodeParams p;
     p.planes = planes; p.coords = nullptr; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
-    p.out_sigma = out_sigma; p.out_rgb = nullptr; p.out_points = out_points; p.M = hi - lo; p.H = H; p.W = W;
+    p.out_sigma = out_sigma; p.out_rgb = nullptr; p.out_cropmask = out_cropmask; p.mask_limit = mask_limit; p.M = hi - lo; p.H = H; p.W = W;
     p.tiles_per_img = (p.M + 31) / 32;
     p.ntiles = p.tiles_per_img;
     p.cfg = make_cfg(opts);

@@ -245,6 +245,10 @@ class TriPlaneGenerator(torch.nn.Module):
                                triplane_crop=x.get("triplane_crop"), cull_clouds=x.get("cull_clouds"),
                                binarize_clouds=x.get("binarize_clouds"), force_rays=force_rays, stop_level=stop_level,
                                normalize_images=normalize_images, neural_rendering_resolution=res,
+                               # extensions of the dict API (absent keys = the reference's behaviour): reuse the planes of
+                               # the previous call for further views of the same subject, deterministic backbone noise
+                               cache_backbone=bool(x.get("cache_backbone", False)),
+                               use_cached_backbone=bool(x.get("use_cached_backbone", False)),
                                **({"noise_mode": x["noise_mode"]} if "noise_mode" in x else {}))
         ret = {k: synth[k] for k in ("image", "image_raw", "image_depth", "image_weights", "triplane", "image_xyz")}
         ret["normalize_images"] = normalize_images

@@ -122,22 +122,24 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     return sigma, rgb
 
 
-def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, return_points=False):
+def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None):
     """Density-only decode of flat indices [lo, hi) of the reference's grid_n^3 sample grid (create_samples), the points
-    generated inside the kernel.  planes_nhwc [1,3,H,W,32] -> sigma [1, hi-lo, 1]."""
+    generated inside the kernel.  planes_nhwc [1,3,H,W,32] -> sigma [1, hi-lo, 1]; with crop_limit also the bool mask
+    [1, hi-lo, 1] of triplane_crop_mask (|x| or |z| beyond the limit) evaluated on the same generated points."""
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     if planes_nhwc.shape[0] != 1:
         raise RuntimeError("grid_density renders one subject at a time")
     _, _, H, W, _ = planes_nhwc.shape
     w0, b0, w1, b1 = _chk_mlp(mlp)
     sigma = torch.empty((1, hi - lo, 1), dtype=torch.float32, device=planes_nhwc.device)
-    pts = torch.empty((1, hi - lo, 3), dtype=torch.float32, device=planes_nhwc.device) if return_points else None
+    msk = torch.empty((1, hi - lo, 1), dtype=torch.uint8, device=planes_nhwc.device) if crop_limit is not None else None
     with torch.cuda.device(planes_nhwc.device):
         rc = _lib.lib().p3d_grid_density_f32(_p(planes_nhwc), H, W, int(grid_n), int(lo), int(hi), np.float32(voxel_size),
                                               np.float32(offsets[0]), np.float32(offsets[1]), np.float32(offsets[2]), _p(w0),
-                                              _p(b0), _p(w1), _p(b1), C.byref(opts), _p(sigma), _p(pts), _stream())
+                                              _p(b0), _p(w1), _p(b1), C.byref(opts), _p(sigma), _p(msk),
+                                              np.float32(crop_limit if crop_limit is not None else 0.0), _stream())
     _lib.check(rc, "p3d_grid_density_f32")
-    return (sigma, pts) if return_points else sigma
+    return (sigma, msk.bool()) if crop_limit is not None else sigma
 
 
 DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "inds", "depths_sorted", "sigma_sorted",

@@ -50,13 +50,12 @@ def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None
     # the grid points are generated inside the decode kernel with create_samples' float arithmetic (no points tensor)
     origin = np.array([0, 0, 0]) - rk["box_warp"] / 2
     vs = rk["box_warp"] / (resolution - 1)
-    res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts,
-                           return_points=triplane_crop is not None)
-    sig, pts = res if triplane_crop is not None else (res, None)
+    lim = None if triplane_crop is None else rk["box_warp"] / 2 - triplane_crop
+    res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts, crop_limit=lim)
+    sig, cropmask = res if lim is not None else (res, None)
     dens = sigma2density(sig)
-    if triplane_crop is not None:  # triplane_crop_mask (renderer.py:138-149) on the sample points: |x| or |z| beyond box/2 - crop
-        lim = rk["box_warp"] / 2 - triplane_crop
-        dens.masked_fill_(((pts[..., 0].abs() > lim) | (pts[..., 2].abs() > lim)).unsqueeze(-1), -1e3)
+    if cropmask is not None:  # triplane_crop_mask (renderer.py:138-149) on the sample points, applied to the DENSITIES
+        dens.masked_fill_(cropmask, -1e3)
     if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
         dens.masked_fill_(sigma2density(dens) < cull_clouds, -1e3)
     return {"sigmas": sig, "densities": dens}

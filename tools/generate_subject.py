@@ -59,8 +59,15 @@ with torch.no_grad():
         o = G.f(xin)
         imgs.append(o["image"])
     t3 = sync()
+    imgs2 = []
+    for k, (elev, azim, fov) in enumerate(views):  # same flow, planes synthesised once per subject (x['use_cached_backbone'])
+        xin = {"elevations": elev * torch.ones(1, device=dev), "azimuths": azim * torch.ones(1, device=dev),
+               "fovs": fov * torch.ones(1, device=dev), "cond": cond, "seeds": [0], "noise_mode": "const",
+               "cache_backbone": k == 0, "use_cached_backbone": k > 0, **opts}
+        imgs2.append(G.f(xin)["image"])
+    t4 = sync()
 assert all(i.shape == (1, 3, 512, 512) and torch.isfinite(i).all() for i in imgs) and dens.shape == (1, 1, 256, 256, 256)
 print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "views": len(views),
                   "views_with_paste_ms": (t3 - t2) * 1e3, "ms_per_view": (t3 - t2) * 1e3 / len(views),
-                  "subject_total_ms": (t3 - t0) * 1e3, "mean_alpha_last_view": float(o["image_weights"].mean()),
+                  "subject_total_ms": (t3 - t0) * 1e3, "ms_per_view_planes_cached": (t4 - t3) * 1e3 / len(views), "mean_alpha_last_view": float(o["image_weights"].mean()),
                   "paste_mask_mean_last_view": float(o["paste"]["mask"].mean())}))
