@@ -32,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int MODE> struct ConvTaps;
 // dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
 template <> struct ConvTaps<0> { static constexpr int IC = 8; static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
-template <> struct ConvTaps<1> { static constexpr int IC = 32; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
+template <> struct ConvTaps<1> { static constexpr int IC = 8; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
 
 struct ConvParams {
     const float* x;       // [N][I][H][W]
@@ -101,47 +101,55 @@ __global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
     const int wcol = wc * (OT / 2) + j;
 
     float xr[XN], wr[WN];
+    // Staging plan of this thread, computed ONCE (the f32 MFMA shares its SIMD with the VALU, so every index instruction in
+    // the K loop is paid in MFMA time): per staged value the element offset inside the chunk-relative source and the LDS slot.
+    int xsrc[XN], wsrc[WN], wdst[WN];  // -1 = padding / out of range; source offsets carry the chunk-local channel in bits 24+
+#pragma unroll
+    for (int u = 0; u < XN; ++u) {
+        int idx = tid + u * 256;
+        int ic = idx / XPL, rem = idx - ic * XPL;
+        int r = rem / XS_ROW, c = rem - r * XS_ROW;
+        int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        bool ok = idx < CONV_IC * XPL && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        xsrc[u] = ok ? (((ic * p.H + iy) * p.W + ix) | (ic << 24)) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < WN; ++u) {
+        int idx = tid + u * 256;
+        int o = idx / KC, k = idx - o * KC;
+        int ic = k / NT, t = k - ic * NT;
+        bool ok = idx < KC * OT && o0 + o < p.O;
+        wsrc[u] = ok ? ((((o0 + o) * p.I + ic) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])) | (ic << 24)) : -1;
+        wdst[u] = idx < KC * OT ? k * WROW + o : -1;
+    }
+    const int HW = p.H * p.W;
     // global -> registers: modulated input patch s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c] (zero outside) and the weight slice
     auto gload = [&](int ic0) {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));  // keep the index arithmetic inside the loop (hoisted, it pins ~100 VGPRs)
+        const float* xb = xn + (size_t)ic0 * HW;
+        const float* wb = p.w + (size_t)ic0 * kk9;
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
-            int idx = tid_ + u * 256;
-            int ic = idx / XPL, rem = idx - ic * XPL;
-            int r = rem / XS_ROW, c = rem - r * XS_ROW;
-            int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
             float v = 0.0f;
-            if (idx < CONV_IC * XPL && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
+            const int ch = ic0 + (xsrc[u] >> 24);
+            if (xsrc[u] >= 0 && ch < ic_end) v = sn[ch] * xb[xsrc[u] & 0xffffff];
             xr[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < WN; ++u) {
-            int idx = tid_ + u * 256;
-            int o = idx / KC, k = idx - o * KC;
-            int ic = k / NT, t = k - ic * NT;
-            int ci = ic0 + ic, oo = o0 + o;
             float v = 0.0f;
-            if (idx < KC * OT && ci < ic_end && oo < p.O)
-                v = p.w[((size_t)oo * p.I + ci) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])];
+            if (wsrc[u] >= 0 && ic0 + (wsrc[u] >> 24) < ic_end) v = wb[wsrc[u] & 0xffffff];
             wr[u] = v;
         }
     };
     auto lstore = [&]() {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
-            int idx = tid_ + u * 256;
+            int idx = tid + u * 256;
             if (idx < CONV_IC * XPL) xs[idx] = xr[u];
         }
 #pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            int idx = tid_ + u * 256;
-            int o = idx / KC, k = idx - o * KC;
-            if (idx < KC * OT) ws[k * WROW + o] = wr[u];
-        }
+        for (int u = 0; u < WN; ++u)
+            if (wdst[u] >= 0) ws[wdst[u]] = wr[u];
     };
     gload(ic_beg);
     lstore();
@@ -233,44 +241,52 @@ __global__ __launch_bounds__(256) void k_modconv_up(ConvParams p) {
     const int wcol = wc * 32 + j;
 
     float xr[XN], wr[WN];
+    // staging plan computed once (see k_modconv): source offsets carry the chunk-local channel in bits 24+; -1 = padding
+    int xsrc[XN], wsrc[WN], wdst[WN];
+#pragma unroll
+    for (int u = 0; u < XN; ++u) {
+        int idx = tid + u * 256;
+        int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
+        int r = rem / XS_ROW, c = rem - r * XS_ROW;
+        int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        bool ok = idx < CONV_IC * XS_PLANE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        xsrc[u] = ok ? (((ic * p.H + iy) * p.W + ix) | (ic << 24)) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < WN; ++u) {
+        int idx = tid + u * 256;
+        int o = idx / KC, k = idx - o * KC;  // k = ic*9 + (ky*3+kx): contiguous in memory
+        bool ok = idx < KC * OT && o0 + o < p.O;
+        wsrc[u] = ok ? (((o0 + o) * p.I * 9 + k) | ((k / NT) << 24)) : -1;
+        wdst[u] = idx < KC * OT ? k * WROW + o : -1;
+    }
+    const int HW = p.H * p.W;
     auto gload = [&](int ic0) {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
+        const float* xb = xn + (size_t)ic0 * HW;
+        const float* wb = p.w + (size_t)ic0 * 9;
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
-            int idx = tid_ + u * 256;
-            int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
-            int r = rem / XS_ROW, c = rem - r * XS_ROW;
-            int iy = gy0 - 1 + r, ix = gx0 - 1 + c, ci = ic0 + ic;
             float v = 0.0f;
-            if (idx < CONV_IC * XS_PLANE && ci < ic_end && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = sn[ci] * xn[((size_t)ci * p.H + iy) * p.W + ix];
+            const int ch = ic0 + (xsrc[u] >> 24);
+            if (xsrc[u] >= 0 && ch < ic_end) v = sn[ch] * xb[xsrc[u] & 0xffffff];
             xr[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < WN; ++u) {
-            int idx = tid_ + u * 256;
-            int o = idx / KC, k = idx - o * KC;  // k = ic*9 + (ky*3+kx): contiguous in memory
-            int ci = ic0 + k / NT, oo = o0 + o;
             float v = 0.0f;
-            if (idx < KC * OT && ci < ic_end && oo < p.O) v = p.w[((size_t)oo * p.I + ic0) * 9 + k];
+            if (wsrc[u] >= 0 && ic0 + (wsrc[u] >> 24) < ic_end) v = wb[wsrc[u] & 0xffffff];
             wr[u] = v;
         }
     };
     auto lstore = [&]() {
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
-            int idx = tid_ + u * 256;
+            int idx = tid + u * 256;
             if (idx < CONV_IC * XS_PLANE) xs[idx] = xr[u];
         }
 #pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            int idx = tid_ + u * 256;
-            int o = idx / KC, k = idx - o * KC;
-            if (idx < KC * OT) ws[k * WROW + o] = wr[u];
-        }
+        for (int u = 0; u < WN; ++u)
+            if (wdst[u] >= 0) ws[wdst[u]] = wr[u];
     };
     gload(ic_beg);
     lstore();

@@ -17,6 +17,6 @@ def run(I, O, H, up, ks, N=1):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
     fl = 2 * ks * ks * I * O * H * H * N
     print(f"I={I:4d} O={O:4d} H={H:4d} up={up} ks={ks} N={N}: {dt*1e3:7.3f} ms  {fl/dt/1e12:6.1f} TF  ({fl/1e9:.1f} GFLOP)")
-for cfg in [(512, 512, 4, 1, 3), (512, 512, 16, 1, 3), (512, 512, 32, 2, 3), (512, 512, 64, 1, 3), (512, 256, 64, 2, 3), (256, 256, 128, 1, 3),
+for cfg in [(256, 3, 256, 1, 1), (128, 3, 512, 1, 1), (32, 256, 128, 2, 3), (512, 512, 4, 1, 3), (512, 512, 16, 1, 3), (512, 512, 32, 2, 3), (512, 512, 64, 1, 3), (512, 256, 64, 2, 3), (256, 256, 128, 1, 3),
             (256, 128, 128, 2, 3), (128, 128, 256, 1, 3), (128, 96, 256, 1, 1), (256, 256, 256, 1, 3), (256, 128, 256, 2, 3), (128, 128, 512, 1, 3)]:
     run(*cfg)
