@@ -36,6 +36,8 @@ extern "C" {
 #define P3D_FLAG_FORCE_SIGMOID 8 /* OSGDecoder.force_sigmoid     (training/triplane.py:539-542) */
 #define P3D_FLAG_WHITE_BACK 16   /* rendering_options.white_back (ray_marcher.py:52-53) */
 #define P3D_FLAG_NO_EARLY_OUT 32 /* p3d_render_f32: disable the exact early-outs (decode every sample; measurement / tests) */
+#define P3D_FLAG_SHARED_PLANES 64 /* planes holds ONE image [1][3][H][W][32] shared by all N batches of rays / points (many
+                                    views of one subject in one launch; the reference would pass planes.expand(N, ...)) */
 
 #define P3D_C 32        /* channels per plane (triplane_width, training/triplane.py:41) */
 #define P3D_HID 64      /* OSGDecoder hidden_dim (training/triplane.py:519) */

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
         bool active = m < p.M;
         long long mc = active ? m : p.M - 1;
         unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
-        const float* base = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
+        const float* base = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
         auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
         float px, py, pz;
         if (p.coords) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
     g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
     unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
-    const float* pbase = p.planes + (size_t)nlo * 3 * (g.plane_bytes / 4);
+    const float* pbase = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
     const P3dDecodeCfg cfg = p.cfg;
     const bool early = !DUMP && !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);

@@ -71,6 +71,12 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
 
 
+def _with_flag(opts, flag):
+    o = Opts.from_buffer_copy(opts)
+    o.flags |= flag
+    return o
+
+
 def prescale_mlp(w0, b0, w1, b1, weight_gain0, bias_gain0, weight_gain1, bias_gain1):
     """FullyConnectedLayer.forward's `w * weight_gain`, `b * bias_gain` (networks_stylegan2.py:121-127), in float32."""
     w0s = (w0.detach().float() * float(weight_gain0)).contiguous()
@@ -109,8 +115,10 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     coords = _chk(coords, "coords")
     N, three, H, W, Cc = planes_nhwc.shape
+    if N == 1 and coords.dim() == 3 and coords.shape[0] > 1:  # one subject, several point batches: planes are shared
+        N, opts = coords.shape[0], _with_flag(opts, _lib.P3D_FLAG_SHARED_PLANES)
     if three != 3 or Cc != 32 or coords.dim() != 3 or coords.shape[0] != N or coords.shape[2] != 3:
-        raise RuntimeError("planes_nhwc must be [N,3,H,W,32] and coords [N,M,3]")
+        raise RuntimeError("planes_nhwc must be [N,3,H,W,32] (or [1,...] shared) and coords [N,M,3]")
     w0, b0, w1, b1 = _chk_mlp(mlp)
     M = coords.shape[1]
     sigma = torch.empty((N, M, 1), dtype=torch.float32, device=coords.device)
@@ -154,8 +162,10 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     rays_o, rays_d, jitter = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions"), _chk(jitter, "jitter")
     N, three, H, W, Cc = planes_nhwc.shape
+    if N == 1 and rays_o.dim() == 3 and rays_o.shape[0] > 1:  # many views of ONE subject in one launch: planes are shared
+        N, opts = rays_o.shape[0], _with_flag(opts, _lib.P3D_FLAG_SHARED_PLANES)
     if three != 3 or Cc != 32 or rays_o.dim() != 3 or rays_o.shape[0] != N or rays_o.shape[2] != 3 or rays_d.shape != rays_o.shape:
-        raise RuntimeError("planes_nhwc must be [N,3,H,W,32]; ray_origins / ray_directions [N,R,3]")
+        raise RuntimeError("planes_nhwc must be [N,3,H,W,32] (or [1,...] shared by all views); ray_origins / ray_directions [N,R,3]")
     R = rays_o.shape[1]
     Sc, Sf = opts.Sc, opts.Sf
     if jitter.numel() != N * R * Sc:

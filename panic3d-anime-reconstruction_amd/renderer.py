@@ -39,7 +39,11 @@ class ImportanceRenderer(torch.nn.Module):
         ref, version, cached = self._planes_cache
         if ref is not None and ref() is planes and version == planes._version:
             return cached
-        cached = ops.planes_to_nhwc(planes)
+        if planes.dim() == 5 and planes.shape[0] > 1 and planes.stride(0) == 0:
+            planes_src = planes[:1]  # planes.expand(N, ...): one subject, N views -> one shared channels-last copy
+        else:
+            planes_src = planes
+        cached = ops.planes_to_nhwc(planes_src)
         self._planes_cache = (weakref.ref(planes), planes._version, cached)
         return cached
 

@@ -269,3 +269,33 @@ def test_renderer_plane_cache_is_not_fooled_by_reused_storage(hip):
         assert torch.equal(same, outs[-1][0])
         del planes
     assert not torch.equal(outs[0][0], outs[1][0])
+
+
+def test_shared_planes_many_views_one_launch(hip, oracle):
+    """Many views of ONE subject in one launch (planes [1,...] shared by all ray batches, or planes.expand(N,...) through the
+    renderer class) == the same views rendered one by one, up to the depth clamp (global min/max is per CALL, ray_marcher.py:50)."""
+    g = T.load_golden("render_32x32_16p16.npz")
+    inp = T.golden_render_inputs(g)
+    planes1 = inp["planes"][:1]
+    opts = hip.ops.make_opts(inp["ro"], **inp["kw"])
+    mlp = hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"])
+    nhwc = hip.ops.planes_to_nhwc(dev(planes1))
+    o, d, jit, u = dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"])
+    both = hip.ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=32)
+    ref = oracle.render(np.concatenate([planes1, planes1]), inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
+                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]))
+    for a, b in zip(both, ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+    # through the class with planes.expand (what training/triplane.py would pass for several views of one subject)
+    class FC:
+        def __init__(self, w, b, i):
+            self.weight, self.bias, self.weight_gain, self.bias_gain = w, b, inp["lr_mul"] / np.sqrt(i), inp["lr_mul"]
+    class Dec:
+        force_sigmoid = bool(inp["kw"]["force_sigmoid"])
+    raw = [dev(x) for x in inp["raw_mlp"]]
+    Dec.net = [FC(raw[0], raw[1], 32), None, FC(raw[2], raw[3], 64)]
+    r = hip.ImportanceRenderer(use_triplane=bool(inp["ro"]["use_triplane"]))
+    kw = {k: v for k, v in inp["kw"].items() if k != "force_sigmoid"}
+    out = r(dev(planes1).expand(2, -1, -1, -1, -1), Dec(), o, d, inp["ro"], jitter=jit, u=u, **kw)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.cpu().numpy(), b)

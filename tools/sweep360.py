@@ -15,6 +15,7 @@ import numpy as np, torch, torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=120)
 ap.add_argument("--res", type=int, default=512)
+ap.add_argument("--batch", type=int, default=1, help="views per launch (planes shared by the batch: P3D_FLAG_SHARED_PLANES)")
 a = ap.parse_args()
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(lrank)
@@ -43,12 +44,18 @@ with torch.no_grad():
         planes = G.synthesis(ws, {}, noise_mode="const").view(1, 3, 32, 256, 256) * 4.0
         return ops.planes_to_nhwc(planes.contiguous())
 
-    def render_one(v):
-        o, d = cameras.rays_from_label(labels[v:v + 1], res)
-        jit = torch.rand((1, R, 48, 1), device=dev)
-        u = torch.rand((R, 48), device=dev)
-        feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
+    def render_one(v, n=1):
+        o, d = cameras.rays_from_label(labels[v:v + n], res)
+        jit = torch.rand((n, R, 48, 1), device=dev)
+        u = torch.rand((n * R, 48), device=dev)
+        feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)  # nhwc is [1,...]: shared by the n views
         return feat, wsum
+
+    def render_local_batched():
+        lo, hi = sharding.partition(a.views, world, rank)
+        fr = [sharding.frames_rgba(*render_one(v, min(a.batch, hi - v)), res) for v in range(lo, hi, a.batch)]
+        counts = [sharding.partition(a.views, world, r)[1] - sharding.partition(a.views, world, r)[0] for r in range(world)]
+        return sharding.gather_frames(torch.cat(fr), counts, 0)
 
     nhwc = synth()
     render_one(0)  # warm-up
@@ -57,14 +64,14 @@ with torch.no_grad():
         dist.barrier()
     t0 = time.perf_counter()
     nhwc = synth()
-    frames = sharding.render_views_sharded(render_one, a.views, res, dst=0)
+    frames = sharding.render_views_sharded(render_one, a.views, res, dst=0) if a.batch == 1 else render_local_batched()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     dt = time.perf_counter() - t0
 if rank == 0:
     assert frames.shape == (a.views, 4, res, res)
-    print(json.dumps({"config": "c4", "views": a.views, "res": res, "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
+    print(json.dumps({"config": "c4", "views": a.views, "res": res, "batch": a.batch, "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
                       "rays_per_s": a.views * R / dt, "alpha_mean": float(frames[:, 3].mean())}))
 if dist.is_initialized():
     dist.destroy_process_group()
