@@ -154,6 +154,24 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
 int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64_t inner, int act, float alpha, float gain,
                      float clamp, float* y, void* stream);
 
+/* ---- iso-surface of the density grid on the device ---------------------------------------------------- */
+
+/* Replaces skimage.measure.marching_cubes(vol, level, spacing=(1,1,1), gradient_direction='descent', method='lewiner') as
+ * called by _util/eg3d_metrics3d.py:186-210 (generate.py:98-103).  Specification: oracle/p3d_oracle_mc.c (triangulation of
+ * ambiguous cubes, vertex / face order and degenerate handling differ from Lewiner's; see that header), case table
+ * include/p3d_mc_table.h.  vol [n][n][n] f32 in (axis0, axis1, axis2) order; flip0 != 0 reads axis 0 reversed, i.e. takes
+ * the flat `densities` of p3d_grid_density_f32 directly (the reference flips that axis, eg3d_metrics3d.py:166-168).
+ * Two calls because the caller owns the output buffers:
+ *   p3d_mc_count_f32  classifies + scans; out_counts (DEVICE uint64[2]) = {#vertices, #triangles}
+ *   p3d_mc_emit_f32   with the SAME vol / n / flip0 / level / workspace: out_verts [V][3] (index space), out_normals [V][3]
+ *                     (unit, towards lower values), out_values [V] (max of the edge's end points), out_faces [F][3] int32.
+ * workspace: 16-byte aligned, p3d_mc_workspace_bytes(n) bytes (4 B per grid point + block sums); 2 <= n <= 1024. */
+size_t p3d_mc_workspace_bytes(int n);
+int p3d_mc_count_f32(const float* vol, int n, int flip0, float level, void* workspace, size_t workspace_bytes,
+                     uint64_t* out_counts, void* stream);
+int p3d_mc_emit_f32(const float* vol, int n, int flip0, float level, void* workspace, size_t workspace_bytes, int64_t nverts,
+                    int64_t ntris, float* out_verts, float* out_normals, float* out_values, int32_t* out_faces, void* stream);
+
 /* Library / build identification ("gfx950"). */
 const char* p3d_build_info(void);
 

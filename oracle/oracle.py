@@ -17,8 +17,9 @@ FLAG_CROP, FLAG_CULL, FLAG_BINARIZE, FLAG_FORCE_SIGMOID, FLAG_WHITE_BACK = 1, 2,
 
 def build(force=False):
     so = os.path.join(_HERE, "libp3d_oracle.so")
-    src = os.path.join(_HERE, "p3d_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "p3d_oracle.c"), os.path.join(_HERE, "p3d_oracle_mc.c"),
+            os.path.join(_HERE, "..", "include", "p3d_numerics.h"), os.path.join(_HERE, "..", "include", "p3d_mc_table.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
@@ -27,8 +28,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libp3d_oracle.so")
-        if not os.path.exists(so):
-            build()
+        build()
         _LIB = C.CDLL(so)
     return _LIB
 
@@ -206,3 +206,20 @@ def math_fn(which, x):
     lib().p3d_oracle_math(px, C.c_long(x.size), {"exp": 0, "log1p01": 1, "softplus": 2, "sigmoid": 3}[which],
                           y.ctypes.data_as(C.c_void_p))
     return y
+
+
+def marching_cubes(vol, level=0.5, flip0=False):
+    """Iso-surface of vol [n,n,n] (p3d_oracle_mc.c): verts [V,3] in index space, faces [F,3] int32, normals [V,3], values [V]."""
+    vol, pv = _f(vol)
+    n = vol.shape[0]
+    assert vol.shape == (n, n, n)
+    cnt = np.zeros(2, dtype=np.int64)
+    lib().or_mc_count(pv, n, int(bool(flip0)), C.c_float(level), cnt.ctypes.data_as(C.c_void_p))
+    V, F = int(cnt[0]), int(cnt[1])
+    verts, normals, values = np.empty((V, 3), np.float32), np.empty((V, 3), np.float32), np.empty((V,), np.float32)
+    faces = np.empty((F, 3), np.int32)
+    rc = lib().or_mc_emit(pv, n, int(bool(flip0)), C.c_float(level), verts.ctypes.data_as(C.c_void_p),
+                          normals.ctypes.data_as(C.c_void_p), values.ctypes.data_as(C.c_void_p), faces.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"or_mc_emit failed: {rc}")
+    return verts, faces, normals, values

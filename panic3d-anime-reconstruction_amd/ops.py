@@ -150,6 +150,35 @@ def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, cr
     return (sigma, msk.bool()) if crop_limit is not None else sigma
 
 
+def marching_cubes(vol, level, flip0=False):
+    """Iso-surface of vol [n,n,n] (device, f32) at `level`, on the device (csrc/p3d_mcubes.hip; specification: DESIGN.md §4.5,
+    case table include/p3d_mc_table.h).  flip0: vol is the un-flipped flat grid of grid_density (axis 0 is read reversed).
+    Returns verts [V,3] (index space, axis 0/1/2 order), faces [F,3] int32, normals [V,3], values [V] — device tensors.
+    One 16-byte D2H read (the counts) sits between the two launches groups because the caller owns the output buffers."""
+    vol = _chk(vol, "vol")
+    n = vol.shape[0]
+    if vol.dim() != 3 or vol.shape != (n, n, n):
+        raise RuntimeError("vol must be [n,n,n]")
+    L = _lib.lib()
+    wsb = L.p3d_mc_workspace_bytes(n)
+    if wsb == 0:
+        raise RuntimeError("marching_cubes: n must be in [2, 1024]")
+    dev = vol.device
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.p3d_mc_count_f32(_p(vol), n, int(bool(flip0)), np.float32(level), _p(ws), wsb, _p(counts), _stream()),
+                   "p3d_mc_count_f32")
+        V, F = (int(x) for x in counts.tolist())
+        verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        normals = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        values = torch.empty((V,), dtype=torch.float32, device=dev)
+        faces = torch.empty((F, 3), dtype=torch.int32, device=dev)
+        _lib.check(L.p3d_mc_emit_f32(_p(vol), n, int(bool(flip0)), np.float32(level), _p(ws), wsb, V, F, _p(verts), _p(normals),
+                                     _p(values), _p(faces), _stream()), "p3d_mc_emit_f32")
+    return verts, faces, normals, values
+
+
 DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "inds", "depths_sorted", "sigma_sorted",
              "depth_unclamped", "tminmax")
 

@@ -15,13 +15,15 @@ from . import ops
 from .renderer import decoder_params
 
 
-def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None, lo=0, hi=None):
-    """Points [1, (hi-lo), 3] of the reference's N^3 grid, flat indices [lo, hi) (eg3d_metrics3d.py:70-92)."""
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None, lo=0, hi=None, idx=None):
+    """Points [1, (hi-lo), 3] of the reference's N^3 grid, flat indices [lo, hi) — or the explicit flat indices `idx` —
+    (eg3d_metrics3d.py:70-92)."""
     origin = np.array(voxel_origin) - cube_length / 2
     voxel_size = cube_length / (N - 1)
-    hi = N ** 3 if hi is None else hi
-    idx = torch.arange(lo, hi, 1, dtype=torch.long, device=device)
-    s = torch.zeros(hi - lo, 3, device=device)
+    if idx is None:
+        hi = N ** 3 if hi is None else hi
+        idx = torch.arange(lo, hi, 1, dtype=torch.long, device=device)
+    s = torch.zeros(idx.numel(), 3, device=idx.device)
     s[:, 2] = idx % N
     s[:, 1] = (idx.float() / N) % N
     s[:, 0] = ((idx.float() / N) / N) % N
@@ -83,3 +85,51 @@ def density_grid_sharded(G, ws, cond, resolution=256, dst=0, **kw):
         g = sharding.gather_frames(slabs, counts, dst)
         res[k] = g.reshape(1, -1, 1) if g is not None else None
     return res
+
+
+def marching_cubes(vol, rgbs, boxwarp, level=0.5, flip0=False):
+    """`_util/eg3d_metrics3d.py:186-210 marching_cubes(vol, rgbs, boxwarp, level)` with the surface extracted on the device.
+    vol [n,n,n] (device tensor; numpy is uploaded), rgbs: [>=3,n,n,n] tensor indexed like the reference does
+    (`rgbs[:3, a, b, c]` at `verts.astype(int)`), or a callable `rgbs(ijk[V,3] long) -> [V,3]`, or None.
+    Returns the reference's dict (verts scaled by /n*bw - bw/2 as eg3d_metrics3d.py:201-202 — sic, n not n-1; numpy
+    arrays).  The triangulation is this repo's, not Lewiner's."""
+    if not torch.is_tensor(vol):
+        vol = torch.as_tensor(np.ascontiguousarray(vol, dtype=np.float32)).cuda()
+    n = vol.shape[-1]
+    verts, faces, normals, values = ops.marching_cubes(vol.contiguous(), level, flip0=flip0)
+    out = {}
+    if rgbs is not None:
+        ijk = verts.long()  # .astype(int): truncation; coordinates are >= 0
+        if callable(rgbs):
+            colors = rgbs(ijk)
+        else:
+            colors = rgbs[:3, ijk[:, 0], ijk[:, 1], ijk[:, 2]].t()
+        out["colors"] = colors.cpu().numpy()
+    out["verts"] = (verts / n * boxwarp - 0.5 * boxwarp).cpu().numpy()
+    out["faces"] = faces.cpu().numpy()
+    out["normals"] = normals.cpu().numpy()
+    out["values"] = values.cpu().numpy()
+    return out
+
+
+def mesh(G, ws, cond, resolution=256, level=0.5, triplane_crop=None, cull_clouds=None, planes=None, **synthesis_kwargs):
+    """generate.py:97-103 (get_eg3d_volume + marching_cubes) without the volume leaving the GPU: density grid on the fused
+    decode kernel, surface extraction on the device, and the 32-channel colour grid of the reference (17 GB at 512^3, of
+    which three channels at the vertices' voxels are used) replaced by ONE decode of exactly those voxels."""
+    rk = G.rendering_kwargs
+    if planes is None:
+        planes = G._planes(ws, cond, **({"noise_mode": "const"} | synthesis_kwargs))
+    g = density_grid(G, ws, cond, resolution, triplane_crop=triplane_crop, cull_clouds=cull_clouds, planes=planes)
+    dens = g["densities"].reshape(resolution, resolution, resolution)
+    mlp, opts = decoder_params(G.decoder), G.renderer._opts(rk, G.decoder)
+    nhwc = G.renderer._nhwc(planes)
+
+    def colors(ijk):  # volume index (a,b,c) -> flat index of the un-flipped grid -> create_samples point -> decoder rgb
+        flat = ((resolution - 1 - ijk[:, 0]) * resolution + ijk[:, 1]) * resolution + ijk[:, 2]
+        pts, _, _ = create_samples(resolution, (0, 0, 0), rk["box_warp"], idx=flat)
+        if pts.shape[1] == 0:
+            return torch.empty((0, 3), device=flat.device)
+        _, rgb = ops.triplane_decode(nhwc, pts.contiguous(), mlp, opts)
+        return rgb[0, :, :3]
+
+    return marching_cubes(dens, colors, rk["box_warp"], level=level, flip0=True)

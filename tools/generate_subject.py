@@ -46,12 +46,17 @@ with torch.no_grad():
     x0 = {"elevations": torch.zeros(1, device=dev), "azimuths": torch.zeros(1, device=dev), "cond": cond, "seeds": [0], "noise_mode": "const",
           "triplane_crop": 0.1, "cull_clouds": 0.5}
     G.f(dict(x0))  # warm-up
+    volume.mesh(G, x0["ws"], cond, resolution=32, level=0.5, triplane_crop=0.1, cull_clouds=0.5)  # warm-up (module load, allocator)
     t0 = sync()
     out = G.f(x0)
     t1 = sync()
     vol = volume.density_grid(G, x0["ws"], cond, resolution=256, triplane_crop=0.1, cull_clouds=0.5)
     dens = volume.to_volume(vol["densities"], 256)
     t2 = sync()
+    level = 0.5  # generate.py:102
+    tm0 = sync()
+    mc = volume.mesh(G, x0["ws"], cond, resolution=256, level=level, triplane_crop=0.1, cull_clouds=0.5)  # generate.py:97-103 -> pkl dict
+    tm1 = sync()
     imgs = []
     for elev, azim, fov in views:
         xin = {"elevations": elev * torch.ones(1, device=dev), "azimuths": azim * torch.ones(1, device=dev),
@@ -67,7 +72,8 @@ with torch.no_grad():
         imgs2.append(G.f(xin)["image"])
     t4 = sync()
 assert all(i.shape == (1, 3, 512, 512) and torch.isfinite(i).all() for i in imgs) and dens.shape == (1, 1, 256, 256, 256)
-print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "views": len(views),
+print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "mesh_256_ms_incl_grid_and_d2h": (tm1 - tm0) * 1e3,
+                  "mesh_verts": len(mc["verts"]), "mesh_faces": len(mc["faces"]), "views": len(views),
                   "views_with_paste_ms": (t3 - t2) * 1e3, "ms_per_view": (t3 - t2) * 1e3 / len(views),
-                  "subject_total_ms": (t3 - t0) * 1e3, "ms_per_view_planes_cached": (t4 - t3) * 1e3 / len(views), "mean_alpha_last_view": float(o["image_weights"].mean()),
+                  "subject_total_ms": (t3 - t0 - (tm0 - t2)) * 1e3, "ms_per_view_planes_cached": (t4 - t3) * 1e3 / len(views), "mean_alpha_last_view": float(o["image_weights"].mean()),
                   "paste_mask_mean_last_view": float(o["paste"]["mask"].mean())}))
