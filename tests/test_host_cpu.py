@@ -181,3 +181,30 @@ def test_create_samples_matches_reference_formula(P):
     assert torch.equal(full[0], ref)
     parts = [P.volume.create_samples(N, cube_length=L, lo=a, hi=b)[0] for a, b in ((0, 500), (500, 1000), (1000, N ** 3))]
     assert torch.equal(torch.cat(parts, dim=1), full)
+
+
+def test_outputs_png_and_pkl_formats(tmp_path):
+    """generate.py's on-disk outputs: PNG quantisation = clamp, x255, truncate (twodee_v1.py:184-185 via torchvision's
+    to_pil_image); xyza composition (generate.py:143-146); mesh pickle keys (eg3d_metrics3d.py:203-209)."""
+    import pickle
+    from PIL import Image
+    from panic3d_amd import outputs
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 8, 6, generator=g) * 1.4 - 0.2
+    q = outputs.to_uint8_hwc(img)
+    ref = (img[0].clamp(0, 1) * 255).numpy().astype(np.uint8).transpose(1, 2, 0)  # truncation, not rounding
+    assert q.shape == (8, 6, 3) and np.array_equal(q, ref) and q.min() == 0 and q.max() == 255
+    out = {"image": img, "image_xyz": torch.rand(1, 3, 8, 6, generator=g) * 0.7 - 0.35, "image_weights": torch.rand(1, 1, 8, 6, generator=g)}
+    a, b = outputs.save_view(out, str(tmp_path / "v" / "front.png"), str(tmp_path / "v" / "front_xyza.png"), 0.7)
+    assert np.array_equal(np.asarray(Image.open(a)), ref)
+    x = np.asarray(Image.open(b))
+    assert x.shape == (8, 6, 4) and Image.open(b).mode == "RGBA"
+    exp = torch.cat([(out["image_xyz"] + 0.35) / 0.7, out["image_weights"]], 1)[0].clamp(0, 1).mul(255).to(torch.uint8).permute(1, 2, 0).numpy()
+    assert np.array_equal(x, exp)
+    mc = {"verts": np.zeros((3, 3), np.float32), "faces": np.array([[0, 1, 2]], np.int32), "normals": np.zeros((3, 3), np.float32),
+          "values": np.ones(3, np.float32), "colors": np.zeros((3, 3), np.float32)}
+    fn = outputs.dump_mesh(mc, str(tmp_path / "m" / "marching_cubes.pkl"))
+    back = pickle.load(open(fn, "rb"))
+    assert set(back) == {"verts", "faces", "normals", "values", "colors"} and back["faces"].dtype == np.int32
+    with pytest.raises(RuntimeError):
+        outputs.to_uint8_hwc(torch.zeros(2, 3, 4, 4))

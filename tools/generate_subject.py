@@ -71,6 +71,11 @@ with torch.no_grad():
                "cache_backbone": k == 0, "use_cached_backbone": k > 0, **opts}
         imgs2.append(G.f(xin)["image"])
     t4 = sync()
+if "--out" in sys.argv:  # the reference's per-subject files (generate.py:104-105,132-148)
+    from panic3d_amd import outputs
+    odn = sys.argv[sys.argv.index("--out") + 1]
+    outputs.dump_mesh(mc, f"{odn}/marching_cubes.pkl")
+    outputs.save_view(o, f"{odn}/rgb60_last.png", f"{odn}/xyza60_last.png", RK["box_warp"])
 assert all(i.shape == (1, 3, 512, 512) and torch.isfinite(i).all() for i in imgs) and dens.shape == (1, 1, 256, 256, 256)
 print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "mesh_256_ms_incl_grid_and_d2h": (tm1 - tm0) * 1e3,
                   "mesh_verts": len(mc["verts"]), "mesh_faces": len(mc["faces"]), "views": len(views),
