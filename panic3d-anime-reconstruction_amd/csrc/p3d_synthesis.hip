@@ -17,6 +17,7 @@
 //   k_bias_act        clamp(act(x + b) * gain)                                            (bias_act.py:93-122)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/panic3d_hip.h"
 
@@ -348,6 +349,256 @@ __global__ __launch_bounds__(256) void k_modconv_up(ConvParams p) {
     }
 }
 
+// =====================================================================================================================
+// v2 of the two 3x3 kernels: the f32 MFMA shares its SIMD with the VALU (tools/ubench/mfma_valu_overlap.hip), so the K loop is
+// written to contain ds_reads and MFMAs only:
+//   * staging goes through raw buffer loads: a per-thread byte offset computed ONCE (0x80000000 = padding / out of range ->
+//     the hardware returns 0, no exec-mask branches), the K-chunk advance lives in the SCALAR base of the buffer resource and
+//     the channel tail in its num_records; weights are fetched along the contiguous k axis (thread = output channel x k
+//     quarter), so global and LDS addresses are affine in the unrolled index (instruction immediates);
+//   * k pairs of one MFMA are (channel 2c, tap t) on lanes 0-31 and (channel 2c+1, same tap) on lanes 32-63: both LDS operand
+//     addresses become lane base + immediate;
+//   * LDS is double buffered: the next chunk is stored while the other buffer is read -> ONE barrier per chunk; with the plan
+//     registers gone three workgroups fit a CU (k_modconv2) / two instead of one (k_modconv_up2).
+// =====================================================================================================================
+#define CONV_OOB ((int)0x80000000)
+#define CONV_RSRC_FLAGS 0x00020000
+
+struct ConvStagePlan {
+    int xoff[6];  // byte offset of staged patch value u inside the chunk-relative image slice (CONV_OOB = zero)
+    int soff[6];  // byte offset of its style inside the chunk-relative style slice
+    int woff;     // byte offset of this thread's first weight inside the chunk-relative weight tensor
+};
+
+template <int NT>
+DEV ConvStagePlan conv_plan(const ConvParams& p, int tid, int gy0, int gx0, int o0) {
+    ConvStagePlan s;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int idx = tid + u * 256;
+        const int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
+        const int r = rem / XS_ROW, c = rem - r * XS_ROW;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        const bool ok = idx < 8 * XS_PLANE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        s.xoff[u] = ok ? ((ic * p.H + iy) * p.W + ix) * 4 : CONV_OOB;
+        s.soff[u] = ok ? ic * 4 : CONV_OOB;
+    }
+    const int wo = tid >> 2, kq = tid & 3;
+    s.woff = (o0 + wo < p.O) ? ((o0 + wo) * p.I * NT + kq * (2 * NT)) * 4 : CONV_OOB;
+    return s;
+}
+
+// registers of one staged chunk (8 input channels): 6 patch values + their styles, 2*NT weights (k = kq*2*NT .. +2*NT-1 of row wo)
+template <int NT>
+struct ConvStageRegs { float x[6], s[6], w[2 * NT]; };
+
+template <int NT>
+DEV void conv_gload(const ConvParams& p, const ConvStagePlan& pl, const float* xn, const float* sn, int ic0, int ic_end,
+                    ConvStageRegs<NT>& r) {
+    const int HW = p.H * p.W;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, (ic_end - ic0) * HW * 4, CONV_RSRC_FLAGS);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, (ic_end - ic0) * 4, CONV_RSRC_FLAGS);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)ic0 * NT), 0, (p.O * p.I - ic0) * NT * 4, CONV_RSRC_FLAGS);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        r.x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, pl.xoff[u], 0, 0));
+        r.s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pl.soff[u], 0, 0));
+    }
+    // (dword loads: __builtin_amdgcn_raw_buffer_load_b64 of this toolchain returns its first dword twice — seen in the ISA)
+#pragma unroll
+    for (int v = 0; v < 2 * NT; ++v) r.w[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, pl.woff, 4 * v, 0));
+}
+
+template <int NT>
+DEV void conv_lstore(float* xs, float* ws, int tid, const ConvStageRegs<NT>& r, int klim /* valid k of this chunk */) {
+    constexpr int WROW = 65;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) xs[tid + u * 256] = r.s[u] * r.x[u];
+    const int wo = tid >> 2, kq = tid & 3;
+    float* wd = ws + (kq * 2 * NT) * WROW + wo;
+    if (klim >= 8 * NT) {
+#pragma unroll
+        for (int v = 0; v < 2 * NT; ++v) wd[v * WROW] = r.w[v];
+    } else {  // channel tail (I not a multiple of 8): k beyond the last channel contributes 0
+#pragma unroll
+        for (int v = 0; v < 2 * NT; ++v) wd[v * WROW] = (kq * 2 * NT + v < klim) ? r.w[v] : 0.0f;
+    }
+}
+
+#define CONV_XSZ (6 * 256)  // staged patch values per buffer (8 * XS_PLANE = 1440, padded to the 6 x 256 store pattern)
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_modconv2(ConvParams p) {
+    using T = ConvTaps<MODE>;
+    constexpr int NT = T::N, KC = 8 * NT, NB = CONV_TH / 4, WROW = 65;
+    __shared__ float xs[2][CONV_XSZ];
+    __shared__ float ws[2][KC * WROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int prow0 = (CONV_TH / 2) * wp + (j >> 4), pcol = j & 15;
+    // lane bases of the two LDS operands: this lane's pixel (+ the halo origin) and its k half
+    const int xlane = (prow0 + 1) * XS_ROW + pcol + 1 + half * XS_PLANE;
+    const int wlane = wc * 32 + j + half * NT * WROW;
+
+    const ConvStagePlan pl = conv_plan<NT>(p, tid, gy0, gx0, o0);
+    ConvStageRegs<NT> rg;
+    conv_gload<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore<NT>(xs[0], ws[0], tid, rg, (ic_end - ic_beg) * NT);
+    __syncthreads();
+    int buf = 0;
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 8) {
+        const bool more = ic0 + 8 < ic_end;
+        if (more) conv_gload<NT>(p, pl, xn, sn, ic0 + 8, ic_end, rg);  // in flight during this chunk's MFMAs
+        const float* xb = xs[buf] + xlane;
+        const float* wb = ws[buf] + wlane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float av = wb[((2 * c) * NT + t) * WROW];
+                float bv[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) bv[b] = xb[(2 * c) * XS_PLANE + T::dy[t] * XS_ROW + T::dx[t] + 2 * b * XS_ROW];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[b], acc[b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the operand reads at most one channel pair ahead of their MFMAs
+        }
+        // the stores wait for the prefetched chunk: they must stay BEHIND the MFMAs (the scheduler would hoist them, and
+        // their vmcnt waits, to the top of the MFMA phase)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) conv_lstore<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, rg, (ic_end - ic0 - 8) * NT);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- epilogue (ksplit > 1: raw partial sums into slice kz of the partial buffer)
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+        if (gy >= p.GH || gx >= p.GW) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ch >= p.O) continue;
+            float v = acc[t][r];
+            if (p.epilogue) {
+                if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
+                if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)gy * p.OW + gx];
+                if (p.bias) v = v + p.bias[ch];
+                v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+            }
+            yout[(((size_t)n * p.O + ch) * p.OH + gy) * p.OW + gx] = v;
+        }
+    }
+}
+
+// k_modconv_up on the same staging (see k_modconv_up for the phase decomposition)
+__global__ __launch_bounds__(256, 2) void k_modconv_up2(ConvParams p) {
+    constexpr int NT = 9, KC = 72, WROW = 65;
+    __shared__ float xs[2][CONV_XSZ];
+    __shared__ float ws[2][KC * WROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[4][2];  // [phase = 2*py + px][N tile]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
+    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
+    const int xlane = (prow0 + 1) * XS_ROW + pcol + 1 + half * XS_PLANE;
+    const int wlane = wc * 32 + j + half * NT * WROW;
+
+    const ConvStagePlan pl = conv_plan<NT>(p, tid, gy0, gx0, o0);
+    ConvStageRegs<NT> rg;
+    conv_gload<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore<NT>(xs[0], ws[0], tid, rg, (ic_end - ic_beg) * NT);
+    __syncthreads();
+    int buf = 0;
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 8) {
+        const bool more = ic0 + 8 < ic_end;
+        if (more) conv_gload<NT>(p, pl, xn, sn, ic0 + 8, ic_end, rg);
+        const float* xb = xs[buf] + xlane;
+        const float* wb = ws[buf] + wlane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* xp = xb + (2 * c) * XS_PLANE;
+            const float* wr = wb + (2 * c) * NT * WROW;
+            // the four input values per N tile: [dy][dx] with dy, dx in {0, -1}; N tile 1 is two rows below
+            float b00[2], b01[2], b10[2], b11[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b00[t] = xp[2 * t * XS_ROW]; b01[t] = xp[2 * t * XS_ROW - 1];
+                b10[t] = xp[2 * t * XS_ROW - XS_ROW]; b11[t] = xp[2 * t * XS_ROW - XS_ROW - 1];
+            }
+            float a[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a[t] = wr[t * WROW];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b00[t], acc[0][t], 0, 0, 0);  // phase (0,0): taps (0,0) (0,2) (2,0) (2,2)
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b00[t], acc[1][t], 0, 0, 0);  // phase (0,1): taps (0,1) (2,1)
+                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b00[t], acc[2][t], 0, 0, 0);  // phase (1,0): taps (1,0) (1,2)
+                acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], b00[t], acc[3][t], 0, 0, 0);  // phase (1,1): tap (1,1)
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b01[t], acc[0][t], 0, 0, 0);
+                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], b01[t], acc[2][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], b10[t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], b10[t], acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], b11[t], acc[0][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the stores wait for the prefetched chunk: they must stay BEHIND the MFMAs (the scheduler would hoist them, and
+        // their vmcnt waits, to the top of the MFMA phase)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) conv_lstore<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, rg, (ic_end - ic0 - 8) * NT);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- raw store of the four phases (ksplit > 1: into slice kz of the partial buffer); the FIR pass applies the epilogue
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+            if (gy > p.H - py || gx > p.W - px) continue;
+            const int oy = 2 * gy + py, ox = 2 * gx + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
+            }
+        }
+    }
+}
+
 // sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
 struct ReduceParams {
     const float* part; float* y; const float* dcoef; const float* noise; const float* bias;
@@ -512,8 +763,18 @@ static inline int chk() {
 // 128->128 @512^2: 69 vs 67 TF), so 8 is used everywhere.
 static int conv_th(int N, int O, int GH, int GW) { (void)N; (void)O; (void)GH; (void)GW; return 8; }
 
+static bool conv_v1() {
+    static const bool v = getenv("P3D_CONV_V1") != nullptr;  // development A/B switch
+    return v;
+}
+
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
+    if (!conv_v1()) {
+        dim3 g2(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+        hipLaunchKernelGGL((k_modconv2<MODE>), g2, dim3(256), 0, st, p);
+        return;
+    }
     const int th = conv_th(p.N, p.O, p.GH, p.GW);
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + th - 1) / th), (p.O + 63) / 64, p.N * p.ksplit);
     if (th == 16) hipLaunchKernelGGL((k_modconv<MODE, 64, 16>), grid, dim3(256), 0, st, p);
@@ -572,7 +833,8 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
+        if (conv_v1()) hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_modconv_up2, grid, dim3(256), 0, st, p);
     }
     if (ksplit > 1) {
         ReduceParams r;
