@@ -3,7 +3,8 @@
 //   k_modconv<MODE>   modulated convolution as an implicit GEMM on the matrix cores (v_mfma_f32_32x32x2_f32; exact f32):
 //                     D[o][pixel] = sum_k W[o][k] * (s[n,i(k)] * x[n,i(k),y+dy(k),x+dx(k)])
 //                     A = weights (LDS tile [k][64 o]), B = modulated input patch (LDS tile [8 ic][10][18] with halo),
-//                     4 waves = 2 (32-channel halves) x 2 (64-pixel halves), 2 accumulators per wave.
+//                     4 waves = 2 (32-channel halves) x 2 (64-pixel halves), 2 accumulators per wave; K loop = ds_reads + MFMAs
+//                     only, double-buffered LDS (see the comment above the kernels).
 //                     MODE 0: 3x3 / pad 1 correlation   (conv1 of every block, networks_stylegan2.py:93 -> conv2d_resample.py:136)
 //                     MODE 1: 1x1                       (ToRGB, networks_stylegan2.py:378)
 //   k_modconv_up      the stride-2 transposed 3x3 conv of the up-sampling layer (conv0, conv2d_resample.py:114-127): the four
@@ -28,12 +29,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CONV_TW 16
 #define XS_ROW (CONV_TW + 2)
 #define XS_PLANE ((CONV_TH + 2) * XS_ROW)
-// input channels staged per K chunk: ConvTaps<MODE>::IC, chosen so that a chunk holds 64-72 k values (MFMA work per staging round)
-
+// a K chunk = 8 input channels (72 k values for 3x3, 8 for 1x1)
 template <int MODE> struct ConvTaps;
-// dy, dx: input offset relative to the output grid position; kidx: index into the 3x3 kernel (ky*3+kx)
-template <> struct ConvTaps<0> { static constexpr int IC = 8; static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; static constexpr int kidx[9] = {0,1,2,3,4,5,6,7,8}; static constexpr int py = 0, px = 0, ostride = 1; };
-template <> struct ConvTaps<1> { static constexpr int IC = 8; static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; static constexpr int kidx[1] = {0}; static constexpr int py = 0, px = 0, ostride = 1; };
+// N taps; dy, dx: input offset of tap t relative to the output position (tap t is element ky*3+kx of the 3x3 kernel)
+template <> struct ConvTaps<0> { static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; };
+template <> struct ConvTaps<1> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; };
 
 struct ConvParams {
     const float* x;       // [N][I][H][W]
@@ -61,296 +61,8 @@ DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
     return v;
 }
 
-// OT: output channels per workgroup (64: one 32-channel A tile per wave, 128: two).  TH: pixel-tile rows (8 or 16; 16 columns):
-// every wave owns TH/2 rows = TH/4 N tiles of 32 pixels.  Per k pair a wave issues OT/64 A reads, TH/4 B reads and
-// (OT/64)*(TH/4) MFMAs; a bigger tile amortises the staging round and its two barriers over more MFMA work.
-template <int MODE, int OT, int TH>
-__global__ __launch_bounds__(256) void k_modconv(ConvParams p) {
-    using T = ConvTaps<MODE>;
-    constexpr int NT = T::N;
-    constexpr int CONV_IC = T::IC;
-    constexpr int KC = CONV_IC * NT;  // k values per chunk
-    constexpr int NA = OT / 64;       // A tiles per wave
-    constexpr int NB = TH / 4;        // N tiles per wave
-    constexpr int WROW = OT + 1;
-    constexpr int XPL = (TH + 2) * XS_ROW;  // patch plane: (TH+2) x 18
-    constexpr int XN = (CONV_IC * XPL + 255) / 256, WN = (KC * OT + 255) / 256;  // staged values per thread
-    __shared__ float xs[CONV_IC * XPL];
-    __shared__ float ws[KC * WROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
-    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
-    const int gy0 = (blockIdx.x / tiles_x) * TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
-    const int o0 = blockIdx.y * OT;
-    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;  // split-K slice of the input channels
-    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;  // multiple of every mode's IC
-    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
-    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
-    const float* sn = p.styles + (size_t)n * p.I;
-    const int kk9 = p.ks * p.ks;
-
-    f32x16 acc[NA][NB];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
-    // this lane's pixel inside the tile for N tile t: row (TH/2)*wp + 2t + (j>>4), col j & 15
-    const int prow0 = (TH / 2) * wp + (j >> 4), pcol = j & 15;
-    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;  // N tile 0 (halo origin at +1,+1); tile t is 2t rows below
-    const int wcol = wc * (OT / 2) + j;
-
-    float xr[XN], wr[WN];
-    // Staging plan of this thread, computed ONCE (the f32 MFMA shares its SIMD with the VALU, so every index instruction in
-    // the K loop is paid in MFMA time): per staged value the element offset inside the chunk-relative source and the LDS slot.
-    int xsrc[XN], wsrc[WN], wdst[WN];  // -1 = padding / out of range; source offsets carry the chunk-local channel in bits 24+
-#pragma unroll
-    for (int u = 0; u < XN; ++u) {
-        int idx = tid + u * 256;
-        int ic = idx / XPL, rem = idx - ic * XPL;
-        int r = rem / XS_ROW, c = rem - r * XS_ROW;
-        int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
-        bool ok = idx < CONV_IC * XPL && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        xsrc[u] = ok ? (((ic * p.H + iy) * p.W + ix) | (ic << 24)) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < WN; ++u) {
-        int idx = tid + u * 256;
-        int o = idx / KC, k = idx - o * KC;
-        int ic = k / NT, t = k - ic * NT;
-        bool ok = idx < KC * OT && o0 + o < p.O;
-        wsrc[u] = ok ? ((((o0 + o) * p.I + ic) * kk9 + (p.ks == 1 ? 0 : T::kidx[t])) | (ic << 24)) : -1;
-        wdst[u] = idx < KC * OT ? k * WROW + o : -1;
-    }
-    const int HW = p.H * p.W;
-    // global -> registers: modulated input patch s[n,ic] * x[n,ic,gy0-1+r,gx0-1+c] (zero outside) and the weight slice
-    auto gload = [&](int ic0) {
-        const float* xb = xn + (size_t)ic0 * HW;
-        const float* wb = p.w + (size_t)ic0 * kk9;
-#pragma unroll
-        for (int u = 0; u < XN; ++u) {
-            float v = 0.0f;
-            const int ch = ic0 + (xsrc[u] >> 24);
-            if (xsrc[u] >= 0 && ch < ic_end) v = sn[ch] * xb[xsrc[u] & 0xffffff];
-            xr[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            float v = 0.0f;
-            if (wsrc[u] >= 0 && ic0 + (wsrc[u] >> 24) < ic_end) v = wb[wsrc[u] & 0xffffff];
-            wr[u] = v;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int u = 0; u < XN; ++u) {
-            int idx = tid + u * 256;
-            if (idx < CONV_IC * XPL) xs[idx] = xr[u];
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u)
-            if (wdst[u] >= 0) ws[wdst[u]] = wr[u];
-    };
-    gload(ic_beg);
-    lstore();
-    __syncthreads();
-    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += CONV_IC) {
-        const bool more = ic0 + CONV_IC < ic_end;
-        if (more) gload(ic0 + CONV_IC);  // next chunk's global loads are in flight during this chunk's MFMAs
-#pragma unroll
-        for (int q = 0; q < KC / 2; ++q) {
-            // lanes 0-31 take k = 2q, lanes 32-63 take k = 2q+1  (A[i][k], B[k][j] operand layout of 32x32x2)
-            const int k0 = 2 * q, k1 = 2 * q + 1;
-            const int xo0 = (k0 / NT) * XPL + T::dy[k0 % NT] * XS_ROW + T::dx[k0 % NT];
-            const int xo1 = (k1 / NT) * XPL + T::dy[k1 % NT] * XS_ROW + T::dx[k1 % NT];
-            const int xo = half ? xo1 : xo0;
-            const int kk = half ? k1 : k0;
-            float bv[NB];
-#pragma unroll
-            for (int t = 0; t < NB; ++t) bv[t] = xs[xo + pix0 + 2 * t * XS_ROW];
-#pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                float av = ws[kk * WROW + wcol + 32 * a];
-#pragma unroll
-                for (int t = 0; t < NB; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[a][t], 0, 0, 0);
-            }
-            // keep the LDS operand reads at most 4 steps ahead of their MFMAs (hoisting all reads costs ~100 VGPRs)
-            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        if (more) lstore();
-        __syncthreads();
-    }
-    // ---- epilogue (ksplit > 1: raw partial sums into slice kz of the partial buffer)
-    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
-        if (gy >= p.GH || gx >= p.GW) continue;
-        const int oy = gy * T::ostride + T::py, ox = gx * T::ostride + T::px;
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = o0 + wc * (OT / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch >= p.O) continue;
-                float v = acc[a][t][r];
-                if (p.epilogue) {
-                    if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
-                    if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)oy * p.OW + ox];
-                    if (p.bias) v = v + p.bias[ch];
-                    v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
-                }
-                yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = v;
-            }
-    }
-}
-
-// Stride-2 transposed 3x3 convolution with ALL FOUR output phases in one workgroup (conv0 of every block,
-// conv2d_resample.py:114-127).  T[o][2y+py][2x+px] = sum_i sum_{ky == py, kx == px (mod 2)} w[o][i][ky][kx] * x[i][y - ky/2][x - kx/2]:
-// the four phases read the same four input values x[y][x], x[y][x-1], x[y-1][x], x[y-1][x-1] with disjoint subsets of the 9 taps
-// (4 / 2 / 2 / 1).  One staging round (8 input channels: the 10x18 input patch and the [72][64] weight slice, exactly the
-// MODE 0 tiles) feeds 9 MFMAs per input-channel pair and N tile instead of 4 / 2 / 2 / 1 in four separate launches.
-// Grid positions: (H+1) x (W+1); 8 accumulators per wave (4 phases x 2 N tiles of 32 positions).  k pairs = two input channels.
-__global__ __launch_bounds__(256) void k_modconv_up(ConvParams p) {
-    constexpr int CONV_IC = 8, NT = 9, KC = CONV_IC * NT, OT = 64, WROW = OT + 1;
-    constexpr int XN = (CONV_IC * XS_PLANE + 255) / 256, WN = (KC * OT + 255) / 256;
-    __shared__ float xs[CONV_IC * XS_PLANE];
-    __shared__ float ws[KC * WROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
-    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
-    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
-    const int o0 = blockIdx.y * OT;
-    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
-    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
-    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
-    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
-    const float* sn = p.styles + (size_t)n * p.I;
-
-    f32x16 acc[4][2];  // [phase = 2*py + px][N tile]
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
-    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
-    const int pix0 = (prow0 + 1) * XS_ROW + pcol + 1;
-    const int pix1 = pix0 + 2 * XS_ROW;
-    const int wcol = wc * 32 + j;
-
-    float xr[XN], wr[WN];
-    // staging plan computed once (see k_modconv): source offsets carry the chunk-local channel in bits 24+; -1 = padding
-    int xsrc[XN], wsrc[WN], wdst[WN];
-#pragma unroll
-    for (int u = 0; u < XN; ++u) {
-        int idx = tid + u * 256;
-        int ic = idx / XS_PLANE, rem = idx - ic * XS_PLANE;
-        int r = rem / XS_ROW, c = rem - r * XS_ROW;
-        int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
-        bool ok = idx < CONV_IC * XS_PLANE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        xsrc[u] = ok ? (((ic * p.H + iy) * p.W + ix) | (ic << 24)) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < WN; ++u) {
-        int idx = tid + u * 256;
-        int o = idx / KC, k = idx - o * KC;  // k = ic*9 + (ky*3+kx): contiguous in memory
-        bool ok = idx < KC * OT && o0 + o < p.O;
-        wsrc[u] = ok ? (((o0 + o) * p.I * 9 + k) | ((k / NT) << 24)) : -1;
-        wdst[u] = idx < KC * OT ? k * WROW + o : -1;
-    }
-    const int HW = p.H * p.W;
-    auto gload = [&](int ic0) {
-        const float* xb = xn + (size_t)ic0 * HW;
-        const float* wb = p.w + (size_t)ic0 * 9;
-#pragma unroll
-        for (int u = 0; u < XN; ++u) {
-            float v = 0.0f;
-            const int ch = ic0 + (xsrc[u] >> 24);
-            if (xsrc[u] >= 0 && ch < ic_end) v = sn[ch] * xb[xsrc[u] & 0xffffff];
-            xr[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            float v = 0.0f;
-            if (wsrc[u] >= 0 && ic0 + (wsrc[u] >> 24) < ic_end) v = wb[wsrc[u] & 0xffffff];
-            wr[u] = v;
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int u = 0; u < XN; ++u) {
-            int idx = tid + u * 256;
-            if (idx < CONV_IC * XS_PLANE) xs[idx] = xr[u];
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u)
-            if (wdst[u] >= 0) ws[wdst[u]] = wr[u];
-    };
-    gload(ic_beg);
-    lstore();
-    __syncthreads();
-    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += CONV_IC) {
-        const bool more = ic0 + CONV_IC < ic_end;
-        if (more) gload(ic0 + CONV_IC);
-#pragma unroll
-        for (int q = 0; q < CONV_IC / 2; ++q) {
-            // this lane's input channel of the pair: lanes 0-31 -> 2q, lanes 32-63 -> 2q+1
-            const int icl = 2 * q + half;
-            const float* xp = xs + icl * XS_PLANE;
-            const float* wrow = ws + (icl * NT) * WROW + wcol;
-            // the four input values per N tile: [dy][dx] with dy, dx in {0, -1}
-            float b00[2], b01[2], b10[2], b11[2];
-            b00[0] = xp[pix0]; b01[0] = xp[pix0 - 1]; b10[0] = xp[pix0 - XS_ROW]; b11[0] = xp[pix0 - XS_ROW - 1];
-            b00[1] = xp[pix1]; b01[1] = xp[pix1 - 1]; b10[1] = xp[pix1 - XS_ROW]; b11[1] = xp[pix1 - XS_ROW - 1];
-            float a[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a[t] = wrow[t * WROW];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // phase (0,0): taps (0,0) (0,2) (2,0) (2,2)
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b00[t], acc[0][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b01[t], acc[0][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[6], b10[t], acc[0][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8], b11[t], acc[0][t], 0, 0, 0);
-                // phase (0,1): taps (0,1) (2,1)
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b00[t], acc[1][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[7], b10[t], acc[1][t], 0, 0, 0);
-                // phase (1,0): taps (1,0) (1,2)
-                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b00[t], acc[2][t], 0, 0, 0);
-                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[5], b01[t], acc[2][t], 0, 0, 0);
-                // phase (1,1): tap (1,1)
-                acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], b00[t], acc[3][t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        if (more) lstore();
-        __syncthreads();
-    }
-    // ---- raw store of the four phases (ksplit > 1: into slice kz of the partial buffer); the FIR pass applies the epilogue
-    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const int py = ph >> 1, px = ph & 1;
-            if (gy > p.H - py || gx > p.W - px) continue;  // phase grids: rows 0..H (py = 0) or 0..H-1 (py = 1)
-            const int oy = 2 * gy + py, ox = 2 * gx + px;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
-            }
-        }
-    }
-}
-
 // =====================================================================================================================
-// v2 of the two 3x3 kernels: the f32 MFMA shares its SIMD with the VALU (tools/ubench/mfma_valu_overlap.hip), so the K loop is
+// The convolution kernels.  The f32 MFMA shares its SIMD with the VALU (tools/ubench/mfma_valu_overlap.hip), so the K loop is
 // written to contain ds_reads and MFMAs only:
 //   * staging goes through raw buffer loads: a per-thread byte offset computed ONCE (0x80000000 = padding / out of range ->
 //     the hardware returns 0, no exec-mask branches), the K-chunk advance lives in the SCALAR base of the buffer resource and
@@ -359,7 +71,7 @@ __global__ __launch_bounds__(256) void k_modconv_up(ConvParams p) {
 //   * k pairs of one MFMA are (channel 2c, tap t) on lanes 0-31 and (channel 2c+1, same tap) on lanes 32-63: both LDS operand
 //     addresses become lane base + immediate;
 //   * LDS is double buffered: the next chunk is stored while the other buffer is read -> ONE barrier per chunk; with the plan
-//     registers gone three workgroups fit a CU (k_modconv2) / two instead of one (k_modconv_up2).
+//     registers gone three workgroups fit a CU (k_modconv) / two instead of one (k_modconv_up).
 // =====================================================================================================================
 #define CONV_OOB ((int)0x80000000)
 #define CONV_RSRC_FLAGS 0x00020000
@@ -428,7 +140,7 @@ DEV void conv_lstore(float* xs, float* ws, int tid, const ConvStageRegs<NT>& r, 
 #define CONV_XSZ (6 * 256)  // staged patch values per buffer (8 * XS_PLANE = 1440, padded to the 6 x 256 store pattern)
 
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void k_modconv2(ConvParams p) {
+__global__ __launch_bounds__(256, 3) void k_modconv(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N, KC = 8 * NT, NB = CONV_TH / 4, WROW = 65;
     __shared__ float xs[2][CONV_XSZ];
@@ -507,8 +219,13 @@ __global__ __launch_bounds__(256, 3) void k_modconv2(ConvParams p) {
     }
 }
 
-// k_modconv_up on the same staging (see k_modconv_up for the phase decomposition)
-__global__ __launch_bounds__(256, 2) void k_modconv_up2(ConvParams p) {
+// Stride-2 transposed 3x3 convolution with ALL FOUR output phases in one workgroup (conv0 of every block,
+// conv2d_resample.py:114-127).  T[o][2y+py][2x+px] = sum_i sum_{ky == py, kx == px (mod 2)} w[o][i][ky][kx] * x[i][y - ky/2][x - kx/2]:
+// the four phases read the same four input values x[y][x], x[y][x-1], x[y-1][x], x[y-1][x-1] with disjoint subsets of the 9 taps
+// (4 / 2 / 2 / 1).  One staging round (8 input channels: the 10x18 input patch and the [72][64] weight slice, exactly the
+// MODE 0 tiles) feeds 9 MFMAs per input-channel pair and N tile instead of 4 / 2 / 2 / 1 in four separate launches.
+// Grid positions: (H+1) x (W+1); 8 accumulators per wave (4 phases x 2 N tiles of 32 positions).  k pairs = two input channels.
+__global__ __launch_bounds__(256, 2) void k_modconv_up(ConvParams p) {
     constexpr int NT = 9, KC = 72, WROW = 65;
     __shared__ float xs[2][CONV_XSZ];
     __shared__ float ws[2][KC * WROW];
@@ -756,29 +473,12 @@ static inline int chk() {
     return e == hipSuccess ? P3D_OK : (int)e;
 }
 
-// (A 128-channel output tile — two A tiles per wave — measured SLOWER on MI355X at every generator shape, e.g. 256->256 @256^2:
-// 53 vs 66 TF: fewer, fatter workgroups.  OT stays 64.)
-
-// pixel-tile rows.  16-row tiles (4 N tiles per wave) measured no better than 8 on MI355X (256->256 @256^2: 58.7 vs 66 TF;
-// 128->128 @512^2: 69 vs 67 TF), so 8 is used everywhere.
-static int conv_th(int N, int O, int GH, int GW) { (void)N; (void)O; (void)GH; (void)GW; return 8; }
-
-static bool conv_v1() {
-    static const bool v = getenv("P3D_CONV_V1") != nullptr;  // development A/B switch
-    return v;
-}
-
+// Tile variants measured on MI355X and rejected (with the first version of these kernels): 128-channel output tiles (two A tiles
+// per wave; 256->256 @256^2: 53 vs 66 TF: fewer, fatter workgroups) and 16-row pixel tiles (58.7 vs 66 TF).
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
-    if (!conv_v1()) {
-        dim3 g2(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        hipLaunchKernelGGL((k_modconv2<MODE>), g2, dim3(256), 0, st, p);
-        return;
-    }
-    const int th = conv_th(p.N, p.O, p.GH, p.GW);
-    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + th - 1) / th), (p.O + 63) / 64, p.N * p.ksplit);
-    if (th == 16) hipLaunchKernelGGL((k_modconv<MODE, 64, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_modconv<MODE, 64, 8>), grid, dim3(256), 0, st, p);
+    dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+    hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
 }
 
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
@@ -833,8 +533,7 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (conv_v1()) hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(k_modconv_up2, grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
     if (ksplit > 1) {
         ReduceParams r;
