@@ -139,9 +139,9 @@ class TriPlaneGenerator(torch.nn.Module):
             ray_origins, ray_directions = cameras.perspective_rays(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
         elif isinstance(force_rays, dict):
             ro, rd = force_rays["ray_origins"], force_rays["ray_directions"]
-            assert ro.shape == rd.shape == (len(ws), 3, res, res)
-            ray_origins = ro.permute(0, 2, 3, 1).reshape(len(ws), res * res, 3)
-            ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ws), res * res, 3)
+            assert ro.shape == rd.shape and ro.shape[1:] == (3, res, res) and (len(ro) == len(ws) or len(ws) == 1)
+            ray_origins = ro.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
+            ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
         else:
             assert False, "force_rays not understood"
         N = ray_origins.shape[0]
@@ -151,6 +151,12 @@ class TriPlaneGenerator(torch.nn.Module):
             planes = self._planes(ws, cond, latent_injection, stop_level, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
+        if len(planes) == 1 and N > 1:
+            # extension: V views of ONE subject in one call (ws / cond of batch 1, V cameras).  The planes are synthesised once
+            # and shared by the V ray batches of a single renderer launch (P3D_FLAG_SHARED_PLANES); the reference would need
+            # ws and cond repeated V times and would run the backbone on V copies.
+            planes = planes.expand(N, -1, -1, -1, -1)
+            ws = ws.expand(N, -1, -1)
         draws = self._inject_draws or (None, None)
         if isinstance(draws, list):  # tests: one (jitter, u) pair per renderer pass, consumed in call order
             draws = draws.pop(0)
@@ -233,7 +239,13 @@ class TriPlaneGenerator(torch.nn.Module):
             x["force_rays"] = force_rays = {"ray_origins": ro, "ray_directions": rd}
         x["conditioning_params"] = x["camera_params"]
         if "ws" not in x:
-            x["ws"] = self.mapping_zplus(x["zs"], x["conditioning_params"], x["cond"], truncation_psi=truncation_psi,
+            cpm = x["conditioning_params"]
+            if len(x["zs"]) == 1 and len(cpm) > 1:  # V views of one subject in one call (see synthesis)
+                if not self.rendering_kwargs["c_gen_conditioning_zero"]:
+                    raise RuntimeError("many views per call need ws that do not depend on the camera: pass x['ws'] or use a "
+                                       "generator without pose conditioning (c_gen_conditioning_zero, PAniC-3D's default)")
+                cpm = cpm[:1]
+            x["ws"] = self.mapping_zplus(x["zs"], cpm, x["cond"], truncation_psi=truncation_psi,
                                          truncation_cutoff=truncation_cutoff)
         _ws = x["ws"]
         if latent_injection is not None:

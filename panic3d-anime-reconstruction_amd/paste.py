@@ -64,6 +64,8 @@ def paste_front(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02
         raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
     view_xyz = out["image_xyz"]
     front_rgb = x["cond"]["image_ortho_front"]
+    if len(front_rgb) == 1 and len(view_xyz) > 1:  # V views of one subject in one call (generator.synthesis)
+        front_rgb = front_rgb.expand(len(view_xyz), -1, -1, -1)
     S = front_rgb.shape[-1]
     with torch.no_grad():
         wmask = (F.interpolate(out["image_weights"], S, mode="bilinear") > thresh_weight).float()

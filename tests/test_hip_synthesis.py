@@ -230,3 +230,41 @@ def test_density_grid(hip):
         assert vol.shape == (1, 1, N, N, N)
         half = hip.volume.density_grid(G, ws, {}, resolution=N, lo=0, hi=N ** 3 // 2)
         assert torch.equal(half["sigmas"], out["sigmas"][:, :N ** 3 // 2])
+
+
+def test_f_many_views_of_one_subject_in_one_call(hip):
+    """Extension of the dict API: ws / cond of batch 1 with V cameras renders V views from ONE backbone pass and ONE fused
+    renderer launch (shared planes).  Equal to V separate f() calls on the same planes and random draws: renderer outputs
+    bit for bit (rays are independent; only the depth clamp is per call), super-resolved / pasted images to fp32 round-off
+    (the batch size changes the split-K choice of the small conv layers)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    V, res, S = 3, 16, 12
+    R = res * res
+    gen = torch.Generator().manual_seed(5)
+    draws = [(torch.rand(V, R, S, 1, generator=gen).cuda(), torch.rand(V * R, S, generator=gen).cuda()) for _ in range(2)]
+    front = torch.rand(1, 3, 512, 512, generator=gen).cuda()
+    el, az, fv = torch.tensor([0.0, 10.0, -5.0]).cuda(), torch.tensor([0.0, 40.0, 200.0]).cuda(), torch.tensor([-1.0, 30.0, 30.0]).cuda()
+    common = dict(seeds=[3], cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=res,
+                  noise_mode="const", paste_params={"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5,
+                                                    "offset_occ": 0.01, "thresh_dxyz": 0.05})
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):  # this fixture's generator is pose-conditioned: ws would differ per view
+            G.f(dict(common, elevations=el, azimuths=az, fovs=fv))
+        x0 = dict(common, elevations=el[:1], azimuths=az[:1], fovs=fv[:1], paste_params=None)
+        G.f(x0)
+        common["ws"] = x0["ws"]  # one subject: the same ws for every view
+        G._inject_draws = [tuple(d) for d in draws]
+        both = G.f(dict(common, elevations=el, azimuths=az, fovs=fv))
+        assert G._inject_draws == [] and both["image"].shape == (V, 3, 512, 512) and both["triplane"].shape[0] == V
+        for v in range(V):
+            G._inject_draws = [(j[v:v + 1].contiguous(), u[v * R:(v + 1) * R].contiguous()) for j, u in draws]
+            one = G.f(dict(common, elevations=el[v:v + 1], azimuths=az[v:v + 1], fovs=fv[v:v + 1]))
+            for k in ("image_raw", "image_weights", "image_xyz"):
+                assert torch.equal(both[k][v:v + 1], one[k]), (k, v)
+            assert (both["image_prepaste"][v:v + 1] - one["image_prepaste"]).abs().max() < 1e-4
+            assert ((both["paste"]["mask"][v:v + 1] - one["paste"]["mask"]).abs() > 1e-3).float().mean() < 1e-3
+            assert (both["image"][v:v + 1] - one["image"]).abs().mean() < 1e-4
+    G._inject_draws = None
