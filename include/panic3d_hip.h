@@ -143,6 +143,17 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
                       float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* f16-operand variant of p3d_modconv2d_f32 (opt-in; the reference runs its super-resolution blocks in fp16 on the GPU:
+ * superresolution.py:264-293 with sr_num_fp16_res = 4, networks_stylegan2.py:52-60).  Same arguments and semantics; x, y and
+ * the accumulation stay fp32, the two MFMA operands (the modulated input s*x and the weights) are rounded to f16 (RNE),
+ * the demodulation coefficients come from the fp32 weights `w`.  w_f16: [O][ks*ks][I] f16 made ONCE per layer by
+ * p3d_conv_weights_to_f16 (16-byte aligned).  Requires I % 16 == 0 (P3D_E_RANGE otherwise: use the fp32 function). */
+int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream);
+int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
+                             const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
+                             int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by
  * `down`.  x [NC][H][W] -> y [NC][(H*up+pady0+pady1-fh)/down+1][(W*up+padx0+padx1-fw)/down+1]. */

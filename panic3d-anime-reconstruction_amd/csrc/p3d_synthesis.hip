@@ -23,6 +23,7 @@
 #include "../../include/panic3d_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DEV __device__ __forceinline__
 
 #define CONV_TH 8
@@ -38,6 +39,7 @@ template <> struct ConvTaps<1> { static constexpr int N = 1; static constexpr in
 struct ConvParams {
     const float* x;       // [N][I][H][W]
     const float* w;       // [O][I][ks][ks]
+    const void* wh;       // f16 copy [O][ks*ks][I] (f16-operand kernels) or null
     const float* styles;  // [N][I]
     const float* dcoef;   // [N][O] or null
     const float* noise;   // [OH*OW] (shared) or [N][OH*OW] or null; already multiplied by noise_strength
@@ -316,6 +318,257 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up(ConvParams p) {
     }
 }
 
+// =====================================================================================================================
+// f16-operand variants (opt-in; the reference runs its super-resolution blocks in fp16 on the GPU, superresolution.py:264-293
+// with sr_num_fp16_res = 4).  Activations and outputs stay fp32 in HBM, accumulation is fp32; only the two MFMA operands are
+// rounded to f16 (RNE) while they are staged: the modulated input s*x per element, the weights once per layer
+// (k_weights_to_f16, layout [O][taps][I]).  v_mfma_f32_32x32x16_f16 does 16x the flops of the f32 instruction per cycle, so
+// the tile is re-balanced around LDS bandwidth: a K chunk is 16 input channels = ONE MFMA per tap and N tile; a lane's operand
+// is 8 consecutive channels = one ds_read_b128.
+//   LDS B: [k half][10 rows][32 px][8 ch] f16  (row pitch 32 px: the 16-lane groups of ds_read_b128 then hit 16 distinct 16-B slots)
+//   LDS A: [tap][k half][64 o][8 ch] f16       (lanes = consecutive o -> consecutive slots)
+// Requires I % 16 == 0 (the host falls back to the f32 kernels otherwise).
+// =====================================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define HX_PITCH 32                           // pixels per patch row in LDS
+#define HX_HALF ((CONV_TH + 2) * HX_PITCH * 16)  // bytes of one k half of the patch
+#define HX_BYTES (2 * HX_HALF)
+#define HX_ITEMS (2 * (CONV_TH + 2) * XS_ROW)  // (k half, pixel) items staged per chunk: 360
+
+struct ConvStagePlanH {
+    int xoff[2];   // byte offset of the item's pixel inside the chunk-relative image slice of its first channel (CONV_OOB = zero)
+    int xdst[2];   // LDS byte offset of the item
+    int soff[2];   // byte offset of the item's 8 styles inside the chunk-relative style slice
+    int woff[5];   // byte offset of weight piece q inside the chunk-relative f16 weight tensor
+};
+
+template <int NT>
+DEV ConvStagePlanH conv_plan_h(const ConvParams& p, int tid, int gy0, int gx0, int o0) {
+    ConvStagePlanH s;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = tid + u * 256;
+        const int h = it / ((CONV_TH + 2) * XS_ROW), px = it - h * ((CONV_TH + 2) * XS_ROW);
+        const int r = px / XS_ROW, c = px - r * XS_ROW;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        const bool item = it < HX_ITEMS;
+        const bool ok = item && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        s.xoff[u] = ok ? ((8 * h * p.H + iy) * p.W + ix) * 4 : CONV_OOB;
+        s.soff[u] = ok ? 32 * h : CONV_OOB;
+        s.xdst[u] = item ? h * HX_HALF + (r * HX_PITCH + c) * 16 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = tid + u * 256;  // piece = (tap, k half, o): 16 bytes = 8 channels
+        const int t = q >> 7, h = (q >> 6) & 1, o = q & 63;
+        const bool ok = q < NT * 128 && o0 + o < p.O;
+        s.woff[u] = ok ? (((o0 + o) * NT + t) * p.I + 8 * h) * 2 : CONV_OOB;
+    }
+    return s;
+}
+
+template <int NT>
+struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[(NT * 128 + 255) / 256]; };
+
+template <int NT>
+DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float* xn, const float* sn, int ic0, int ic_end,
+                      ConvStageRegsH<NT>& r) {
+    const int HW = p.H * p.W;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, (ic_end - ic0) * HW * 4, CONV_RSRC_FLAGS);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, (ic_end - ic0) * 4, CONV_RSRC_FLAGS);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + (size_t)ic0 * 2), 0,
+                                                (p.O * NT * p.I - ic0) * 2, CONV_RSRC_FLAGS);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            r.x[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, pl.xoff[u], i * HW * 4, 0));
+        r.s[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pl.soff[u], 0, 0));
+        r.s[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pl.soff[u], 16, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < (NT * 128 + 255) / 256; ++u) r.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, pl.woff[u], 0, 0);
+}
+
+template <int NT>
+DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT>& r) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (pl.xdst[u] < 0) continue;
+        f16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (_Float16)(r.s[u][i >> 2][i & 3] * r.x[u][i]);  // RNE
+        *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < (NT * 128 + 255) / 256; ++u) {
+        const int q = tid + u * 256;
+        if (q < NT * 128) *reinterpret_cast<i32x4*>(ws + q * 16) = r.w[u];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
+    using T = ConvTaps<MODE>;
+    constexpr int NT = T::N, NB = CONV_TH / 4, WBYTES = NT * 128 * 16;
+    __shared__ __attribute__((aligned(16))) char xs[2][HX_BYTES];
+    __shared__ __attribute__((aligned(16))) char ws[2][WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int prow0 = (CONV_TH / 2) * wp + (j >> 4), pcol = j & 15;
+    const int xlane = half * HX_HALF + ((prow0 + 1) * HX_PITCH + pcol + 1) * 16;  // bytes
+    const int wlane = (half * 64 + wc * 32 + j) * 16;
+
+    const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
+    ConvStageRegsH<NT> rg;
+    conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    __syncthreads();
+    int buf = 0;
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
+        const bool more = ic0 + 16 < ic_end;
+        if (more) conv_gload_h<NT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        const char* xb = xs[buf] + xlane;
+        const char* wb = ws[buf] + wlane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f16x8 av = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(xb + ((T::dy[t] + 2 * b) * HX_PITCH + T::dx[t]) * 16);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the stores (and their vmcnt waits) stay behind the MFMAs
+        if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+        if (gy >= p.GH || gx >= p.GW) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ch >= p.O) continue;
+            float v = acc[t][r];
+            if (p.epilogue) {
+                if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
+                if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)gy * p.OW + gx];
+                if (p.bias) v = v + p.bias[ch];
+                v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+            }
+            yout[(((size_t)n * p.O + ch) * p.OH + gy) * p.OW + gx] = v;
+        }
+    }
+}
+
+// the fused four-phase transposed convolution (see k_modconv_up) on f16 operands
+__global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
+    constexpr int NT = 9, WBYTES = NT * 128 * 16;
+    __shared__ __attribute__((aligned(16))) char xs[2][HX_BYTES];
+    __shared__ __attribute__((aligned(16))) char ws[2][WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * CONV_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
+    const int prow0 = 4 * wp + (j >> 4), pcol = j & 15;
+    const int xlane = half * HX_HALF + ((prow0 + 1) * HX_PITCH + pcol + 1) * 16;
+    const int wlane = (half * 64 + wc * 32 + j) * 16;
+
+    const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
+    ConvStageRegsH<NT> rg;
+    conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    __syncthreads();
+    int buf = 0;
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
+        const bool more = ic0 + 16 < ic_end;
+        if (more) conv_gload_h<NT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        const char* xb = xs[buf] + xlane;
+        const char* wb = ws[buf] + wlane;
+        f16x8 a[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const char* xp = xb + (2 * t * HX_PITCH) * 16;
+            const f16x8 b00 = *reinterpret_cast<const f16x8*>(xp);
+            const f16x8 b01 = *reinterpret_cast<const f16x8*>(xp - 16);
+            const f16x8 b10 = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
+            const f16x8 b11 = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b00, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b00, acc[1][t], 0, 0, 0);
+            acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b00, acc[2][t], 0, 0, 0);
+            acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[4], b00, acc[3][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b01, acc[0][t], 0, 0, 0);
+            acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[5], b01, acc[2][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[6], b10, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[7], b10, acc[1][t], 0, 0, 0);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[8], b11, acc[0][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+            if (gy > p.H - py || gx > p.W - px) continue;
+            const int oy = 2 * gy + py, ox = 2 * gx + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
+            }
+        }
+    }
+}
+
+// w [O][I][kk] f32 -> wh [O][kk][I] f16 (RNE), once per layer
+__global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int kk, _Float16* __restrict__ wh) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)O * I * kk) return;
+    const int i = (int)(idx % I), t = (int)((idx / I) % kk), o = (int)(idx / ((long long)I * kk));
+    wh[idx] = (_Float16)w[((long long)o * I + i) * kk + t];
+}
+
 // sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
 struct ReduceParams {
     const float* part; float* y; const float* dcoef; const float* noise; const float* bias;
@@ -478,7 +731,8 @@ static inline int chk() {
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-    hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
+    if (p.wh) hipLaunchKernelGGL((k_modconv_h<MODE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
 }
 
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
@@ -500,11 +754,13 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     return b + 256;
 }
 
-int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
-                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
-                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int O, int ks,
+                        const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
+                        int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
     if (!x || !w || !styles || !y || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    // 32-bit byte offsets inside one image / the weight tensor (raw buffer addressing)
+    if ((long long)I * H * W * 4 >= (1ll << 31) || (long long)O * I * ks * ks * 4 >= (1ll << 31)) return P3D_E_RANGE;
     if (!((ks == 3 && (up == 1 || up == 2)) || (ks == 1 && up == 1))) return P3D_E_RANGE;
     if (up == 2 && !fir) return P3D_E_ARG;
     if (workspace_bytes < p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)) return P3D_E_WORKSPACE;
@@ -520,7 +776,7 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     }
     const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
     ConvParams p;
-    p.x = x; p.w = w; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
+    p.x = x; p.w = w; p.wh = wh; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
@@ -533,7 +789,8 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
+        if (p.wh) hipLaunchKernelGGL(k_modconv_up_h, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
     if (ksplit > 1) {
         ReduceParams r;
@@ -552,6 +809,33 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
     dim3 grid(((q.OW + 31) / 32) * ((q.OH + 31) / 32), (unsigned)q.NC);
     hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
     return chk();
+}
+
+int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
+                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
+                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return modconv_impl(x, N, I, H, W, w, nullptr, O, ks, styles, demodulate, noise, noise_per_sample, bias, up, act, alpha, gain,
+                        clamp, fir, y, workspace, workspace_bytes, stream);
+}
+
+int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream) {
+    if (!w || !w_f16 || O <= 0 || I <= 0) return P3D_E_ARG;
+    if (ks != 1 && ks != 3) return P3D_E_RANGE;
+    const long long total = (long long)O * I * ks * ks;
+    hipLaunchKernelGGL(k_weights_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, O, I, ks * ks,
+                       (_Float16*)w_f16);
+    return chk();
+}
+
+int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
+                             const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
+                             int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (!w_f16) return P3D_E_ARG;
+    if (I % 16 != 0 || ((uintptr_t)w_f16 & 15)) return P3D_E_RANGE;  // a K chunk is 16 channels; 16-byte weight pieces
+    return modconv_impl(x, N, I, H, W, w, w_f16, O, ks, styles, demodulate, noise, noise_per_sample, bias, up, act, alpha, gain,
+                        clamp, fir, y, workspace, workspace_bytes, stream);
 }
 
 int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,

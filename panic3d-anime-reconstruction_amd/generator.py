@@ -274,3 +274,12 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def set_force_sigmoid(self, state):
         return self.decoder.set_force_sigmoid(state)
+
+    def set_sr_mma_f16(self, state=True):
+        """Opt-in: run the super-resolution convolutions on f16 MFMA operands (fp32 accumulate, fp32 activations in HBM).
+        The reference runs these blocks in fp16 on the GPU (sr_num_fp16_res = 4, superresolution.py:277-280); the default here
+        is exact fp32, which is what its CPU path (the source of the golden fixtures) computes."""
+        for m in self.superresolution.modules():
+            if isinstance(m, (stylegan2.SynthesisLayer, stylegan2.ToRGBLayer)):
+                m.mma_f16 = bool(state)
+        return bool(state)

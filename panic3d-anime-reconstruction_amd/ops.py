@@ -374,11 +374,23 @@ def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
     return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * up * up)
 
 
+def conv_weights_to_f16(weight):
+    """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer)."""
+    weight = _chk(weight, "weight")
+    O, I, kh, kw = weight.shape
+    wh = torch.empty((O, kh * kw, I), dtype=torch.float16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().p3d_conv_weights_to_f16(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16")
+    return wh
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
-                     bias=None, act="linear", gain=None, clamp=None):
+                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
-    noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength)."""
+    noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
+    weight_f16 (from conv_weights_to_f16): run the matrix cores on f16 operands (fp32 accumulate, fp32 in/out) — what the
+    reference's fp16 super-resolution blocks do on the GPU, with less rounding; needs I % 16 == 0."""
     x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
     N, I, H, W = x.shape
     O, I2, kh, kw = weight.shape
@@ -407,7 +419,15 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(noise), nps,
-                                 _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
-    _lib.check(rc, "p3d_modconv2d_f32")
+        if weight_f16 is not None:
+            if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape) != (O, kh * kw, I) or not weight_f16.is_contiguous():
+                raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] float16 tensor of conv_weights_to_f16")
+            rc = L.p3d_modconv2d_f16mma_f32(_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
+                                            _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y),
+                                            _p(ws), wsb, _stream())
+            _lib.check(rc, "p3d_modconv2d_f16mma_f32")
+        else:
+            rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(noise), nps,
+                                     _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
+            _lib.check(rc, "p3d_modconv2d_f32")
     return y

@@ -85,6 +85,17 @@ class MappingNetwork(torch.nn.Module):
         return x
 
 
+def _f16_operand(layer):
+    """The cached [O,k*k,I] f16 copy of layer.weight when the layer is switched to f16 MFMA operands (`layer.mma_f16`,
+    see TriPlaneGenerator.set_sr_mma_f16), else None.  A plain attribute, not a buffer: the state_dict stays the reference's."""
+    if not getattr(layer, "mma_f16", False) or layer.in_channels % 16 != 0:
+        return None
+    key = (layer.weight.data_ptr(), layer.weight._version)
+    if getattr(layer, "_wh_key", None) != key:
+        layer._wh, layer._wh_key = ops.conv_weights_to_f16(layer.weight.detach()), key
+    return layer._wh
+
+
 class SynthesisLayer(torch.nn.Module):
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
                  activation="lrelu", resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False):
@@ -112,7 +123,7 @@ class SynthesisLayer(torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
-                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self))
 
 
 class ToRGBLayer(torch.nn.Module):
@@ -127,7 +138,7 @@ class ToRGBLayer(torch.nn.Module):
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
         return ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
-                                    clamp=self.conv_clamp)
+                                    clamp=self.conv_clamp, weight_f16=_f16_operand(self))
 
 
 class SynthesisBlock(torch.nn.Module):

@@ -268,3 +268,49 @@ def test_f_many_views_of_one_subject_in_one_call(hip):
             assert ((both["paste"]["mask"][v:v + 1] - one["paste"]["mask"]).abs() > 1e-3).float().mean() < 1e-3
             assert (both["image"][v:v + 1] - one["image"]).abs().mean() < 1e-4
     G._inject_draws = None
+
+
+@pytest.mark.parametrize("I,O,H,up,ks,N", [(32, 64, 24, 1, 3, 2), (64, 40, 20, 2, 3, 1), (48, 3, 33, 1, 1, 2), (256, 128, 64, 2, 3, 1),
+                                           (128, 128, 96, 1, 3, 1)])
+def test_modconv_f16_operands_vs_fp32(hip, I, O, H, up, ks, N):
+    """The opt-in f16-operand convolution (fp32 accumulate) against (a) the exact-fp32 HIP convolution: error at the level of
+    the f16 rounding of the operands (2^-11 relative per operand, averaged over K terms); (b) the same fp32 convolution fed
+    with operands pre-rounded to f16 by torch: only fp32 summation-order differences remain."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(I + O)
+    x = torch.randn(N, I, H, H, generator=g).cuda(); w = torch.randn(O, I, ks, ks, generator=g).cuda()
+    s = (torch.randn(N, I, generator=g) * 0.5 + 1).cuda(); b = torch.randn(O, generator=g).cuda()
+    f = ops.setup_filter([1, 3, 3, 1]).cuda()
+    kw = dict(up=up, padding=ks // 2, resample_filter=f, demodulate=ks == 3, bias=b, act="lrelu" if ks == 3 else "linear")
+    wh = ops.conv_weights_to_f16(w)
+    assert wh.shape == (O, ks * ks, I) and torch.equal(wh, w.reshape(O, I, ks * ks).permute(0, 2, 1).half())
+    y32 = ops.modulated_conv2d(x, w, s, **kw)
+    y16 = ops.modulated_conv2d(x, w, s, weight_f16=wh, **kw)
+    scale = y32.abs().mean()
+    assert (y16 - y32).abs().mean() < 1e-3 * scale and (y16 - y32).abs().max() < 2e-2 * y32.abs().max()
+    if ks == 1:  # (b) without demodulation the rounded-operand convolution can be stated exactly: x' = f16(s*x) with s = 1
+        xs = (x * s[:, :, None, None]).half().float()
+        ref = ops.modulated_conv2d(xs, w.half().float(), torch.ones_like(s), **kw)
+        assert (y16 - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_sr_f16_operands_image_quality(hip):
+    """TriPlaneGenerator with set_sr_mma_f16: the 512^2 image stays within f16-operand rounding of the fp32 image
+    (PSNR > 50 dB on [-1,1] images; the reference's own fp16 blocks round activations as well)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    x = dict(elevations=torch.tensor([0.0]).cuda(), azimuths=torch.tensor([20.0]).cuda(), fovs=torch.tensor([30.0]).cuda(),
+             seeds=[3], cond={}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+    with torch.no_grad():
+        G._inject_draws = (dev(g["jitter"])[:1], dev(g["u"])[:256])
+        a = G.f(dict(x))["image"]
+        G.set_sr_mma_f16(True)
+        G._inject_draws = (dev(g["jitter"])[:1], dev(g["u"])[:256])
+        b = G.f(dict(x))["image"]
+    G._inject_draws = None
+    used = [m for m in G.superresolution.modules() if getattr(m, "_wh", None) is not None]
+    assert len(used) >= 3  # the 16-channel-aligned layers really took the f16 path
+    mse = float(((a - b).double() ** 2).mean())
+    assert mse > 0 and 10 * np.log10(4.0 / mse) > 50.0, 10 * np.log10(4.0 / max(mse, 1e-30))

@@ -48,4 +48,12 @@ with torch.no_grad():
     dt = timeit(lambda: sr(rgb, x, ws, noise_mode="none"))
     fl = 2 * (9 * 32 * 256 * 128 ** 2 + 9 * 256 * 256 * 256 ** 2 + 256 * 3 * 256 ** 2 + 9 * 256 * 128 * 256 ** 2 + 9 * 128 * 128 * 512 ** 2 + 128 * 3 * 512 ** 2)
     out["superres_N1"] = {"ms": dt * 1e3, "GFLOP": fl / 1e9, "TFLOP/s": fl / dt / 1e12, "frac_of_157.3": fl / dt / 157.3e12}
+    for m in sr.modules():  # opt-in f16 MFMA operands (TriPlaneGenerator.set_sr_mma_f16)
+        if isinstance(m, (sg.SynthesisLayer, sg.ToRGBLayer)):
+            m.mma_f16 = True
+    dt = timeit(lambda: sr(rgb, x, ws, noise_mode="none"))
+    out["superres_N1_f16_operands"] = {"ms": dt * 1e3, "TFLOP/s": fl / dt / 1e12, "frac_of_2500_f16": fl / dt / 2.5e15}
+    x16 = x.expand(16, -1, -1, -1).contiguous(); rgb16 = x16[:, :3].contiguous(); ws16 = ws.expand(16, -1, -1).contiguous()
+    dt = timeit(lambda: sr(rgb16, x16, ws16, noise_mode="none"), n=3)
+    out["superres_N16_f16_operands"] = {"ms_per_image": dt * 1e3 / 16, "TFLOP/s": 16 * fl / dt / 1e12}
 print(json.dumps(out))

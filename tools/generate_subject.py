@@ -81,6 +81,13 @@ with torch.no_grad():
     t5 = sync()
     ob = G.f(xin)
     t6 = sync()
+    G.set_sr_mma_f16(True)  # opt-in: super-resolution convolutions on f16 MFMA operands (the reference's SR blocks are fp16 on GPU)
+    G.f(dict(xin))
+    t7 = sync()
+    oh = G.f(dict(xin))
+    t8 = sync()
+    G.set_sr_mma_f16(False)
+    sr_f16_psnr = float(10 * torch.log10(1.0 / ((oh["image_prepaste"] - ob["image_prepaste"]).double() ** 2).mean()))
 if "--out" in sys.argv:  # the reference's per-subject files (generate.py:104-105,132-148)
     from panic3d_amd import outputs
     odn = sys.argv[sys.argv.index("--out") + 1]
@@ -90,5 +97,6 @@ assert all(i.shape == (1, 3, 512, 512) and torch.isfinite(i).all() for i in imgs
 print(json.dumps({"one_view_f_ms": (t1 - t0) * 1e3, "density_grid_256_ms": (t2 - t1) * 1e3, "mesh_256_ms_incl_grid_and_d2h": (tm1 - tm0) * 1e3,
                   "mesh_verts": len(mc["verts"]), "mesh_faces": len(mc["faces"]), "views": len(views),
                   "views_with_paste_ms": (t3 - t2) * 1e3, "ms_per_view": (t3 - t2) * 1e3 / len(views),
-                  "subject_total_ms": (t3 - t0 - (tm0 - t2)) * 1e3, "ms_per_view_planes_cached": (t4 - t3) * 1e3 / len(views), "ms_per_view_all_views_one_call": (t6 - t5) * 1e3 / len(views), "mean_alpha_last_view": float(o["image_weights"].mean()),
+                  "subject_total_ms": (t3 - t0 - (tm0 - t2)) * 1e3, "ms_per_view_planes_cached": (t4 - t3) * 1e3 / len(views), "ms_per_view_all_views_one_call": (t6 - t5) * 1e3 / len(views),
+                  "ms_per_view_all_views_one_call_sr_f16_operands": (t8 - t7) * 1e3 / len(views), "sr_f16_vs_fp32_psnr_db": sr_f16_psnr, "mean_alpha_last_view": float(o["image_weights"].mean()),
                   "paste_mask_mean_last_view": float(o["paste"]["mask"].mean())}))
