@@ -110,9 +110,13 @@ template <int NT>
 DEV void conv_gload(const ConvParams& p, const ConvStagePlan& pl, const float* xn, const float* sn, int ic0, int ic_end,
                     ConvStageRegs<NT>& r) {
     const int HW = p.H * p.W;
-    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, (ic_end - ic0) * HW * 4, CONV_RSRC_FLAGS);
-    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, (ic_end - ic0) * 4, CONV_RSRC_FLAGS);
-    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)ic0 * NT), 0, (p.O * p.I - ic0) * NT * 4, CONV_RSRC_FLAGS);
+    // channels left in this split-K slice; a slice beyond the last channel (I not a multiple of the slice width) has none:
+    // every load is then out of range -> zeros -> the workgroup stores a zero partial sum
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, left * HW * 4, CONV_RSRC_FLAGS);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, left * 4, CONV_RSRC_FLAGS);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)ic0 * NT), 0, left ? (p.O * p.I - ic0) * NT * 4 : 0,
+                                                CONV_RSRC_FLAGS);
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         r.x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, pl.xoff[u], 0, 0));
@@ -375,10 +379,13 @@ template <int NT>
 DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float* xn, const float* sn, int ic0, int ic_end,
                       ConvStageRegsH<NT>& r) {
     const int HW = p.H * p.W;
-    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, (ic_end - ic0) * HW * 4, CONV_RSRC_FLAGS);
-    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, (ic_end - ic0) * 4, CONV_RSRC_FLAGS);
+    // channels left in this split-K slice; a slice beyond the last channel (I not a multiple of the slice width) has none:
+    // every load is then out of range -> zeros -> the workgroup stores a zero partial sum
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, left * HW * 4, CONV_RSRC_FLAGS);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, left * 4, CONV_RSRC_FLAGS);
     auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + (size_t)ic0 * 2), 0,
-                                                (p.O * NT * p.I - ic0) * 2, CONV_RSRC_FLAGS);
+                                                left ? (p.O * NT * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll

@@ -101,7 +101,10 @@ def torch_modconv_ref(x, w, s, noise, up, demod, bias, f):
 
 
 @pytest.mark.parametrize("I,O,H,up,ks", [(512, 512, 16, 1, 3), (512, 512, 8, 2, 3), (256, 128, 32, 2, 3), (128, 96, 64, 1, 1),
-                                         (40, 72, 13, 1, 3)])
+                                         (40, 72, 13, 1, 3),
+                                         # channel tails (I not a multiple of the 8-channel K chunk; e.g. conditioning channels
+                                         # concatenated to the feature map), ragged tiles, O < 64, split-K with a partial slice
+                                         (20, 70, 13, 1, 3), (35, 10, 9, 2, 3), (19, 5, 11, 1, 1), (515, 64, 8, 1, 3), (131, 64, 16, 2, 3)])
 def test_modconv_hot_path_shapes_vs_torch_fp32(hip, I, O, H, up, ks):
     g = torch.Generator().manual_seed(I + O + H)
     N = 2
