@@ -299,3 +299,47 @@ def test_shared_planes_many_views_one_launch(hip, oracle):
     out = r(dev(planes1).expand(2, -1, -1, -1, -1), Dec(), o, d, inp["ro"], jitter=jit, u=u, **kw)
     for a, b in zip(out, ref):
         assert np.array_equal(a.cpu().numpy(), b)
+
+
+def _random_config(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 4))
+    H, W = int(rng.integers(8, 97)), int(rng.integers(8, 97))  # non-square, odd sizes
+    side = int(rng.choice([0, 8, 16, 24]))  # 0: a ragged ray list; else an image of side x (4k) rays (tiled lane order)
+    R = int(rng.integers(1, 150)) if side == 0 else side * int(rng.choice([4, 8, 12]))
+    Sc = int(rng.integers(4, 71))
+    Sf = int(rng.choice([0, int(rng.integers(1, 71)), int(rng.integers(129, 150))]))
+    rs = float(rng.uniform(0.3, 0.7)); re = rs + float(rng.uniform(0.5, 1.2))
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, ray_start=rs, ray_end=re,
+              box_warp=float(rng.choice([0.7, 1.0, 2.0])), white_back=bool(rng.integers(0, 2)), use_triplane=int(rng.integers(0, 2)))
+    kw = dict(triplane_crop=[None, 0.1, 0.05][int(rng.integers(0, 3))], force_sigmoid=bool(rng.integers(0, 2)))
+    m = int(rng.integers(0, 3))
+    kw["cull_clouds"] = 0.5 if m == 1 else None
+    kw["binarize_clouds"] = 0.4 if m == 2 else None
+    planes = T.make_planes(seed, N, H, W, scale=float(rng.uniform(0.5, 4.0)), smooth=int(rng.choice([0, 4, 8])))
+    raw = T.make_decoder_params(seed + 1, float(rng.choice([1.0, 0.5])), float(rng.choice([1.0, 10.0, 30.0])))
+    # cameras on a sphere of radius ~1 looking at the box, plus a few rays that miss it entirely
+    o = rng.standard_normal((N, R, 3)); o /= np.linalg.norm(o, axis=-1, keepdims=True)
+    tgt = rng.uniform(-0.3, 0.3, (N, R, 3)) * ro["box_warp"]
+    d = tgt - o; d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d[:, ::7] = -d[:, ::7]
+    jit, u = T.make_random_draws(seed + 2, N, R, Sc, Sf)
+    return dict(ro=ro, kw=kw, planes=planes, raw=raw, lr_mul=1.0, o=o.astype(np.float32), d=d.astype(np.float32), jit=jit, u=u,
+                tile_w=(side if side else 0), early_out=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(100, 124))
+def test_render_random_configs_bit_exact(hip, oracle, seed):
+    """Randomised sweep over what the golden fixtures do not enumerate: N 1-3, non-square planes of odd sizes, ragged ray
+    counts (incl. fewer than one wavefront), 4 <= Sc <= 70, Sf in {0, 1..70 (sorting network), 129..149 (LDS sort)}, every
+    mask mode, both plane conventions, white/black background, early-outs on/off, rays that miss the volume.  Bit-exact."""
+    c = _random_config(seed)
+    mlp = hip_mlp(hip, c["raw"], c["lr_mul"])
+    opts = hip.ops.make_opts(c["ro"], early_out=c["early_out"], **c["kw"])
+    out = hip.ops.render(hip.ops.planes_to_nhwc(dev(c["planes"])), dev(c["o"]), dev(c["d"]), dev(c["jit"]), dev(c["u"]), mlp, opts,
+                         ray_tile_w=c["tile_w"])
+    ref = oracle.render(c["planes"], c["o"], c["d"], c["jit"], c["u"], oracle.prescale_mlp(*c["raw"], lr_mul=c["lr_mul"]),
+                        oracle.make_opts(c["ro"], **c["kw"]))
+    for name, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
+        a = a.cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), (name, seed, float(np.nanmax(np.abs(a - b))))
