@@ -85,8 +85,17 @@ GEN_KW = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, 
               channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
 
 
-def generator_cases():
-    for tag, cond_mode in (("none", "none"), ("cond", "ortho_front.add_shuffle2_4.inj_6b_4.crossavg_4.reschonk_add_8.resnetcond_16")):
+# every branch of the conditioning glue (networks_stylegan2.py:551-694) appears in at least one mode; the image-channel
+# counts limit which branches can be combined (the tiled condition must fit a quarter of the 64 feature channels)
+COND_MODES = (("none", "none"), ("cond", "ortho_front.add_shuffle2_4.inj_6b_4.crossavg_4.reschonk_add_8.resnetcond_16"),
+              ("cond2", "ortho_front.gt_sides.cond_img_norm_4.add_4.concatfront.crossavgt_38"),
+              ("cond3", "ortho_front.mult_shuffle2_4.crossavg_4"), ("cond4", "ortho_front.dorthoA.add_4"))
+
+
+def generator_cases(only=None):
+    for tag, cond_mode in COND_MODES:
+        if only and tag not in only:
+            continue
         torch.manual_seed(77)
         G = ns.Generator(cond_mode=cond_mode, **GEN_KW).eval()
         gg = torch.Generator().manual_seed(78)
@@ -99,6 +108,10 @@ def generator_cases():
         c = torch.randn(2, 25, generator=gg)
         cond = {"image_ortho_front": torch.rand(2, 4, 32, 32, generator=gg), "resnet_feats": torch.randn(2, 32, generator=gg),
                 "resnet_chonk": torch.randn(2, 8, 8, 8, generator=gg)}
+        if "gt_sides" in cond_mode:
+            cond.update(image_ortho_left=torch.rand(2, 4, 32, 32, generator=gg), image_ortho_right=torch.rand(2, 4, 32, 32, generator=gg))
+        if "dorthoA" in cond_mode:
+            cond.update(image_dorthoA_left=torch.rand(2, 4, 32, 32, generator=gg), image_dorthoA_right=torch.rand(2, 4, 32, 32, generator=gg))
         ws = G.mapping(z, c, cond, truncation_psi=0.7, truncation_cutoff=4)
         img = G.synthesis(ws, cond, noise_mode="const")
         ws1 = G.mapping(z, c, cond)
@@ -210,5 +223,7 @@ if __name__ == "__main__":
         layer_cases()
     if "generator" in which:
         generator_cases()
+    if any(w.startswith("cond") for w in which):  # e.g. `make_golden_synthesis.py cond2 cond3 cond4`
+        generator_cases(only=[w for w in which if w.startswith("cond")])
     if "triplane" in which:
         triplane_case()

@@ -124,7 +124,7 @@ def test_modconv_hot_path_shapes_vs_torch_fp32(hip, I, O, H, up, ks):
     assert err < 3e-6 * np.sqrt(I * ks * ks), err  # ~2e-4 at K = 4608
 
 
-@pytest.mark.parametrize("tag", ["none", "cond"])
+@pytest.mark.parametrize("tag", ["none", "cond", "cond2", "cond3", "cond4"])  # cond*: every branch of the conditioning glue
 def test_generator_vs_reference(hip, tag):
     from panic3d_amd import stylegan2 as sg
     g = T.load_golden(f"syn_generator_{tag}.npz")
