@@ -216,6 +216,53 @@ def triplane_case():
     save("syn_triplane_f.npz", **arrs)
 
 
+def triplane_cond_case():
+    """G.f of a CONDITIONED generator (image + resnet conditioning as _scripts/eval/generate.py:88-96 passes them, pose
+    conditioning zeroed like PAniC-3D's trainer default): pins mapping_zplus with resnet features (triplane.py:124-186),
+    c_gen_conditioning_zero and the conditioned backbone inside the full f() flow."""
+    from training.triplane import TriPlaneGenerator
+    torch.manual_seed(15)
+    kw = dict(TRI_KW, cond_mode="ortho_front.concatfront.inj_6b_4.crossavg_4.reschonk_add_8.resnetcond_16",
+              rendering_kwargs=dict(TRI_RK, c_gen_conditioning_zero=True))
+    G = TriPlaneGenerator(**kw).eval()
+    gg = torch.Generator().manual_seed(16)
+    for n, p in G.named_parameters():
+        if n.endswith(".bias") and "affine" not in n:
+            p.copy_(torch.randn(p.shape, generator=gg) * 0.2)
+    for n, p in G.backbone.synthesis.named_parameters():
+        if n.endswith("torgb.weight"):
+            p.mul_(30.0)
+    G.decoder.net[2].weight[0] *= float(os.environ.get('P3D_COND_SIGMA_GAIN', '1.0'))
+    G.decoder.net[2].bias[0] = float(os.environ.get('P3D_COND_SIGMA_BIAS', '-20.0'))  # mixes surface and background
+    G.set_force_sigmoid(True)
+    cond = {"image_ortho_front": torch.rand(1, 3, 64, 64, generator=gg), "resnet_feats": torch.randn(1, 32, generator=gg),
+            "resnet_chonk": torch.randn(1, 8, 8, 8, generator=gg)}
+    rec = {}
+    o_rl, o_r = torch.rand_like, torch.rand
+
+    def rand_like(t, *a, **k):
+        r = o_rl(t, *a, **k); rec.setdefault("jitter", r.clone()); return r
+
+    def rand(*a, **k):
+        r = o_r(*a, **k); rec.setdefault("u", r.clone()); return r
+
+    x = dict(elevations=torch.tensor([5.0]), azimuths=torch.tensor([-30.0]), fovs=torch.tensor([30.0]), seeds=[7], cond=cond,
+             triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+    torch.rand_like, torch.rand = rand_like, rand
+    try:
+        torch.manual_seed(19)
+        out = G.f(x)
+    finally:
+        torch.rand_like, torch.rand = o_rl, o_r
+    print("conditioned fixture: image_weights mean %.3f" % float(out["image_weights"].mean()))
+    arrs = {k: out[k].numpy() for k in ("image_raw", "image_weights", "image_xyz", "triplane")}
+    arrs["image_sub4"] = out["image"][..., ::4, ::4].contiguous().numpy()
+    arrs.update(jitter=rec["jitter"].numpy(), u=rec["u"].numpy(), ws=x["ws"].numpy(), cond_mode=np.array(kw["cond_mode"]))
+    arrs.update({"cond_" + k: v.numpy() for k, v in cond.items()})
+    arrs.update(sd_np(G, "sd_"))
+    save("syn_triplane_f_cond.npz", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["layers", "generator", "triplane"]
@@ -227,3 +274,5 @@ if __name__ == "__main__":
         generator_cases(only=[w for w in which if w.startswith("cond")])
     if "triplane" in which:
         triplane_case()
+    if "triplane_cond" in which or not sys.argv[1:]:
+        triplane_cond_case()

@@ -317,3 +317,29 @@ def test_sr_f16_operands_image_quality(hip):
     assert len(used) >= 3  # the 16-channel-aligned layers really took the f16 path
     mse = float(((a - b).double() ** 2).mean())
     assert mse > 0 and 10 * np.log10(4.0 / mse) > 50.0, 10 * np.log10(4.0 / max(mse, 1e-30))
+
+
+def test_triplane_generator_f_conditioned_vs_reference(hip):
+    """G.f of a conditioned generator (front illustration + resnet features + resnet 'chonk', pose conditioning zeroed: what
+    _scripts/eval/generate.py:88-96 feeds the released model) against the reference's own G.f on CPU: mapping_zplus with
+    resnet features, the conditioned backbone, fused renderer, super-resolution."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f_cond.npz")
+    kw = dict(TRI_KW, cond_mode=str(g["cond_mode"]), rendering_kwargs=dict(TRI_RK, c_gen_conditioning_zero=True))
+    G = load_sd(TriPlaneGenerator(**kw), g, "sd_")
+    G.set_force_sigmoid(True)
+    G._inject_draws = (dev(g["jitter"]), dev(g["u"]))
+    cond = {k[5:]: dev(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+    x = dict(elevations=torch.tensor([5.0]).cuda(), azimuths=torch.tensor([-30.0]).cuda(), fovs=torch.tensor([30.0]).cuda(), seeds=[7],
+             cond=cond, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+    with torch.no_grad():
+        out = G.f(x)
+    G._inject_draws = None
+    assert np.abs(x["ws"].cpu().numpy() - g["ws"]).max() < 1e-5
+    assert rel_err(out["triplane"].cpu().numpy(), g["triplane"]) < 1e-4
+    for k, tol in (("image_raw", 2e-3), ("image_weights", 2e-3), ("image_xyz", 2e-3)):
+        d = np.abs(out[k].cpu().numpy() - g[k])
+        assert d.max() < 20 * tol and d.mean() < tol, (k, d.max(), d.mean())
+    d = np.abs(out["image"][..., ::4, ::4].cpu().numpy() - g["image_sub4"])
+    assert d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
+    assert 0.05 < float(out["image_weights"].mean()) < 0.999  # the fixture shows both surface and background
