@@ -263,6 +263,44 @@ def triplane_cond_case():
     save("syn_triplane_f_cond.npz", **arrs)
 
 
+def volume_case():
+    """The reference's OWN get_eg3d_volume (_util/eg3d_metrics3d.py:94-183) on the syn_triplane_f generator.  The module
+    cannot be imported here (it pulls the whole _util / _databacks tree: cv2, trimesh, ...), so the three functions are
+    compiled from the reference's source text, unmodified, into a namespace that supplies their module-level names."""
+    import ast
+    from training.triplane import TriPlaneGenerator
+    from training.volumetric_rendering.renderer import triplane_crop_mask, cull_clouds_mask
+    g = np.load(os.path.join(HERE, "syn_triplane_f.npz"))
+    G = TriPlaneGenerator(**TRI_KW).eval()
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")})
+    G.set_force_sigmoid(True)
+
+    class Dict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    path = "/root/reference/_util/eg3d_metrics3d.py"
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("sigma2density", "create_samples", "get_eg3d_volume")]
+    assert len(keep) == 3
+    ns_ = {"torch": torch, "nn": torch.nn, "np": np, "Dict": Dict, "device": torch.device("cpu"),
+           "triplane_crop_mask": triplane_crop_mask, "cull_clouds_mask": cull_clouds_mask}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns_)
+    N = 14
+    out = {}
+    for tag, extra in (("plain", {}), ("masked", {"triplane_crop": 0.1, "cull_clouds": 0.5})):
+        xin = {"cond": {}, "seeds": [3], "neural_rendering_resolution": 8, **extra}
+        torch.manual_seed(21)
+        vol = ns_["get_eg3d_volume"](G, xin, resolution=N, max_batch=1000)
+        out[f"{tag}_densities"] = vol["densities"].contiguous().numpy()
+        out[f"{tag}_sigmas"] = vol["sigmas"].contiguous().numpy()
+        out[f"{tag}_rgb3"] = vol["rgbs"][:, :3].contiguous().numpy()
+        out[f"{tag}_coordinates"] = vol["coordinates"].contiguous().numpy()
+    print("volume fixture: density > 0.5 fraction %.3f, culled fraction %.3f" % (
+        float((out["plain_densities"] > 0.5).mean()), float((out["masked_densities"] == -1e3).mean())))
+    save("volume_reference.npz", resolution=np.array(N), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["layers", "generator", "triplane"]
@@ -276,3 +314,5 @@ if __name__ == "__main__":
         triplane_case()
     if "triplane_cond" in which or not sys.argv[1:]:
         triplane_cond_case()
+    if "volume" in which or not sys.argv[1:]:
+        volume_case()

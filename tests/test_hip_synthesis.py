@@ -343,3 +343,37 @@ def test_triplane_generator_f_conditioned_vs_reference(hip):
     d = np.abs(out["image"][..., ::4, ::4].cpu().numpy() - g["image_sub4"])
     assert d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
     assert 0.05 < float(out["image_weights"].mean()) < 0.999  # the fixture shows both surface and background
+
+
+def test_density_grid_vs_the_references_get_eg3d_volume(hip):
+    """volume.density_grid / to_volume / create_samples against the output of the reference's OWN get_eg3d_volume
+    (_util/eg3d_metrics3d.py:94-183, executed from its source text by tests/golden/make_golden_synthesis.py volume_case):
+    sigmas, densities with and without the crop / cull masks, the rgb grid and the coordinate grid, in the reference's final
+    [1,C,N,N,N] layout (first axis flipped)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    gv, gt = T.load_golden("volume_reference.npz"), T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), gt, "sd_")
+    G.set_force_sigmoid(True)
+    N = int(gv["resolution"])
+    vol = hip.volume
+    with torch.no_grad():
+        x = dict(elevations=torch.zeros(1).cuda(), azimuths=torch.zeros(1).cuda(), seeds=[3], cond={}, neural_rendering_resolution=8)
+        G.f(x)  # the reference obtains ws the same way (eg3d_metrics3d.py:101-109)
+        ws = x["ws"]
+        plain = vol.density_grid(G, ws, {}, resolution=N)
+        masked = vol.density_grid(G, ws, {}, resolution=N, triplane_crop=0.1, cull_clouds=0.5)
+        pts = vol.create_samples(N, cube_length=0.7)[0]
+        rgb = G.sample_mixed(pts.cuda().contiguous(), None, ws, {}, noise_mode="const")["rgb"]
+    assert np.array_equal(vol.to_volume(pts, N).numpy(), gv["plain_coordinates"])  # same float ops on the CPU
+    sig = vol.to_volume(plain["sigmas"], N).cpu().numpy()
+    assert sig.shape == gv["plain_sigmas"].shape == (1, 1, N, N, N) and rel_err(sig, gv["plain_sigmas"]) < 1e-3
+    assert np.abs(vol.to_volume(plain["densities"], N).cpu().numpy() - gv["plain_densities"]).max() < 2e-4
+    assert np.abs(vol.to_volume(rgb, N)[:, :3].cpu().numpy() - gv["plain_rgb3"]).max() < 2e-3
+    dm, ref = vol.to_volume(masked["densities"], N).cpu().numpy(), gv["masked_densities"]
+    same = (dm == -1e3) == (ref == -1e3)
+    assert same.mean() > 0.995 and (ref == -1e3).mean() > 0.5  # thresholded masks: only boundary voxels may flip
+    both = same & (ref != -1e3)
+    assert both.sum() > 10 and np.abs(dm[both] - ref[both]).max() < 2e-4
+    # and the mesh of generate.py:98-103 from the reference's own volume runs through the device extractor
+    mc = vol.marching_cubes(torch.from_numpy(gv["plain_densities"][0, 0]).cuda(), torch.from_numpy(gv["plain_rgb3"][0]).cuda(), 0.7, level=0.5)
+    assert len(mc["faces"]) > 50 and mc["colors"].shape == (len(mc["verts"]), 3) and np.abs(mc["verts"]).max() <= 0.35 + 1e-6
