@@ -2,17 +2,21 @@
 // skimage.measure.marching_cubes call of _util/eg3d_metrics3d.py:186-210 (called from _scripts/eval/generate.py:98-103)
 // so that the 512^3 density volume never leaves HBM; only the mesh (a few MB) does.  gfx950 only.
 //
-// HBM-bound integer / index work.  One 256-thread workgroup owns one grid ROW (fixed a, b; all c), so the (a,b,c) index
-// arithmetic is scalar and every volume access is a coalesced row read; rows are walked in flat grid order, which fixes the
-// vertex / face order (oracle/p3d_oracle_mc.c reproduces it -> bit-exact parity):
-//   k_mc_classify   per grid point: #owned crossed edges (0..3) and #triangles of its cube (table) -> one packed sum per row
-//   k_mc_scan_rows  one workgroup per plane a: exclusive scan of that plane's n row sums, plane totals
+// HBM-bound integer / index work.  One workgroup owns a GROUP of MC_G consecutive grid rows (fixed a; b0 .. b0+MC_G-1; all c),
+// one thread 4 consecutive points of each of them: the (a,b,c) arithmetic is scalar, every volume access is a coalesced 16-byte
+// row read, the 2 x (MC_G+1) rows a group touches are all requested before the first is used (the kernels are latency-bound
+// otherwise: measured 1.9 TB/s with one row per workgroup), and each row is fetched once per group instead of twice.
+// Groups are walked in flat grid order, which fixes the vertex / face order (oracle/p3d_oracle_mc.c reproduces it -> bit-exact):
+//   k_mc_classify    per grid point: #owned crossed edges (0..3) and #triangles of its cube (table) -> one packed sum per group
+//   k_mc_scan_rows   one workgroup per plane a: exclusive scan of that plane's group sums, plane totals
 //   k_mc_scan_planes one workgroup: exclusive scan of the n plane totals (64-bit), grand totals
-//   k_mc_verts      in-row scan -> global vertex id per point, packed with its 3-bit crossed-edge mask into vert_info[n^3]
-//                   (the only per-point array, 4 B); writes position / normal / value of every vertex
-//   k_mc_tris       in-row scan -> triangle id; fetches the three vertex ids of every triangle from vert_info of the owning
-//                   grid points (corners of the same cube: L1/L2 hits); writes faces
-// Algorithmic bytes per grid point: 3 volume reads (4 B each, neighbour rows come from L2) + vert_info write + read = 20 B
+//   k_mc_compact     same walk + in-group scans -> global vertex id per point, packed with its 3-bit crossed-edge mask into
+//                    vert_info[n^3] (the only per-point array, 4 B), and one compact record per vertex / per triangle, parked in
+//                    the output buffers themselves
+//   k_mc_emit_verts  one thread per vertex: position / normal / value from its record
+//   k_mc_emit_tris   one thread per triangle: the three vertex ids from vert_info of the owning grid points (corners of the
+//                    same cube: L1/L2 hits)
+// Algorithmic bytes per grid point: 3 volume reads (4 B each; the a+1 plane comes from L2) + vert_info write + read = 20 B
 // -> 2.7 GB at 512^3 (+ the mesh itself).
 // The case table is include/p3d_mc_table.h (derived by tools/gen_mc_table.py, not copied from anywhere).
 #include <hip/hip_runtime.h>
@@ -24,15 +28,17 @@
 
 #define MC_T 256      // max threads per workgroup; a thread owns MC_PT consecutive points of the row
 #define MC_PT 4
-#define MC_MAXN 1024  // = MC_T * MC_PT: one workgroup covers a whole row
+#define MC_MAXN 1024  // = MC_T * MC_PT: one workgroup covers whole rows
+#define MC_G 8        // rows per workgroup
 
 struct McParams {
     const float* vol;
     int n;
     int flip0;
     float level;
-    unsigned* row_sum;             // [n*n] packed (tris << 16 | verts) per row (<= 5120 / 3072)
-    uint2* row_off;                // [n*n] exclusive (verts, tris) offsets of the row within its plane
+    int gpp;                       // row groups per plane = ceil(n / MC_G)
+    unsigned* row_sum;             // [n*gpp] packed (tris << 16 | verts) per row group (<= 40960 / 24576)
+    uint2* row_off;                // [n*gpp] exclusive (verts, tris) offsets of the group within its plane
     unsigned long long* plane;     // [2][n] plane totals, then exclusive plane offsets (verts / tris)
     unsigned long long* totals;    // [2]
     unsigned* vert_info;           // [n^3] (first vertex id of the point << 3) | crossed-edge mask
@@ -60,35 +66,38 @@ __device__ __forceinline__ void mc_load5(const float* r, int c, int n, float v[5
     v[4] = c + 4 < n ? r[c + 4] : 0.0f;
 }
 
-// The thread's MC_PT points c .. c+3 of row (a,b): crossed owned edges (bit 0/1/2: along c/b/a) and cube case (or -1),
-// f[0][j] = value at the point, f[1..3][j] = the (a,b+1), (a+1,b), (a+1,b+1) rows (0 past the border; masked by hb / ha).
-struct McTile {
-    float f[4][5];
-    unsigned cross[MC_PT];
-    int ccase[MC_PT];
-};
+// The volume rows of one group: f[r][0] = row (a, b0+r), f[r][1] = row (a+1, b0+r), r = 0..MC_G (the extra row closes the last
+// cubes); each holds the thread's points c .. c+4.  Rows past the border stay 0 and are masked by the callers' hb / ha.
+struct McGroup { float f[MC_G + 1][2][5]; };
 
 template <bool VEC>
-__device__ __forceinline__ void mc_tile(const McParams& p, int a, int b, int c, McTile& T) {
+__device__ __forceinline__ void mc_load_group(const McParams& p, int a, int b0, int c, McGroup& T) {
     const int n = p.n;
-    const bool hb = b + 1 < n, ha = a + 1 < n;
-    const float lv = p.level;
-    mc_load5<VEC>(mc_row_ptr(p, a, b), c, n, T.f[0]);
-    if (hb) mc_load5<VEC>(mc_row_ptr(p, a, b + 1), c, n, T.f[1]);
-    if (ha) mc_load5<VEC>(mc_row_ptr(p, a + 1, b), c, n, T.f[2]);
-    if (ha && hb) mc_load5<VEC>(mc_row_ptr(p, a + 1, b + 1), c, n, T.f[3]);
+    const bool ha = a + 1 < n;
 #pragma unroll
-    for (int j = 0; j < MC_PT; ++j) {
-        const bool valid = c + j < n, hc = c + j + 1 < n;
-        const bool i0 = T.f[0][j] > lv;
-        const bool ic = T.f[0][j + 1] > lv, ib = T.f[1][j] > lv, ia = T.f[2][j] > lv;
-        T.cross[j] = !valid ? 0u : (((hc && ic != i0) ? 1u : 0u) | ((hb && ib != i0) ? 2u : 0u) | ((ha && ia != i0) ? 4u : 0u));
-        // corner v at (da,db,dc) = (v>>2&1, v>>1&1, v&1): 0 self, 1 +c, 2 +b, 3 +b+c, 4 +a, 5 +a+c, 6 +a+b, 7 +a+b+c
-        T.ccase[j] = (hc && hb && ha)
-                         ? ((i0 ? 1 : 0) | (ic ? 2 : 0) | (ib ? 4 : 0) | (T.f[1][j + 1] > lv ? 8 : 0) | (ia ? 16 : 0) |
-                            (T.f[2][j + 1] > lv ? 32 : 0) | (T.f[3][j] > lv ? 64 : 0) | (T.f[3][j + 1] > lv ? 128 : 0))
-                         : -1;
+    for (int r = 0; r <= MC_G; ++r) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) T.f[r][0][i] = T.f[r][1][i] = 0.0f;
+        if (b0 + r < n) {  // uniform
+            mc_load5<VEC>(mc_row_ptr(p, a, b0 + r), c, n, T.f[r][0]);
+            if (ha) mc_load5<VEC>(mc_row_ptr(p, a + 1, b0 + r), c, n, T.f[r][1]);
+        }
     }
+}
+
+// point j (0..3) of row r of the group: crossed owned edges (bit 0/1/2: along c/b/a) and cube case (or -1)
+__device__ __forceinline__ void mc_point(const McParams& p, const McGroup& T, int a, int b, int r, int c, int j, unsigned& cross,
+                                         int& ccase) {
+    const int n = p.n;
+    const float lv = p.level;
+    const bool valid = c + j < n, hc = c + j + 1 < n, hb = b + 1 < n, ha = a + 1 < n;
+    const bool i0 = T.f[r][0][j] > lv, ic = T.f[r][0][j + 1] > lv, ib = T.f[r + 1][0][j] > lv, ia = T.f[r][1][j] > lv;
+    cross = !valid ? 0u : (((hc && ic != i0) ? 1u : 0u) | ((hb && ib != i0) ? 2u : 0u) | ((ha && ia != i0) ? 4u : 0u));
+    // corner v at (da,db,dc) = (v>>2&1, v>>1&1, v&1): 0 self, 1 +c, 2 +b, 3 +b+c, 4 +a, 5 +a+c, 6 +a+b, 7 +a+b+c
+    ccase = (hc && hb && ha) ? ((i0 ? 1 : 0) | (ic ? 2 : 0) | (ib ? 4 : 0) | (T.f[r + 1][0][j + 1] > lv ? 8 : 0) | (ia ? 16 : 0) |
+                                (T.f[r][1][j + 1] > lv ? 32 : 0) | (T.f[r + 1][1][j] > lv ? 64 : 0) |
+                                (T.f[r + 1][1][j + 1] > lv ? 128 : 0))
+                             : -1;
 }
 
 // exclusive scan of one unsigned per thread over the workgroup (<= 4 waves); *total = workgroup sum
@@ -119,50 +128,55 @@ __device__ __forceinline__ void mc_stage_ntri(unsigned char* l_ntri) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) l_ntri[i] = P3D_MC_NTRI[i];
 }
 
+// exclusive scans of MC_G per-thread counts (each <= 20, workgroup sums <= 5120) packed two per word; tot[r] = row totals
+__device__ __forceinline__ void mc_scan_rows8(const unsigned cnt[MC_G], unsigned excl[MC_G], unsigned tot[MC_G], unsigned* lds) {
+#pragma unroll
+    for (int k = 0; k < MC_G / 2; ++k) {
+        unsigned t;
+        const unsigned e = mc_wg_scan(cnt[2 * k] | (cnt[2 * k + 1] << 16), &t, lds);
+        excl[2 * k] = e & 0xffffu; excl[2 * k + 1] = e >> 16;
+        tot[2 * k] = t & 0xffffu; tot[2 * k + 1] = t >> 16;
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(MC_T) void k_mc_classify(McParams p) {
     __shared__ unsigned lds[4];
     __shared__ unsigned char l_ntri[256];
-    const int row = blockIdx.x, a = row / p.n, b = row - a * p.n;
+    const int grp = blockIdx.x, a = grp / p.gpp, b0 = (grp - a * p.gpp) * MC_G;
     const int c = MC_PT * threadIdx.x;
-    unsigned acc = 0;
-    McTile T;
-    if (c < p.n) mc_tile<VEC>(p, a, b, c, T);  // volume loads in flight while the table is staged
+    McGroup T;
+    if (c < p.n) mc_load_group<VEC>(p, a, b0, c, T);  // all volume loads in flight while the table is staged
     mc_stage_ntri(l_ntri);
     __syncthreads();
+    unsigned acc = 0;
     if (c < p.n) {
 #pragma unroll
-        for (int j = 0; j < MC_PT; ++j)
-            acc += (unsigned)__popc(T.cross[j]) | ((T.ccase[j] >= 0 ? (unsigned)l_ntri[T.ccase[j]] : 0u) << 16);
+        for (int r = 0; r < MC_G; ++r) {
+            if (b0 + r >= p.n) break;
+#pragma unroll
+            for (int j = 0; j < MC_PT; ++j) {
+                unsigned cross; int cs;
+                mc_point(p, T, a, b0 + r, r, c, j, cross, cs);
+                acc += (unsigned)__popc(cross) | ((cs >= 0 ? (unsigned)l_ntri[cs] : 0u) << 16);
+            }
+        }
     }
     unsigned total;
     mc_wg_scan(acc, &total, lds);
-    if (threadIdx.x == 0) p.row_sum[row] = total;
+    if (threadIdx.x == 0) p.row_sum[grp] = total;
 }
 
-// block = plane a; n <= 1024 rows, 4 per thread
+// block = plane a; gpp <= 128 row groups, one per thread
 __global__ __launch_bounds__(MC_T) void k_mc_scan_rows(McParams p) {
     __shared__ unsigned lds[MC_T / 64 + 1];
-    const int a = blockIdx.x;
-    const unsigned* rs = p.row_sum + (size_t)a * p.n;
-    unsigned v[4], t[4], sv = 0, st = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = 4 * threadIdx.x + k;
-        const unsigned x = i < p.n ? rs[i] : 0u;
-        v[k] = x & 0xffffu; t[k] = x >> 16;
-        sv += v[k]; st += t[k];
-    }
+    const int a = blockIdx.x, i = threadIdx.x;
+    const unsigned x = i < p.gpp ? p.row_sum[(size_t)a * p.gpp + i] : 0u;
     unsigned totv, tott;
-    unsigned ev = mc_wg_scan(sv, &totv, lds);
-    unsigned et = mc_wg_scan(st, &tott, lds);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = 4 * threadIdx.x + k;
-        if (i < p.n) p.row_off[(size_t)a * p.n + i] = make_uint2(ev, et);
-        ev += v[k]; et += t[k];
-    }
-    if (threadIdx.x == 0) { p.plane[a] = totv; p.plane[p.n + a] = tott; }
+    const unsigned ev = mc_wg_scan(x & 0xffffu, &totv, lds);
+    const unsigned et = mc_wg_scan(x >> 16, &tott, lds);
+    if (i < p.gpp) p.row_off[(size_t)a * p.gpp + i] = make_uint2(ev, et);
+    if (i == 0) { p.plane[a] = totv; p.plane[p.n + a] = tott; }
 }
 
 __global__ __launch_bounds__(MC_T) void k_mc_scan_planes(McParams p) {
@@ -207,142 +221,147 @@ __device__ __forceinline__ float mc_grad1(const McParams& p, int a, int b, int c
     return (hi - lo == 2) ? 0.5f * d : d;
 }
 
+// Pass C: the same streaming walk as k_mc_classify, now with the global offsets known: writes vert_info for every point and ONE
+// compact record per vertex and per triangle INTO THE OUTPUT BUFFERS THEMSELVES — values[vid] (as u32) = (point id << 2) | edge slot,
+// faces[3t] = point id of the cube, faces[3t+1] = case | (index of the triangle in its cube << 8) — so that the two emit kernels
+// run one thread per vertex / per triangle (dense, perfectly balanced; each thread reads its own record and overwrites it).
 template <bool VEC>
-__global__ __launch_bounds__(MC_T) void k_mc_verts(McParams p) {
-    __shared__ unsigned lds[4];
-    const int row = blockIdx.x, a = row / p.n, b = row - a * p.n;
-    const int c = MC_PT * threadIdx.x;
-    McTile T;
-    unsigned mine = 0;
-    if (c < p.n) {
-        mc_tile<VEC>(p, a, b, c, T);
-#pragma unroll
-        for (int j = 0; j < MC_PT; ++j) mine += (unsigned)__popc(T.cross[j]);
-    }
-    unsigned total;
-    const unsigned excl = mc_wg_scan(mine, &total, lds);
-    if (c >= p.n) return;
-    unsigned long long vid = p.plane[a] + p.row_off[row].x + excl;
-    unsigned info[MC_PT];
-    {
-        unsigned run = (unsigned)vid;
-#pragma unroll
-        for (int j = 0; j < MC_PT; ++j) { info[j] = (run << 3) | T.cross[j]; run += (unsigned)__popc(T.cross[j]); }
-    }
-    unsigned* vi = p.vert_info + (size_t)row * p.n + c;
-    if (VEC) *reinterpret_cast<uint4*>(vi) = make_uint4(info[0], info[1], info[2], info[3]);
-    else {
-#pragma unroll
-        for (int j = 0; j < MC_PT; ++j) if (c + j < p.n) vi[j] = info[j];
-    }
-    if (!mine) return;
-#pragma unroll
-    for (int j = 0; j < MC_PT; ++j) {
-        const unsigned cross = T.cross[j];
-        if (!cross) continue;
-        const int cj = c + j;
-        const float f0 = T.f[0][j];
-        float g0[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) g0[ax] = mc_grad1(p, a, b, cj, ax);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (!(cross & (1u << s))) continue;
-            const int a1 = a + (s == 2), b1 = b + (s == 1), c1 = cj + (s == 0);
-            const float f1 = s == 0 ? T.f[0][j + 1] : (s == 1 ? T.f[1][j] : T.f[2][j]);
-            const float t = (p.level - f0) / (f1 - f0);
-            float pos[3] = {(float)a, (float)b, (float)cj};  // (a, b, c) = skimage's (axis 0, 1, 2) vertex order
-            pos[2 - s] += t;
-            float g[3];
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const float g1 = mc_grad1(p, a1, b1, c1, ax);
-                g[ax] = __builtin_fmaf(t, g1 - g0[ax], g0[ax]);
-            }
-            // |g| through binary64: sqrt in double then rounding to float IS the correctly rounded float sqrt (53 >= 2*24+2);
-            // the f32 hardware sqrt is not.  normal = -g/|g| in (a,b,c) order: g[2] is d/da.
-            const float len2 = __builtin_fmaf(g[0], g[0], __builtin_fmaf(g[1], g[1], g[2] * g[2]));
-            const float len = (float)__dsqrt_rn((double)len2);
-            const bool ok = len > 0.0f;
-            float* V = p.verts + 3 * vid;
-            float* N = p.normals + 3 * vid;
-            V[0] = pos[0]; V[1] = pos[1]; V[2] = pos[2];
-            N[0] = ok ? -g[2] / len : 0.0f;
-            N[1] = ok ? -g[1] / len : 0.0f;
-            N[2] = ok ? -g[0] / len : 0.0f;
-            p.values[vid] = f0 > f1 ? f0 : f1;
-            ++vid;
-        }
-    }
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(MC_T) void k_mc_tris(McParams p) {
+__global__ __launch_bounds__(MC_T) void k_mc_compact(McParams p) {
     __shared__ unsigned lds[4];
     __shared__ unsigned char l_ntri[256];
-    __shared__ signed char l_tri[256 * P3D_MC_ROW];
-    const int row = blockIdx.x, a = row / p.n, b = row - a * p.n;
-    if (a + 1 >= p.n || b + 1 >= p.n) return;  // uniform: no cubes start on the last plane / row
+    const int grp = blockIdx.x, a = grp / p.gpp, b0 = (grp - a * p.gpp) * MC_G;
     const int c = MC_PT * threadIdx.x;
-    McTile T;
-    unsigned nt[MC_PT] = {0, 0, 0, 0}, mine = 0;
-    if (c < p.n) mc_tile<VEC>(p, a, b, c, T);
+    McGroup T;
+    unsigned cv[MC_G], ct[MC_G], ev[MC_G], et[MC_G], tv[MC_G], tt[MC_G];
+#pragma unroll
+    for (int r = 0; r < MC_G; ++r) cv[r] = ct[r] = 0;
+    if (c < p.n) mc_load_group<VEC>(p, a, b0, c, T);
     mc_stage_ntri(l_ntri);
     __syncthreads();
     if (c < p.n) {
 #pragma unroll
-        for (int j = 0; j < MC_PT; ++j) { nt[j] = T.ccase[j] >= 0 ? (unsigned)l_ntri[T.ccase[j]] : 0u; mine += nt[j]; }
-    }
-    unsigned total;
-    const unsigned excl = mc_wg_scan(mine, &total, lds);
-    if (!total) return;  // uniform: most rows of a real volume hold no surface -> the 4 KB triangle table is not staged
-    for (int i = threadIdx.x; i < 256 * P3D_MC_ROW / 4; i += blockDim.x)
-        reinterpret_cast<int*>(l_tri)[i] = reinterpret_cast<const int*>(&P3D_MC_TRI[0][0])[i];
-    __syncthreads();
-    if (!mine) return;
-    int* F = p.faces + 3 * (p.plane[p.n + a] + p.row_off[row].y + excl);
-    const size_t n = p.n;
+        for (int r = 0; r < MC_G; ++r) {
+            if (b0 + r >= p.n) break;
 #pragma unroll
-    for (int j = 0; j < MC_PT; ++j) {
-        if (!nt[j]) continue;
-        const size_t pid = (size_t)row * n + c + j;
-        const signed char* tri = l_tri + T.ccase[j] * P3D_MC_ROW;
-        for (unsigned t = 0; t < nt[j]; ++t) {
-            int id[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int e = tri[3 * t + k];
-                // lower corner of edge e: P3D_MC_EDGE[e][0] = 0,2,4,6, 0,1,4,5, 0,1,2,3 packed 3 bits each; slot = e >> 2
-                const int v0 = (int)((0x688b08d10ull >> (3 * e)) & 7), slot = e >> 2;
-                const size_t owner = pid + ((v0 >> 2) & 1) * n * n + ((v0 >> 1) & 1) * n + (v0 & 1);
-                const unsigned info = p.vert_info[owner];
-                id[k] = (int)((info >> 3) + __popc(info & ((1u << slot) - 1u)));
+            for (int j = 0; j < MC_PT; ++j) {
+                unsigned cross; int cs;
+                mc_point(p, T, a, b0 + r, r, c, j, cross, cs);
+                cv[r] += (unsigned)__popc(cross);
+                ct[r] += cs >= 0 ? (unsigned)l_ntri[cs] : 0u;
             }
-            F[0] = id[0]; F[1] = id[1]; F[2] = id[2];
-            F += 3;
         }
     }
+    mc_scan_rows8(cv, ev, tv, lds);
+    mc_scan_rows8(ct, et, tt, lds);
+    if (c >= p.n) return;
+    const uint2 off = p.row_off[grp];
+    unsigned long long vbase = p.plane[a] + off.x, tbase = p.plane[p.n + a] + off.y;
+    unsigned* vrec = reinterpret_cast<unsigned*>(p.values);
+#pragma unroll
+    for (int r = 0; r < MC_G; ++r) {
+        const int b = b0 + r;
+        if (b >= p.n) break;
+        unsigned vid = (unsigned)(vbase + ev[r]), tid = (unsigned)(tbase + et[r]);
+        vbase += tv[r]; tbase += tt[r];
+        const unsigned pid0 = ((unsigned)a * p.n + b) * p.n + c;
+        unsigned info[MC_PT];
+#pragma unroll
+        for (int j = 0; j < MC_PT; ++j) {
+            unsigned cross; int cs;
+            mc_point(p, T, a, b, r, c, j, cross, cs);
+            info[j] = (vid << 3) | cross;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (cross & (1u << s)) vrec[vid++] = ((pid0 + j) << 2) | (unsigned)s;
+            const unsigned nt = cs >= 0 ? (unsigned)l_ntri[cs] : 0u;
+            for (unsigned i = 0; i < nt; ++i, ++tid) {
+                p.faces[3 * (size_t)tid] = (int)(pid0 + j);
+                p.faces[3 * (size_t)tid + 1] = cs | (int)(i << 8);
+            }
+        }
+        unsigned* vi = p.vert_info + pid0;
+        if (VEC) *reinterpret_cast<uint4*>(vi) = make_uint4(info[0], info[1], info[2], info[3]);
+        else {
+#pragma unroll
+            for (int j = 0; j < MC_PT; ++j) if (c + j < p.n) vi[j] = info[j];
+        }
+    }
+}
+
+// one thread per vertex
+__global__ __launch_bounds__(256) void k_mc_emit_verts(McParams p, unsigned nverts) {
+    const unsigned vid = blockIdx.x * 256u + threadIdx.x;
+    if (vid >= nverts) return;
+    const unsigned rec = reinterpret_cast<const unsigned*>(p.values)[vid];
+    const unsigned pid = rec >> 2;
+    const int s = (int)(rec & 3u), n = p.n;
+    const int c = (int)(pid % (unsigned)n), ab = (int)(pid / (unsigned)n), b = ab % n, a = ab / n;
+    const int a1 = a + (s == 2), b1 = b + (s == 1), c1 = c + (s == 0);
+    const float f0 = mc_row_ptr(p, a, b)[c], f1 = mc_row_ptr(p, a1, b1)[c1];
+    const float t = (p.level - f0) / (f1 - f0);
+    float pos[3] = {(float)a, (float)b, (float)c};  // (a, b, c) = skimage's (axis 0, 1, 2) vertex order
+    pos[2 - s] += t;
+    float g[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const float g0 = mc_grad1(p, a, b, c, ax), g1 = mc_grad1(p, a1, b1, c1, ax);
+        g[ax] = __builtin_fmaf(t, g1 - g0, g0);
+    }
+    // |g| through binary64: sqrt in double then rounding to float IS the correctly rounded float sqrt (53 >= 2*24+2); the f32
+    // hardware sqrt is not.  normal = -g/|g| in (a,b,c) order: g[2] is d/da.
+    const float len2 = __builtin_fmaf(g[0], g[0], __builtin_fmaf(g[1], g[1], g[2] * g[2]));
+    const float len = (float)__dsqrt_rn((double)len2);
+    const bool ok = len > 0.0f;
+    float* V = p.verts + 3 * (size_t)vid;
+    float* N = p.normals + 3 * (size_t)vid;
+    V[0] = pos[0]; V[1] = pos[1]; V[2] = pos[2];
+    N[0] = ok ? -g[2] / len : 0.0f;
+    N[1] = ok ? -g[1] / len : 0.0f;
+    N[2] = ok ? -g[0] / len : 0.0f;
+    p.values[vid] = f0 > f1 ? f0 : f1;
+}
+
+// one thread per triangle
+__global__ __launch_bounds__(256) void k_mc_emit_tris(McParams p, unsigned ntris) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntris) return;
+    int* F = p.faces + 3 * (size_t)t;
+    const unsigned pid = (unsigned)F[0];
+    const int rec = F[1], cs = rec & 255, i = rec >> 8;
+    const size_t n = p.n;
+    int id[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = P3D_MC_TRI[cs][3 * i + k];
+        // lower corner of edge e: P3D_MC_EDGE[e][0] = 0,2,4,6, 0,1,4,5, 0,1,2,3 packed 3 bits each; slot = e >> 2
+        const int v0 = (int)((0x688b08d10ull >> (3 * e)) & 7), slot = e >> 2;
+        const size_t owner = pid + ((v0 >> 2) & 1) * n * n + ((v0 >> 1) & 1) * n + (v0 & 1);
+        const unsigned info = p.vert_info[owner];
+        id[k] = (int)((info >> 3) + __popc(info & ((1u << slot) - 1u)));
+    }
+    F[0] = id[0]; F[1] = id[1]; F[2] = id[2];
 }
 
 extern "C" {
 
 size_t p3d_mc_workspace_bytes(int n) {
     if (n < 2 || n > MC_MAXN) return 0;
-    const size_t nn = (size_t)n * n;
-    return 256 + 16 * (size_t)MC_MAXN + 12 * nn + 4 * nn * n;
+    const size_t nn = (size_t)n * n, ng = (size_t)n * ((n + MC_G - 1) / MC_G);
+    return 256 + 16 * (size_t)MC_MAXN + 12 * ((ng + 3) / 4 * 4) + 4 * nn * n;
 }
 
 static int mc_params(McParams& p, const float* vol, int n, int flip0, float level, void* workspace, size_t workspace_bytes) {
     if (!vol || !workspace) return P3D_E_ARG;
     if (n < 2 || n > MC_MAXN) return P3D_E_RANGE;
     if (workspace_bytes < p3d_mc_workspace_bytes(n) || ((uintptr_t)workspace & 15)) return P3D_E_WORKSPACE;
-    const size_t nn = (size_t)n * n;
     p.vol = vol; p.n = n; p.flip0 = flip0 ? 1 : 0; p.level = level;
+    p.gpp = (n + MC_G - 1) / MC_G;
+    const size_t ng = ((size_t)n * p.gpp + 3) / 4 * 4;  // keeps vert_info 16-byte aligned
     char* w = (char*)workspace;
     p.totals = (unsigned long long*)w;            w += 256;
     p.plane = (unsigned long long*)w;             w += 16 * (size_t)MC_MAXN;
-    p.row_off = (uint2*)w;                        w += 8 * nn;
-    p.row_sum = (unsigned*)w;                     w += 4 * nn;
+    p.row_off = (uint2*)w;                        w += 8 * ng;
+    p.row_sum = (unsigned*)w;                     w += 4 * ng;
     p.vert_info = (unsigned*)w;
     p.verts = p.normals = p.values = nullptr; p.faces = nullptr;
     return P3D_OK;
@@ -356,8 +375,8 @@ int p3d_mc_count_f32(const float* vol, int n, int flip0, float level, void* work
     if (!out_counts) return P3D_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const unsigned threads = (unsigned)(((n + MC_PT - 1) / MC_PT + 63) / 64 * 64);
-    if (n % 4 == 0 && ((uintptr_t)vol & 15) == 0) hipLaunchKernelGGL(k_mc_classify<true>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
-    else hipLaunchKernelGGL(k_mc_classify<false>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
+    if (n % 4 == 0 && ((uintptr_t)vol & 15) == 0) hipLaunchKernelGGL(k_mc_classify<true>, dim3((unsigned)(n * p.gpp)), dim3(threads), 0, s, p);
+    else hipLaunchKernelGGL(k_mc_classify<false>, dim3((unsigned)(n * p.gpp)), dim3(threads), 0, s, p);
     hipLaunchKernelGGL(k_mc_scan_rows, dim3((unsigned)n), dim3(MC_T), 0, s, p);
     hipLaunchKernelGGL(k_mc_scan_planes, dim3(1), dim3(MC_T), 0, s, p);
     hipError_t e = hipMemcpyAsync(out_counts, p.totals, 16, hipMemcpyDeviceToDevice, s);
@@ -378,13 +397,10 @@ int p3d_mc_emit_f32(const float* vol, int n, int flip0, float level, void* works
     p.verts = out_verts; p.normals = out_normals; p.values = out_values; p.faces = out_faces;
     hipStream_t s = (hipStream_t)stream;
     const unsigned threads = (unsigned)(((n + MC_PT - 1) / MC_PT + 63) / 64 * 64);
-    if (n % 4 == 0 && ((uintptr_t)vol & 15) == 0) {
-        hipLaunchKernelGGL(k_mc_verts<true>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
-        hipLaunchKernelGGL(k_mc_tris<true>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
-    } else {
-        hipLaunchKernelGGL(k_mc_verts<false>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
-        hipLaunchKernelGGL(k_mc_tris<false>, dim3((unsigned)(n * n)), dim3(threads), 0, s, p);
-    }
+    if (n % 4 == 0 && ((uintptr_t)vol & 15) == 0) hipLaunchKernelGGL(k_mc_compact<true>, dim3((unsigned)(n * p.gpp)), dim3(threads), 0, s, p);
+    else hipLaunchKernelGGL(k_mc_compact<false>, dim3((unsigned)(n * p.gpp)), dim3(threads), 0, s, p);
+    hipLaunchKernelGGL(k_mc_emit_verts, dim3((unsigned)((nverts + 255) / 256)), dim3(256), 0, s, p, (unsigned)nverts);
+    hipLaunchKernelGGL(k_mc_emit_tris, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, s, p, (unsigned)ntris);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? P3D_OK : (int)e;
 }
