@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE config c5: marching-cubes density grid N^3 (default 512^3 = 134 M points), the fused density-only query with the
+grid's slowest axis split into one contiguous slab per GPU, ONE RCCL gather of the sigma slabs to rank 0, iso-surface on rank 0.
+
+    python tools/bench_c5.py [--grid 512]                                                        # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_c5.py   # 8 GPUs
+Prints one JSON line on rank 0."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.distributed as dist
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", type=int, default=512)
+a = ap.parse_args()
+rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+torch.cuda.set_device(lrank)
+dev = torch.device("cuda", lrank)
+if "RANK" in os.environ:
+    dist.init_process_group("nccl", device_id=dev)
+import panic3d_amd as P
+from panic3d_amd import ops, sharding, volume
+import bench
+
+N = a.grid
+planes, raw, _, _ = bench.make_scene(dev, 0, 64, 20.0)  # same seed on every rank -> identical planes
+mlp = ops.prescale_mlp(*(x.to(dev) for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
+opts = ops.make_opts(dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=48, use_triplane=1), force_sigmoid=True)
+nhwc = ops.planes_to_nhwc(planes.to(dev))
+vs, org = 0.7 / (N - 1), -0.35
+lo, hi = sharding.partition(N, world, rank)  # slab of the slowest grid axis
+counts = [sharding.partition(N, world, r)[1] - sharding.partition(N, world, r)[0] for r in range(world)]
+
+
+def run():
+    sig = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts)
+    full = sharding.gather_frames(sig.reshape(hi - lo, N * N), counts, 0)
+    if rank != 0:
+        return None
+    dens = volume.sigma2density(full.reshape(N, N, N))
+    return ops.marching_cubes(dens, 0.5, flip0=True)
+
+
+def sync():
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    return time.perf_counter()
+
+
+run()
+t0 = sync()
+K = 3
+for _ in range(K):
+    out = run()
+t1 = sync()
+if rank == 0:
+    dt = (t1 - t0) / K
+    print(json.dumps({"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
+                      "verts": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
+if dist.is_initialized():
+    dist.destroy_process_group()
