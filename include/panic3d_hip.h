@@ -165,6 +165,13 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
 int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64_t inner, int act, float alpha, float gain,
                      float clamp, float* y, void* stream);
 
+/* sigma -> density of get_eg3d_volume with its two masks, one pass (_util/eg3d_metrics3d.py:65-69,153-163):
+ * d = 1 - exp(-softplus(sigma - 1)); cropmask[m] != 0 -> -1000; cull_thresh >= 0: the reference's cull mask is evaluated on the
+ * DENSITIES (sic): 1 - exp(-softplus(d - 1)) < cull_thresh -> -1000.  cropmask may be NULL; cull_thresh < 0: no cull.
+ * May run in place (out_density == sigma). */
+int p3d_sigma2density_f32(const float* sigma, const unsigned char* cropmask, int64_t M, float cull_thresh, float* out_density,
+                          void* stream);
+
 /* ---- iso-surface of the density grid on the device ---------------------------------------------------- */
 
 /* Replaces skimage.measure.marching_cubes(vol, level, spacing=(1,1,1), gradient_direction='descent', method='lewiner') as

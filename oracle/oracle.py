@@ -223,3 +223,13 @@ def marching_cubes(vol, level=0.5, flip0=False):
     if rc != 0:
         raise RuntimeError(f"or_mc_emit failed: {rc}")
     return verts, faces, normals, values
+
+
+def sigma2density(sigma, cropmask=None, cull=None):
+    """get_eg3d_volume's activation + masks on a flat sigma array (p3d_oracle_sigma2density)."""
+    sigma, ps = _f(sigma)
+    out = np.empty_like(sigma)
+    cm = None if cropmask is None else np.ascontiguousarray(cropmask, dtype=np.uint8)
+    lib().p3d_oracle_sigma2density(ps, None if cm is None else cm.ctypes.data_as(C.c_void_p), C.c_long(sigma.size),
+                                   C.c_float(-1.0 if cull is None else cull), out.ctypes.data_as(C.c_void_p))
+    return out

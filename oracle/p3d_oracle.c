@@ -485,6 +485,20 @@ int p3d_oracle_render(const float* planes, int N, int H, int W, const float* ray
 }
 
 /* expose the scalar functions for unit tests of the contract */
+/* sigma2density + crop / cull masks of get_eg3d_volume (_util/eg3d_metrics3d.py:65-69,153-163; cull_clouds_mask renderer.py:150-153
+ * applied to the densities, as the reference does) */
+void p3d_oracle_sigma2density(const float* sigma, const unsigned char* cropmask, long n, float cull_thresh, float* out) {
+    for (long i = 0; i < n; ++i) {
+        float d = 1.0f - or_exp_nonpos(-or_softplus(sigma[i] - 1.0f));
+        if (cropmask && cropmask[i]) d = -1000.0f;
+        if (cull_thresh >= 0.0f) {
+            float a2 = 1.0f - or_exp_nonpos(-or_softplus(d - 1.0f));
+            if (a2 < cull_thresh) d = -1000.0f;
+        }
+        out[i] = d;
+    }
+}
+
 void p3d_oracle_math(const float* x, long n, int which, float* y) {
     for (long i = 0; i < n; ++i)
         y[i] = which == 0 ? or_exp(x[i]) : which == 1 ? or_log1p01(x[i]) : which == 2 ? or_softplus(x[i]) : or_sigmoid(x[i]);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_bias_act_f32": (_I, [_P, _P, _L, _I, _L, _I, _F, _F, _F, _P, _P]),
+    "p3d_sigma2density_f32": (_I, [_P, _P, _L, _F, _P, _P]),
     "p3d_mc_workspace_bytes": (_Z, [_I]),
     "p3d_mc_count_f32": (_I, [_P, _I, _I, _F, _P, _Z, _P, _P]),
     "p3d_mc_emit_f32": (_I, [_P, _I, _I, _F, _P, _Z, _L, _L, _P, _P, _P, _P, _P]),

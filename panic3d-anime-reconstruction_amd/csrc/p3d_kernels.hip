@@ -672,6 +672,39 @@ __global__ void k_unify_perm(const float* __restrict__ tc, const float* __restri
     }
 }
 
+// sigma2density + the two masks of get_eg3d_volume (_util/eg3d_metrics3d.py:65-69,153-163), one HBM pass:
+//   d = 1 - exp(-softplus(sigma - 1));  cropmask -> d = -1000;  cull (sic, evaluated on the DENSITIES, renderer.py:150-153):
+//   1 - exp(-softplus(d - 1)) < cull_thresh -> d = -1000.   Contract math (include/p3d_numerics.h).
+P3D_DEV float p3d_density_of(float sigma, bool cropped, float cull_thresh) {
+    float d = 1.0f - p3d_exp_nonpos(-p3d_softplus(sigma - 1.0f));
+    if (cropped) d = -1000.0f;
+    if (cull_thresh >= 0.0f) {
+        const float a2 = 1.0f - p3d_exp_nonpos(-p3d_softplus(d - 1.0f));
+        if (a2 < cull_thresh) d = -1000.0f;
+    }
+    return d;
+}
+// four values per thread (16-byte loads / stores); the host passes vec = 1 only when sigma / out are 16-byte and cropmask
+// 4-byte aligned
+__global__ void k_sigma2density(const float* __restrict__ sigma, const unsigned char* __restrict__ cropmask, long long M,
+                                float cull_thresh, float* __restrict__ out, int vec) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= M) return;
+    if (vec && i + 3 < M) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sigma + i);
+        uchar4 c4 = make_uchar4(0, 0, 0, 0);
+        if (cropmask) c4 = *reinterpret_cast<const uchar4*>(cropmask + i);
+        float4 d4;
+        d4.x = p3d_density_of(s4.x, c4.x != 0, cull_thresh);
+        d4.y = p3d_density_of(s4.y, c4.y != 0, cull_thresh);
+        d4.z = p3d_density_of(s4.z, c4.z != 0, cull_thresh);
+        d4.w = p3d_density_of(s4.w, c4.w != 0, cull_thresh);
+        *reinterpret_cast<float4*>(out + i) = d4;
+    } else {
+        for (long long k = i; k < i + 4 && k < M; ++k) out[k] = p3d_density_of(sigma[k], cropmask && cropmask[k], cull_thresh);
+    }
+}
+
 // =====================================================================================================================
 // C ABI
 // =====================================================================================================================
@@ -858,6 +891,15 @@ int p3d_unify_perm_f32(const float* tc, const float* tf, int64_t NR, int Sc, int
     if (Sc < 1 || Sf < 0) return P3D_E_RANGE;
     hipLaunchKernelGGL(k_unify_perm, dim3((unsigned)((NR + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tc, tf,
                        (long long)NR, Sc, Sf, perm);
+    return p3d_check_launch();
+}
+
+int p3d_sigma2density_f32(const float* sigma, const unsigned char* cropmask, int64_t M, float cull_thresh, float* out_density,
+                          void* stream) {
+    if (!sigma || !out_density || M <= 0) return P3D_E_ARG;
+    const int vec = (((uintptr_t)sigma | (uintptr_t)out_density) & 15) == 0 && ((uintptr_t)cropmask & 3) == 0;
+    hipLaunchKernelGGL(k_sigma2density, dim3((unsigned)((M + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, sigma, cropmask,
+                       (long long)M, cull_thresh, out_density, vec);
     return p3d_check_launch();
 }
 

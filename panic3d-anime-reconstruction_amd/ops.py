@@ -150,6 +150,23 @@ def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, cr
     return (sigma, msk.bool()) if crop_limit is not None else sigma
 
 
+def sigma2density(sigma, cropmask=None, cull=None):
+    """get_eg3d_volume's activation and masks in one pass (eg3d_metrics3d.py:65-69,153-163): 1 - exp(-softplus(sigma - 1)),
+    -1000 where cropmask, then -1000 where the cull mask — evaluated on the densities, as the reference does — fires."""
+    sigma = _chk(sigma, "sigma")
+    out = torch.empty_like(sigma)
+    cm = None
+    if cropmask is not None:
+        cm = cropmask.to(torch.uint8).contiguous()
+        if cm.numel() != sigma.numel() or not cm.is_cuda:
+            raise RuntimeError("cropmask must be a CUDA tensor with one entry per sigma")
+    with torch.cuda.device(sigma.device):
+        rc = _lib.lib().p3d_sigma2density_f32(_p(sigma), _p(cm), sigma.numel(), np.float32(-1.0 if cull is None else cull), _p(out),
+                                              _stream())
+    _lib.check(rc, "p3d_sigma2density_f32")
+    return out
+
+
 def marching_cubes(vol, level, flip0=False):
     """Iso-surface of vol [n,n,n] (device, f32) at `level`, on the device (csrc/p3d_mcubes.hip; specification: DESIGN.md §4.5,
     case table include/p3d_mc_table.h).  flip0: vol is the un-flipped flat grid of grid_density (axis 0 is read reversed).

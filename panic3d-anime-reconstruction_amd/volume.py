@@ -55,11 +55,9 @@ def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None
     lim = None if triplane_crop is None else rk["box_warp"] / 2 - triplane_crop
     res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts, crop_limit=lim)
     sig, cropmask = res if lim is not None else (res, None)
-    dens = sigma2density(sig)
-    if cropmask is not None:  # triplane_crop_mask (renderer.py:138-149) on the sample points, applied to the DENSITIES
-        dens.masked_fill_(cropmask, -1e3)
-    if cull_clouds is not None:  # cull_clouds_mask applied to densities (sic)
-        dens.masked_fill_(sigma2density(dens) < cull_clouds, -1e3)
+    # activation + triplane_crop_mask (renderer.py:138-149, on the sample points, applied to the DENSITIES) + cull_clouds_mask
+    # (applied to the densities, sic) in one pass over the grid
+    dens = ops.sigma2density(sig, cropmask, cull_clouds)
     return {"sigmas": sig, "densities": dens}
 
 

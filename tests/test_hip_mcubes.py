@@ -138,7 +138,7 @@ def test_mesh_flow_colors(hip):
         mc = hip.volume.mesh(G, ws, {}, resolution=N, level=level)
         pts = hip.volume.create_samples(N, cube_length=0.7)[0].cuda()
         out = G.sample_mixed(pts.contiguous(), None, ws, {}, noise_mode="const")
-        dens = hip.volume.to_volume(hip.volume.sigma2density(out["sigma"]), N)[0, 0].contiguous()
+        dens = hip.volume.to_volume(hip.ops.sigma2density(out["sigma"]), N)[0, 0].contiguous()
         rgbs = hip.volume.to_volume(out["rgb"], N)[0, :3].contiguous()
         ref = hip.volume.marching_cubes(dens, rgbs, 0.7, level=level)
     assert len(mc["faces"]) > 100 and mc["colors"].shape == (len(mc["verts"]), 3)

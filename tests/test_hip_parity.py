@@ -343,3 +343,18 @@ def test_render_random_configs_bit_exact(hip, oracle, seed):
     for name, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
         a = a.cpu().numpy()
         assert np.array_equal(a, b, equal_nan=True), (name, seed, float(np.nanmax(np.abs(a - b))))
+
+
+def test_sigma2density_bit_exact(hip, oracle):
+    """get_eg3d_volume's activation + crop / cull masks in one pass (p3d_sigma2density_f32) against the oracle, bit for bit,
+    incl. the quirk that the cull mask is evaluated on the densities; and against the torch formulation to 1e-6."""
+    rng = np.random.default_rng(3)
+    sigma = (rng.standard_normal(100003) * 8).astype(np.float32)
+    sigma[:5] = [-1000.0, 1000.0, 0.0, 1.0, -0.0]
+    crop = rng.integers(0, 2, sigma.size).astype(np.uint8)
+    for cm, cull in ((None, None), (crop, None), (None, 0.5), (crop, 0.37)):
+        got = hip.ops.sigma2density(dev(sigma), None if cm is None else dev(cm).bool(), cull).cpu().numpy()
+        assert np.array_equal(got, oracle.sigma2density(sigma, cm, cull))
+    plain = hip.ops.sigma2density(dev(sigma)).cpu()
+    ref = 1 - torch.exp(-torch.nn.functional.softplus(torch.from_numpy(sigma) - 1))
+    assert (plain - ref).abs().max() < 1e-6

@@ -36,7 +36,7 @@ def run():
     full = sharding.gather_frames(sig.reshape(hi - lo, N * N), counts, 0)
     if rank != 0:
         return None
-    dens = volume.sigma2density(full.reshape(N, N, N))
+    dens = ops.sigma2density(full.reshape(N, N, N))
     return ops.marching_cubes(dens, 0.5, flip0=True)
 
 

@@ -28,7 +28,7 @@ def timed(fn, reps=3):
 
 
 sig, t_grid = timed(lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts))
-dens, t_act = timed(lambda: volume.sigma2density(sig))
+dens, t_act = timed(lambda: ops.sigma2density(sig))
 vol = dens.reshape(N, N, N)
 level = 0.5
 (v, f, nr, va), t_mc = timed(lambda: ops.marching_cubes(vol, level, flip0=True))
