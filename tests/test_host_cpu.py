@@ -42,6 +42,16 @@ def test_cabi_argument_errors_without_gpu(P):
     assert L.p3d_triplane_decode_f32(None, 1, 8, 8, None, 1, None, None, None, None, C.byref(o), None, None, None) == -1
     assert L.p3d_sample_stratified_f32(0.5, 1.5, 0.02, 48, None, 1, None, None) == -1
     assert L.p3d_importance_f32(None, None, 0, 48, 48, None, None, None, None) == -1
+    assert L.p3d_sigma2density_f32(None, None, 8, -1.0, None, None) == -1
+    assert L.p3d_mc_workspace_bytes(1) == 0 and L.p3d_mc_workspace_bytes(1025) == 0 and L.p3d_mc_workspace_bytes(64) > 4 * 64 ** 3
+    assert L.p3d_mc_count_f32(None, 8, 0, 0.5, None, 0, None, None) == -1
+    assert L.p3d_conv_weights_to_f16(None, 4, 16, 3, None, None) == -1
+    fake = C.c_void_p(16)  # never dereferenced: the range checks come first
+    assert L.p3d_conv_weights_to_f16(fake, 4, 16, 2, fake, None) == -2  # ks must be 1 or 3
+    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 24, 8, 8, fake, fake, 8, 3, fake, 1, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
+                                      fake, 1 << 20, None) == -2  # I % 16 != 0: use the fp32 entry point
+    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 32, 8, 8, fake, None, 8, 3, fake, 1, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
+                                      fake, 1 << 20, None) == -1  # no f16 weights
 
 
 def test_opts_match_oracle(P, oracle):
