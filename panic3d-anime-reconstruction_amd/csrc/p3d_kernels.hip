@@ -70,6 +70,15 @@ struct DecodeParams {
     P3dDecodeCfg cfg;
 };
 
+// fmodf(a, b) for finite a >= 0, b > 0 with a / b < 2^24 — exactly C's fmodf there, without its generic exponent loop:
+// q = trunc(RN(a/b)) is floor(a/b) or one more (rounding is monotonic and integers are representable); a - q*b is then exactly
+// representable (a multiple of ulp(b), magnitude < b), so the fma returns it without rounding and one conditional add fixes q+1.
+P3D_DEV float p3d_fmod_pos(float a, float b) {
+    const float q = __builtin_truncf(a / b);
+    const float r = __builtin_fmaf(-q, b, a);
+    return r < 0.0f ? r + b : r;
+}
+
 template <bool WANT_RGB>
 __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
     __shared__ __attribute__((aligned(16))) float lds[P3D_LDS_MLP_FLOATS];
@@ -82,7 +91,8 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
     // grid-stride over tiles of 32 points; a tile never straddles two images
     for (long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave; tile < p.ntiles;
          tile += (long long)gridDim.x * P3D_WAVES_PER_WG) {
-        long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
+        long long n = 0, tl = tile;
+        if (p.tiles_per_img != p.ntiles) { n = tile / p.tiles_per_img; tl = tile - n * p.tiles_per_img; }  // uniform; 1 image: no 64-bit division
         long long m = tl * 32 + j;
         bool active = m < p.M;
         long long mc = active ? m : p.M - 1;
@@ -90,23 +100,35 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
         const float* base = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
         auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
         float px, py, pz;
+        bool skip = false;
         if (p.coords) {
             const float* c = p.coords + ((size_t)n * p.M + mc) * 3;
             px = c[0]; py = c[1]; pz = c[2];
         } else {  // the same float arithmetic as the reference's create_samples (float division: fractional carries are kept)
-            const long long idx = p.grid_lo + mc;
+            // idx < grid_n^3 <= 2^31 (the host checks grid_n <= 1290): 32-bit index arithmetic; (float)idx rounds like torch's
+            const unsigned idx = (unsigned)(p.grid_lo + mc);
             const float fn = (float)p.grid_n, f = (float)idx;
-            const float s2 = (float)(idx % p.grid_n);
+            const float s2 = (float)(idx % (unsigned)p.grid_n);
             const float q1 = f / fn;
-            const float s1 = __builtin_fmodf(q1, fn);
-            const float s0 = __builtin_fmodf(q1 / fn, fn);
+            const float s1 = p3d_fmod_pos(q1, fn);
+            const float s0 = p3d_fmod_pos(q1 / fn, fn);
             px = s0 * p.vsize + p.goff0; py = s1 * p.vsize + p.goff1; pz = s2 * p.vsize + p.goff2;
-            if (p.out_cropmask && active && h == 0)
-                p.out_cropmask[m] = (__builtin_fabsf(px) > p.mask_limit || __builtin_fabsf(pz) > p.mask_limit) ? 1 : 0;
+            if (p.out_cropmask) {
+                const bool cropped = __builtin_fabsf(px) > p.mask_limit || __builtin_fabsf(pz) > p.mask_limit;
+                if (active && h == 0) p.out_cropmask[m] = cropped ? 1 : 0;
+                if (p.cfg.flags & P3D_FLAG_SKIP_CROPPED) skip = cropped;
+            }
         }
         float sigma;
         f32x16 rgb;
-        p3d_decode_wave<WANT_RGB>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb);
+        // P3D_FLAG_SKIP_CROPPED (grid mode): a cropped point's density is -1000 whatever the network says
+        // (eg3d_metrics3d.py:155-159), so it is not decoded: whole wavefronts are skipped, single lanes fetch nothing
+        if (__builtin_amdgcn_ballot_w64(active && !skip) == 0) {
+            if (active && h == 0) p.out_sigma[(size_t)n * p.M + m] = -1000.0f;
+            continue;
+        }
+        p3d_decode_wave<WANT_RGB>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb, !skip);
+        if (skip) sigma = -1000.0f;
         if (active) {
             size_t o = (size_t)n * p.M + m;
             if (h == 0) p.out_sigma[o] = sigma;
@@ -761,7 +783,8 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
                          float off1, float off2, const float* w0, const float* b0, const float* w1, const float* b1,
                          const p3d_opts* opts, float* out_sigma, unsigned char* out_cropmask, float mask_limit, void* stream) {
     if (!planes || !w0 || !b0 || !w1 || !b1 || !opts || !out_sigma || grid_n <= 1 || lo < 0 || hi <= lo) return P3D_E_ARG;
-    if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL || hi > (int64_t)grid_n * grid_n * grid_n) return P3D_E_RANGE;
+    if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL || hi > (int64_t)grid_n * grid_n * grid_n || grid_n > 1290)
+        return P3D_E_RANGE;  // grid_n^3 < 2^31: the kernel's index arithmetic is 32-bit
     DecodeParams p;
     p.planes = planes; p.coords = nullptr; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.out_sigma = out_sigma; p.out_rgb = nullptr; p.out_cropmask = out_cropmask; p.mask_limit = mask_limit; p.M = hi - lo; p.H = H; p.W = W;
@@ -770,7 +793,10 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     p.cfg = make_cfg(opts);
     p.grid_n = grid_n; p.grid_lo = lo; p.vsize = voxel_size; p.goff0 = off0; p.goff1 = off1; p.goff2 = off2;
     long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    // grid-stride beyond 16 workgroups per CU; an ODD workgroup count, so that the stride (4 tiles per workgroup) is not a
+    // multiple of the tiles per grid row: with P3D_FLAG_SKIP_CROPPED the masked ends of every row would otherwise always fall
+    // on the same waves (measured: 10.7 ms instead of the expected ~7.5 at 512^3 with half of the grid masked)
+    if (blocks > 256 * 16 - 1) blocks = 256 * 16 - 1;
     hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
     return p3d_check_launch();
 }

@@ -130,10 +130,13 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     return sigma, rgb
 
 
-def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None):
+def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None, skip_cropped=False):
     """Density-only decode of flat indices [lo, hi) of the reference's grid_n^3 sample grid (create_samples), the points
     generated inside the kernel.  planes_nhwc [1,3,H,W,32] -> sigma [1, hi-lo, 1]; with crop_limit also the bool mask
-    [1, hi-lo, 1] of triplane_crop_mask (|x| or |z| beyond the limit) evaluated on the same generated points."""
+    [1, hi-lo, 1] of triplane_crop_mask (|x| or |z| beyond the limit) evaluated on the same generated points.
+    skip_cropped: do not decode masked points (sigma = -1000 there): exact for the densities, which are overwritten anyway."""
+    if skip_cropped and crop_limit is not None:
+        opts = _with_flag(opts, _lib.P3D_FLAG_SKIP_CROPPED)
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     if planes_nhwc.shape[0] != 1:
         raise RuntimeError("grid_density renders one subject at a time")

@@ -38,9 +38,10 @@ def sigma2density(sigma):  # eg3d_metrics3d.py:65-69
 
 
 def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None, cull_clouds=None, lo=0, hi=None,
-                 planes=None, **synthesis_kwargs):
+                 planes=None, skip_cropped=False, **synthesis_kwargs):
     """sigma / density for flat grid indices [lo, hi) of the resolution^3 grid, on the device: dict(sigmas, densities)
-    of shape [1, hi-lo, 1].  `planes` (NCHW [1,3,32,H,W]) skips the backbone."""
+    of shape [1, hi-lo, 1].  `planes` (NCHW [1,3,32,H,W]) skips the backbone.  skip_cropped: the points triplane_crop masks
+    (about half of the grid at the released crop of 0.1) are not decoded — identical densities, their `sigmas` read -1000."""
     rk = G.rendering_kwargs
     dev = ws.device
     if planes is None:
@@ -53,7 +54,8 @@ def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None
     origin = np.array([0, 0, 0]) - rk["box_warp"] / 2
     vs = rk["box_warp"] / (resolution - 1)
     lim = None if triplane_crop is None else rk["box_warp"] / 2 - triplane_crop
-    res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts, crop_limit=lim)
+    res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts, crop_limit=lim,
+                           skip_cropped=skip_cropped)
     sig, cropmask = res if lim is not None else (res, None)
     # activation + triplane_crop_mask (renderer.py:138-149, on the sample points, applied to the DENSITIES) + cull_clouds_mask
     # (applied to the densities, sic) in one pass over the grid
@@ -117,7 +119,8 @@ def mesh(G, ws, cond, resolution=256, level=0.5, triplane_crop=None, cull_clouds
     rk = G.rendering_kwargs
     if planes is None:
         planes = G._planes(ws, cond, **({"noise_mode": "const"} | synthesis_kwargs))
-    g = density_grid(G, ws, cond, resolution, triplane_crop=triplane_crop, cull_clouds=cull_clouds, planes=planes)
+    g = density_grid(G, ws, cond, resolution, triplane_crop=triplane_crop, cull_clouds=cull_clouds, planes=planes,
+                     skip_cropped=True)  # only the densities are used below
     dens = g["densities"].reshape(resolution, resolution, resolution)
     mlp, opts = decoder_params(G.decoder), G.renderer._opts(rk, G.decoder)
     nhwc = G.renderer._nhwc(planes)

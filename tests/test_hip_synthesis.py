@@ -234,6 +234,12 @@ def test_density_grid(hip):
         assert (got - dens)[same].abs().max() < 1e-6
         vol = hip.volume.to_volume(out["densities"], N)
         assert vol.shape == (1, 1, N, N, N)
+        # skip_cropped: masked points are not decoded — the densities are identical, the sigmas of masked points read -1000
+        sk = hip.volume.density_grid(G, ws, {}, resolution=N, triplane_crop=0.1, cull_clouds=0.5, skip_cropped=True)
+        assert torch.equal(sk["densities"], out["densities"])
+        cropped = (pts[..., 0].abs() > 0.25) | (pts[..., 2].abs() > 0.25)
+        assert 0.3 < cropped.float().mean() < 0.7
+        assert torch.equal(sk["sigmas"][~cropped], out["sigmas"][~cropped]) and (sk["sigmas"][cropped] == -1000).all()
         half = hip.volume.density_grid(G, ws, {}, resolution=N, lo=0, hi=N ** 3 // 2)
         assert torch.equal(half["sigmas"], out["sigmas"][:, :N ** 3 // 2])
 

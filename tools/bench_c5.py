@@ -11,6 +11,7 @@ import numpy as np, torch, torch.distributed as dist
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=512)
+ap.add_argument("--crop", type=float, default=None, help="triplane_crop (generate.py uses 0.1): masked points are not decoded")
 a = ap.parse_args()
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(lrank)
@@ -32,11 +33,15 @@ counts = [sharding.partition(N, world, r)[1] - sharding.partition(N, world, r)[0
 
 
 def run():
-    sig = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts)
+    if a.crop is None:
+        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts), None
+    else:
+        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts, crop_limit=0.35 - a.crop, skip_cropped=True)
     full = sharding.gather_frames(sig.reshape(hi - lo, N * N), counts, 0)
+    fmsk = None if msk is None else sharding.gather_frames(msk.to(torch.uint8).reshape(hi - lo, N * N), counts, 0)
     if rank != 0:
         return None
-    dens = ops.sigma2density(full.reshape(N, N, N))
+    dens = ops.sigma2density(full.reshape(N, N, N), None if fmsk is None else fmsk.reshape(N, N, N), None)
     return ops.marching_cubes(dens, 0.5, flip0=True)
 
 
@@ -55,7 +60,7 @@ for _ in range(K):
 t1 = sync()
 if rank == 0:
     dt = (t1 - t0) / K
-    print(json.dumps({"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
+    print(json.dumps({"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "triplane_crop": a.crop, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
                       "verts": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
 if dist.is_initialized():
     dist.destroy_process_group()

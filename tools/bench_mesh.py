@@ -28,11 +28,14 @@ def timed(fn, reps=3):
 
 
 sig, t_grid = timed(lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts))
+(_, msk), t_grid_crop = timed(lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts, crop_limit=0.25, skip_cropped=True))
+(_, _), t_grid_crop_noskip = timed(lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts, crop_limit=0.25))
 dens, t_act = timed(lambda: ops.sigma2density(sig))
 vol = dens.reshape(N, N, N)
 level = 0.5
 (v, f, nr, va), t_mc = timed(lambda: ops.marching_cubes(vol, level, flip0=True))
 t0 = time.perf_counter(); host = {k: x.cpu().numpy() for k, x in dict(verts=v, faces=f, normals=nr, values=va).items()}; t_d2h = (time.perf_counter() - t0) * 1e3
-print(json.dumps({"grid": N, "points": N ** 3, "grid_density_ms": t_grid, "sigma2density_ms": t_act, "marching_cubes_ms": t_mc,
+print(json.dumps({"grid": N, "points": N ** 3, "grid_density_ms": t_grid, "grid_density_crop0.1_skip_ms": t_grid_crop, "grid_density_crop0.1_noskip_ms": t_grid_crop_noskip,
+                  "cropped_fraction": float(msk.float().mean()), "sigma2density_ms": t_act, "marching_cubes_ms": t_mc,
                   "mesh_d2h_ms": t_d2h, "verts": len(v), "faces": len(f), "mesh_MB": sum(x.nbytes for x in host.values()) / 1e6,
                   "mc_GBps_algorithmic": 20.0 * N ** 3 / (t_mc * 1e-3) / 1e9, "volume_MB_kept_on_device": 4 * N ** 3 / 1e6}))
