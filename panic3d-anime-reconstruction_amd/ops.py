@@ -150,7 +150,7 @@ def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, cr
                                               _p(b0), _p(w1), _p(b1), C.byref(opts), _p(sigma), _p(msk),
                                               np.float32(crop_limit if crop_limit is not None else 0.0), _stream())
     _lib.check(rc, "p3d_grid_density_f32")
-    return (sigma, msk.bool()) if crop_limit is not None else sigma
+    return (sigma, msk.view(torch.bool)) if crop_limit is not None else sigma  # the kernel writes 0 / 1 bytes: no conversion pass
 
 
 def sigma2density(sigma, cropmask=None, cull=None):
@@ -160,7 +160,8 @@ def sigma2density(sigma, cropmask=None, cull=None):
     out = torch.empty_like(sigma)
     cm = None
     if cropmask is not None:
-        cm = cropmask.to(torch.uint8).contiguous()
+        cm = cropmask.contiguous()
+        cm = cm.view(torch.uint8) if cm.dtype == torch.bool else cm.to(torch.uint8)  # bool is one 0 / 1 byte: reinterpret
         if cm.numel() != sigma.numel() or not cm.is_cuda:
             raise RuntimeError("cropmask must be a CUDA tensor with one entry per sigma")
     with torch.cuda.device(sigma.device):

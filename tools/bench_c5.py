@@ -38,7 +38,7 @@ def run():
     else:
         sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts, crop_limit=0.35 - a.crop, skip_cropped=True)
     full = sharding.gather_frames(sig.reshape(hi - lo, N * N), counts, 0)
-    fmsk = None if msk is None else sharding.gather_frames(msk.to(torch.uint8).reshape(hi - lo, N * N), counts, 0)
+    fmsk = None if msk is None else sharding.gather_frames(msk.view(torch.uint8).reshape(hi - lo, N * N), counts, 0)
     if rank != 0:
         return None
     dens = ops.sigma2density(full.reshape(N, N, N), None if fmsk is None else fmsk.reshape(N, N, N), None)
