@@ -36,6 +36,7 @@ extern "C" {
 #define P3D_FLAG_FORCE_SIGMOID 8 /* OSGDecoder.force_sigmoid     (training/triplane.py:539-542) */
 #define P3D_FLAG_WHITE_BACK 16   /* rendering_options.white_back (ray_marcher.py:52-53) */
 #define P3D_FLAG_NO_EARLY_OUT 32 /* p3d_render_f32: disable the exact early-outs (decode every sample; measurement / tests) */
+#define P3D_FLAG_NO_PAIR 256 /* p3d_render_f32: never use the small-launch kernel (16 rays x 2 samples per wave); tests */
 #define P3D_FLAG_SKIP_CROPPED 128 /* p3d_grid_density_f32 with out_cropmask: points whose crop mask fires are not decoded and get
                                      out_sigma = -1000 (get_eg3d_volume overwrites their density anyway, eg3d_metrics3d.py:155-159) */
 #define P3D_FLAG_SHARED_PLANES 64 /* planes holds ONE image [1][3][H][W][32] shared by all N batches of rays / points (many

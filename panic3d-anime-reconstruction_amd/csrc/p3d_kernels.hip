@@ -536,6 +536,284 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     }
 }
 
+// =====================================================================================================================
+// k_render_pair: the same algorithm for SMALL launches (fewer 32-ray tiles than the chip has SIMDs, e.g. the pipeline's single
+// 128^2-ray views: 512 tiles on 1024 SIMDs, each wave alone on its SIMD and ALU-bound at ~4.7 us per decode step).  A wave owns
+// 16 rays and decodes TWO consecutive samples of every ray per step: lane j = ray (j & 15) x sample slot (j >> 4) x channel half,
+// so a launch makes twice as many waves, each with half as many decode steps.  Everything per ray (depth rows in LDS, marcher,
+// cdf, inverse-CDF draws, sort, merge, compositing) is executed identically by both slots of a ray — same inputs, same order,
+// same results, so the arithmetic contract and the accumulation order are untouched — and only the decode differs: after
+// it the two slots exchange sigma / skipped flag / their 16 colour channels (ds_bpermute), then both consume sample A and
+// sample B in order.  Slot 0 writes the outputs.  No dumps on this path (the host falls back to k_render for them).
+// =====================================================================================================================
+template <int NF>
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(RenderParams p) {  // 1 workgroup per CU is all a small launch has: up to 512 VGPRs
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int jr = j & 15, slot = j >> 4;
+    const int nwaves = blockDim.x >> 6;
+    long long tile = (long long)blockIdx.x * nwaves + wave;  // 16-ray tiles
+    if (tile >= p.ntiles) return;  // no workgroup barrier below this line
+    float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;
+
+    const int Sc = p.Sc, Sf = p.Sf, S = Sc + Sf;
+    long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
+    long long r;
+    if (p.tile_w > 0) {  // 4x4 pixel tile, Morton lane order
+        long long ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
+        const int lx = (jr & 1) | ((jr >> 1) & 2), ly = ((jr >> 1) & 1) | ((jr >> 2) & 2);
+        r = (ty * 4 + ly) * p.tile_w + tx * 4 + lx;
+    } else {
+        r = tl * 16 + jr;
+    }
+    const bool active = r < p.R;
+    const long long rc = active ? r : p.R - 1;
+    const size_t ray = (size_t)n * p.R + rc;
+
+    P3dPlaneGeom g;
+    g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
+    g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
+    unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
+    const float* pbase = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
+    const P3dDecodeCfg cfg = p.cfg;
+    const bool early = !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);
+    const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0;
+    int ndec = 0;
+    const int laneA = jr + 32 * h, laneB = laneA + 16;  // the two slots of this lane's ray (same channel half)
+
+    const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
+    const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+
+    // LDS rows of this wave: row(i)[jr]; both slots of a ray write the same values
+    float* tcA = wl;
+    float* wcA = tcA + Sc * 32;
+    float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;
+
+    bool unsorted = false;
+    {
+        const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
+        const float* jit = p.jitter + ray * Sc;
+        float prev = -__builtin_inff();
+        for (int i = 0; i < Sc; ++i) {
+            float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
+            float t = lin + jit[i] * p.depth_delta;
+            tcA[i * 32 + jr] = t;
+            unsorted |= (t < prev);
+            prev = t;
+        }
+    }
+    float tmin = __builtin_inff(), tmax = -__builtin_inff();
+    auto is_cropped = [&](float px, float pz) {
+        return f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+    };
+    if (Sf > 0) {
+        // ---- coarse pass, two samples per step
+        MarchState st;
+        st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+        for (int i = 0; i < Sc; i += 2) {
+            const bool haveB = i + 1 < Sc;  // uniform
+            const float tA = tcA[i * 32 + jr], tB = tcA[(haveB ? i + 1 : i) * 32 + jr];
+            const float t = slot ? tB : tA;
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            float sigma = P3D_SIGMA_MASKED;
+            bool skip = false, live = true;
+            if (early) {
+                live = !(is_cropped(px, pz) || st.Td < 1e-60);  // slot 1: Td before sample A's interval — conservative, still exact
+                skip = __builtin_amdgcn_ballot_w64(live) == 0;
+            }
+            if (!skip) {
+                f32x16 dummy;
+                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                ndec += 1;
+            }
+            const float sA = __shfl(sigma, laneA, 64), sB = __shfl(sigma, laneB, 64);
+            if (i > 0) {
+                float tm;
+                wcA[(i - 1) * 32 + jr] = p3d_march_weight(st, tA, sA, tm);
+            }
+            st.prev_t = tA; st.prev_sigma = sA;
+            if (haveB) {
+                float tm;
+                wcA[i * 32 + jr] = p3d_march_weight(st, tB, sB, tm);
+                st.prev_t = tB; st.prev_sigma = sB;
+            }
+        }
+        const int Ns = Sc - 3;
+        {
+            double sum = 0.0;
+            float wa = wcA[0 * 32 + jr], wb = wcA[1 * 32 + jr];
+            for (int jj = 0; jj < Ns; ++jj) {
+                float wc = wcA[(jj + 2) * 32 + jr];
+                float m1 = __builtin_fmaxf(wa, wb), m2 = __builtin_fmaxf(wb, wc);
+                float v = ((m1 + m2) * 0.5f + 0.01f) + 1e-5f;
+                sum += (double)v;
+                wcA[(jj + 1) * 32 + jr] = v;
+                wa = wb; wb = wc;
+            }
+            float fsum = (float)sum;
+            double acc = 0.0;
+            wcA[jr] = 0.0f;
+            for (int jj = 0; jj < Ns; ++jj) {
+                float pdf = wcA[(jj + 1) * 32 + jr] / fsum;
+                acc += (double)pdf;
+                wcA[(jj + 1) * 32 + jr] = (float)acc;
+            }
+        }
+        const float* uu = p.u + ray * Sf;
+        if constexpr (NF > 0) {
+            float tf[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                tf[i] = __builtin_inff();
+                if (i < Sf) {
+                    int k;
+                    tf[i] = p3d_inverse_cdf(wcA, tcA, Ns, jr, uu[i], k);
+                }
+            }
+            p3d_sort_network<NF>(tf);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (i < Sf) tfA[i * 32 + jr] = tf[i];
+        } else {
+            // the generic path sorts in LDS: only slot 0 may move the keys (both slots of a ray share the column)
+            float* tmpA = tfA;
+            for (int i = 0; i < Sf; ++i) {
+                int k;
+                float v = p3d_inverse_cdf(wcA, tcA, Ns, jr, uu[i], k);
+                tmpA[i * 32 + jr] = v;
+            }
+            if (slot == 0 && h == 0) p3d_lds_insertion_sort(tfA, Sf, jr);
+        }
+        if (__builtin_amdgcn_ballot_w64(unsorted) != 0 && slot == 0 && h == 0) p3d_lds_insertion_sort(tcA, Sc, jr);
+    }
+    // ---- final pass: two merged samples per step
+    MarchState st;
+    st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+    f32x16 C, prev_rgb;
+    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
+    {
+        int ci = 0, fi = 0;
+        float ta = tcA[jr], tb = (Sf > 0) ? tfA[jr] : __builtin_inff();
+        bool prev_skipped = false;
+        auto next_depth = [&]() {  // unify_samples' merge: ties take the coarse sample first (stable sort)
+            const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+            const float t = take_c ? ta : tb;
+            ci += take_c ? 1 : 0;
+            fi += take_c ? 0 : 1;
+            if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + jr];
+            else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + jr];
+            tmin = __builtin_fminf(tmin, t);
+            tmax = __builtin_fmaxf(tmax, t);
+            return t;
+        };
+        // the second half of k_render's loop body, for one sample whose decode (or skip) has already happened
+        auto consume = [&](int m, float t, float px, float py, float pz, float sigma, f32x16 rgb, bool skipped) {
+            if (m > 0) {
+                float tm;
+                float w = p3d_march_weight(st, t, sigma, tm);
+                if (early) {
+                    if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
+                        float s2;
+                        f32x16 c2;
+                        p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        if (prev_skipped) prev_rgb = c2;
+                        prev_skipped = false;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(skipped && w != 0.0f) != 0) {
+                        float s2;
+                        p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        skipped = false;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+                Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+                Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+                Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                st.W = st.W + w;
+                st.D = p3d_fma(w, tm, st.D);
+            }
+            st.prev_t = t; st.prev_sigma = sigma;
+            prev_rgb = rgb;
+            prev_skipped = skipped;
+            ppx = px; ppy = py; ppz = pz;
+        };
+        for (int m = 0; m < S; m += 2) {
+            const bool haveB = m + 1 < S;  // uniform
+            const float tA = next_depth();
+            const float tB = haveB ? next_depth() : tA;
+            const float pxA = ox + tA * dx, pyA = oy + tA * dy, pzA = oz + tA * dz;
+            const float pxB = ox + tB * dx, pyB = oy + tB * dy, pzB = oz + tB * dz;
+            const float px = slot ? pxB : pxA, py = slot ? pyB : pyA, pz = slot ? pzB : pzA;
+            float sigma = P3D_SIGMA_MASKED;
+            f32x16 rgb;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
+            bool skipped = false, live = true;
+            if (early) {
+                live = !(is_cropped(px, pz) || st.Td < 1e-60);
+                skipped = __builtin_amdgcn_ballot_w64(live) == 0;
+            }
+            if (!skipped) {
+                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                ndec += 1;
+                skipped = !live;
+            }
+            // exchange: every lane gets both samples of its ray (its own channel half)
+            const float sA = __shfl(sigma, laneA, 64), sB = __shfl(sigma, laneB, 64);
+            const int kA = __shfl((int)skipped, laneA, 64), kB = __shfl((int)skipped, laneB, 64);
+            f32x16 rgbA, rgbB;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float other = __shfl(rgb[c], lane ^ 16, 64);
+                rgbA[c] = slot ? other : rgb[c];
+                rgbB[c] = slot ? rgb[c] : other;
+            }
+            consume(m, tA, pxA, pyA, pzA, sA, rgbA, kA != 0);
+            if (haveB) consume(m + 1, tB, pxB, pyB, pzB, sB, rgbB, kB != 0);
+        }
+    }
+    {
+        const float Wt = st.W;
+        float d = st.D / Wt;
+        if (d != d) d = __builtin_inff();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = C[c];
+            if (p.white_back) v = (v + 1.0f) - Wt;
+            C[c] = v * 2.0f - 1.0f;
+        }
+        if (p.white_back) { Cx = (Cx + 1.0f) - Wt; Cy = (Cy + 1.0f) - Wt; Cz = (Cz + 1.0f) - Wt; }
+        Cx = Cx * 2.0f - 1.0f; Cy = Cy * 2.0f - 1.0f; Cz = Cz * 2.0f - 1.0f;
+        if (active && slot == 0) {
+            float* dst = p.out_feat + ray * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){C[4 * q], C[4 * q + 1], C[4 * q + 2], C[4 * q + 3]};
+            if (h == 0) {
+                p.out_depth[ray] = d;
+                p.out_wsum[ray] = Wt;
+                p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz;
+            }
+        }
+    }
+    if (!active) { tmin = __builtin_inff(); tmax = -__builtin_inff(); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        tmin = __builtin_fminf(tmin, __shfl_xor(tmin, o));
+        tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, o));
+    }
+    if (lane == 0) {
+        atomicMin(p.gminmax, p3d_f2ord(tmin));
+        atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+        atomicAdd((unsigned long long*)(p.gminmax + 2), (unsigned long long)ndec);
+    }
+}
+
 __global__ void k_minmax_init(uint32_t* g) {
     g[0] = 0xffffffffu;
     g[1] = 0u;
@@ -854,6 +1132,37 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     }
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
     const bool dmp = dumps != nullptr;
+    // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
+    // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
+    if (!dmp && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
+        if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
+        else p.tiles_per_img = (R + 15) / 16;
+        p.ntiles = p.tiles_per_img * N;
+        nwaves = P3D_RENDER_WAVES;
+        for (;; nwaves >>= 1) {
+            lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
+            if (lds_bytes <= 160 * 1024) break;
+            if (nwaves == 1) return P3D_E_RANGE;
+        }
+        dim3 grid2((unsigned)((p.ntiles + nwaves - 1) / nwaves)), blk2(64 * nwaves);
+        hipError_t e2 = hipSuccess;
+#define P3D_LAUNCH2(NFV)                                                                                             \
+    do {                                                                                                             \
+        e2 = hipFuncSetAttribute((const void*)k_render_pair<NFV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                 (int)lds_bytes);                                                                    \
+        if (e2 == hipSuccess) hipLaunchKernelGGL((k_render_pair<NFV>), grid2, blk2, lds_bytes, st, p);              \
+    } while (0)
+        if (nf == 64) P3D_LAUNCH2(64);
+        else if (nf == 128) P3D_LAUNCH2(128);
+        else P3D_LAUNCH2(0);
+        if (e2 != hipSuccess) return (int)e2;
+        int rc2 = p3d_check_launch();
+        if (rc2) return rc2;
+        long long NR2 = (long long)N * R;
+        hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR2 + 255) / 256)), dim3(256), 0, st, out_depth, NR2, p.gminmax,
+                           (float*)nullptr);
+        return p3d_check_launch();
+    }
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
     p.swz = 16;  // measured: 8..64 within 0.5 %, 1..4 and >= 256 about 1-3 % slower
     dim3 grid((unsigned)blocks), blk(64 * nwaves);

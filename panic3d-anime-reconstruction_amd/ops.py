@@ -33,7 +33,7 @@ def _p(t):
 
 
 def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_clouds=None, force_sigmoid=False,
-              early_out=True):
+              early_out=True, small_launch_kernel=True):
     """rendering_kwargs + ImportanceRenderer.forward arguments (renderer.py:162) -> p3d_opts.
     The double -> binary32 conversions are the ones include/p3d_numerics.h states."""
     ro = rendering_options
@@ -66,6 +66,8 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= _lib.P3D_FLAG_WHITE_BACK
     if not early_out:  # decode every sample even where the result provably cannot matter (measurement / tests)
         flags |= _lib.P3D_FLAG_NO_EARLY_OUT
+    if not small_launch_kernel:  # keep small launches on the 32-rays-per-wave kernel (tests)
+        flags |= _lib.P3D_FLAG_NO_PAIR
     rs, re = float(ro["ray_start"]), float(ro["ray_end"])
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
@@ -252,8 +254,15 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
     _lib.check(rc, "p3d_render_f32")
     if stats is not None:  # synchronises: wave-level decode steps executed (32 samples each) vs the full count
         steps = int(ws[8:16].view(torch.int64).item())
-        tiles = -(-R // 32) * N if not (ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0) else (R // 32) * N
-        stats.update(decode_steps=steps, decode_steps_full=tiles * (Sc + Sc + Sf if Sf > 0 else Sc))
+        tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)
+        tiles = (R // 32) * N if tiled else -(-R // 32) * N
+        pair = not dumps and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
+        if pair:  # 16 rays x 2 samples per wave-step
+            tiles = (R // 16) * N if tiled else -(-R // 16) * N
+            full = tiles * ((-(-Sc // 2) + -(-(Sc + Sf) // 2)) if Sf > 0 else -(-Sc // 2))
+        else:
+            full = tiles * (Sc + Sc + Sf if Sf > 0 else Sc)
+        stats.update(decode_steps=steps, decode_steps_full=full, small_launch_kernel=pair)
     return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)
 
 

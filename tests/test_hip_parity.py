@@ -95,15 +95,17 @@ def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
 
 @pytest.mark.parametrize("name", T.RENDER_GOLDENS)
 @pytest.mark.parametrize("early_out", [True, False])
-def test_render_production_kernel_bit_exact(hip, oracle, name, early_out):
-    """The kernel variant that ships (no dumps; with and without the exact early-outs) against the oracle: outputs only."""
+@pytest.mark.parametrize("pair", [True, False])
+def test_render_production_kernel_bit_exact(hip, oracle, name, early_out, pair):
+    """The kernel variants that ship (no dumps; with and without the exact early-outs; the small-launch kernel with 16 rays x 2
+    samples per wave and the 32-rays-per-wave kernel) against the oracle: outputs only."""
     g = T.load_golden(name + ".npz")
     inp = T.golden_render_inputs(g)
     R = inp["rays_o"].shape[1]
     side = int(round(R ** 0.5))
     ref = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
                         oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]))
-    opts = hip.ops.make_opts(inp["ro"], early_out=early_out, **inp["kw"])
+    opts = hip.ops.make_opts(inp["ro"], early_out=early_out, small_launch_kernel=pair, **inp["kw"])
     planes = hip.ops.planes_to_nhwc(dev(inp["planes"]))
     st = {}
     out = hip.ops.render(planes, dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"]),
@@ -111,6 +113,7 @@ def test_render_production_kernel_bit_exact(hip, oracle, name, early_out):
                          ray_tile_w=side if (side * side == R and side % 8 == 0) else 0, stats=st)
     for name_, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
         assert np.array_equal(a.cpu().numpy(), b), name_
+    assert st["small_launch_kernel"] == pair
     assert 0 < st["decode_steps"] <= st["decode_steps_full"]
     if not early_out:
         assert st["decode_steps"] == st["decode_steps_full"]
@@ -328,14 +331,17 @@ def _random_config(seed):
                 tile_w=(side if side else 0), early_out=bool(rng.integers(0, 2)))
 
 
+@pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("seed", range(100, 124))
-def test_render_random_configs_bit_exact(hip, oracle, seed):
+def test_render_random_configs_bit_exact(hip, oracle, seed, pair):
     """Randomised sweep over what the golden fixtures do not enumerate: N 1-3, non-square planes of odd sizes, ragged ray
     counts (incl. fewer than one wavefront), 4 <= Sc <= 70, Sf in {0, 1..70 (sorting network), 129..149 (LDS sort)}, every
-    mask mode, both plane conventions, white/black background, early-outs on/off, rays that miss the volume.  Bit-exact."""
+    mask mode, both plane conventions, white/black background, early-outs on/off, rays that miss the volume, and both render
+    kernels (the small-launch kernel these sizes would get, and the 32-rays-per-wave kernel forced).  Bit-exact."""
     c = _random_config(seed)
     mlp = hip_mlp(hip, c["raw"], c["lr_mul"])
-    opts = hip.ops.make_opts(c["ro"], early_out=c["early_out"], **c["kw"])
+    # pair: small launches go to k_render_pair (16 rays x 2 samples per wave); not pair: the 32-rays-per-wave kernel
+    opts = hip.ops.make_opts(c["ro"], early_out=c["early_out"], small_launch_kernel=pair, **c["kw"])
     out = hip.ops.render(hip.ops.planes_to_nhwc(dev(c["planes"])), dev(c["o"]), dev(c["d"]), dev(c["jit"]), dev(c["u"]), mlp, opts,
                          ray_tile_w=c["tile_w"])
     ref = oracle.render(c["planes"], c["o"], c["d"], c["jit"], c["u"], oracle.prescale_mlp(*c["raw"], lr_mul=c["lr_mul"]),
