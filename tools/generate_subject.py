@@ -48,6 +48,9 @@ with torch.no_grad():
           "triplane_crop": 0.1, "cull_clouds": 0.5}
     xw = dict(x0)
     G.f(xw)  # warm-up
+    for fov in (-1.0, 30.0):  # ... including the paste path, orthographic and perspective (first use of a torch kernel loads its code object)
+        G.f({"elevations": torch.zeros(1, device=dev), "azimuths": 10 * torch.ones(1, device=dev), "fovs": fov * torch.ones(1, device=dev),
+             "cond": cond, "seeds": [0], **opts})
     volume.mesh(G, xw["ws"], cond, resolution=32, level=0.5, triplane_crop=0.1, cull_clouds=0.5)  # warm-up (module load, allocator)
     t0 = sync()
     out = G.f(x0)
