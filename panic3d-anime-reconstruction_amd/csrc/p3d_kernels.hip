@@ -582,7 +582,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
     const bool early = !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);
     const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0;
     int ndec = 0;
-    const int laneA = jr + 32 * h, laneB = laneA + 16;  // the two slots of this lane's ray (same channel half)
+    // value of the partner slot (lane ^ 16): ds_swizzle bit mode and 0x1f, or 0, xor 0x10 — the crossbar, no address VGPR
+    auto partner = [](float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));
+    };
 
     const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
     const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
                 p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
                 ndec += 1;
             }
-            const float sA = __shfl(sigma, laneA, 64), sB = __shfl(sigma, laneB, 64);
+            const float so = partner(sigma);
+            const float sA = slot ? so : sigma, sB = slot ? sigma : so;
             if (i > 0) {
                 float tm;
                 wcA[(i - 1) * 32 + jr] = p3d_march_weight(st, tA, sA, tm);
@@ -765,12 +769,14 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
                 skipped = !live;
             }
             // exchange: every lane gets both samples of its ray (its own channel half)
-            const float sA = __shfl(sigma, laneA, 64), sB = __shfl(sigma, laneB, 64);
-            const int kA = __shfl((int)skipped, laneA, 64), kB = __shfl((int)skipped, laneB, 64);
+            const float so = partner(sigma);
+            const float sA = slot ? so : sigma, sB = slot ? sigma : so;
+            const int ko = __builtin_amdgcn_ds_swizzle((int)skipped, 0x401f);
+            const int kA = slot ? ko : (int)skipped, kB = slot ? (int)skipped : ko;
             f32x16 rgbA, rgbB;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const float other = __shfl(rgb[c], lane ^ 16, 64);
+                const float other = partner(rgb[c]);
                 rgbA[c] = slot ? other : rgb[c];
                 rgbB[c] = slot ? rgb[c] : other;
             }
