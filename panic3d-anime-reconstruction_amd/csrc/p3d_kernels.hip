@@ -6,7 +6,9 @@
 //   k_render           ImportanceRenderer.forward fused per wavefront: 32 rays per wave (lane pair = ray x channel half);
 //                      coarse density pass -> weights -> importance resampling -> merge -> final decode + compositing,
 //                      all per-ray state in registers / LDS; no intermediate tensor ever reaches HBM.
+//   k_render_pair      the same algorithm for small launches: 16 rays x 2 samples per wave (bit-identical results).
 //   k_render_finish    the one cross-ray dependency: depth clamp to the global [min t, max t] (ray_marcher.py:49-50).
+//   k_sigma2density    get_eg3d_volume's activation + crop / cull masks in one pass.
 //   k_stratified / k_composite / k_importance / k_unify_perm   operator-level stand-alone stages (one thread per ray).
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see panic3d-anime-reconstruction_amd/_build.py).
