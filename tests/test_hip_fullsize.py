@@ -82,6 +82,15 @@ def test_c3_512x512_96_samples(hip, oracle):
     out2 = hip.ops.render(pl, *args, ray_tile_w=0)
     for a, b in zip(out, out2):
         assert torch.equal(a, b)
+    # rays are independent (only the depth clamp is global): a 128x128 block of the same rays, small enough for the
+    # small-launch kernel (16 rays x 2 samples per wave), gives the same bits as the 512^2 launch on the 32-ray kernel
+    sub = (torch.arange(128)[:, None] * res + torch.arange(128)[None, :] + 200 * res + 170).reshape(-1).cuda()
+    o2, d2, j2 = args[0][:, sub].contiguous(), args[1][:, sub].contiguous(), args[2][:, sub].contiguous()
+    st = {}
+    out3 = hip.ops.render(pl, o2, d2, j2, args[3][sub].contiguous(), mlp, opts, ray_tile_w=128, stats=st)
+    assert st["small_launch_kernel"]
+    for k in (0, 2, 3):
+        assert torch.equal(out[k][:, sub], out3[k])
 
 
 def test_c5_density_grid_slabs(hip, oracle):
