@@ -265,6 +265,7 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 //   In the final pass a skipped sample's colour is needed only if one of its two interval weights is non-zero (sigma of
 //   the neighbour >= ~794); that is checked on the exact weights and, if it ever happens, the sample is decoded after
 //   all — results are bit-identical by construction.
+// the host picks the workgroup size (1, 2 or 4 waves) that fills the CU's 160 KB of LDS best
 template <int NF, bool DUMP>
 __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1133,8 +1134,24 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     // small ray counts (e.g. the pipeline's 128^2 rays = 512 tiles): shrink the workgroup so that every CU gets work
     while (nwaves > 1 && p.ntiles / nwaves < 2 * 256) nwaves >>= 1;
     size_t lds_bytes;
+    const size_t lds_fixed = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4, lds_wave = (size_t)p.lds_rows * 128;
+    if (nwaves == P3D_RENDER_WAVES) {
+        // large launch: the workgroup shape (4, 2 or 1 waves, as many workgroups as fit) that puts most waves on a CU, at
+        // most 8 (two per SIMD: the register cap); ties go to the LARGER workgroup.  48+48: 2 x 4 waves; 64+64: 3 x 2 instead of
+        // 1 x 4 (measured 6.85 -> 6.53 ms at 512^2); 96+96 stays 1 x 4 (measured: 2 x 2 waves 13.3 ms, 1 x 5 12.6, 1 x 4 11.2)
+        int best = 0, best_waves = 0;
+        for (int w = 4; w >= 1; w >>= 1) {
+            const size_t per_wg = lds_fixed + w * lds_wave;
+            if (per_wg > 160 * 1024) continue;
+            int wgs = (int)((160 * 1024) / per_wg);
+            int waves = wgs * w > 8 ? 8 / w * w : wgs * w;
+            if (waves > best_waves) { best_waves = waves; best = w; }
+        }
+        if (best == 0) return P3D_E_RANGE;
+        nwaves = best;
+    }
     for (;; nwaves >>= 1) {
-        lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
+        lds_bytes = lds_fixed + (size_t)nwaves * lds_wave;
         if (lds_bytes <= 160 * 1024) break;
         if (nwaves == 1) return P3D_E_RANGE;
     }

@@ -112,3 +112,24 @@ def test_c5_density_grid_slabs(hip, oracle):
     osig, _ = oracle.decode(planes, pts[:, sub].numpy(), oracle.prescale_mlp(*raw), 0.7, plane_mode=1, flags=opts.flags,
                             density_only=True)
     assert np.array_equal(whole[:, sub].cpu().numpy(), osig)
+
+
+@pytest.mark.parametrize("Sc,Sf", [(96, 96), (64, 64)])
+def test_large_launch_other_sampling_rates(hip, oracle, Sc, Sf):
+    """The eval-faithful 96+96 (eg3dc_v0.py:30-31) and 64+64 at 256^2 rays: large launches whose LDS rows make the host pick
+    other workgroup shapes (1 x 4 resp. 3 x 2 waves per CU: it fills the CU's 160 KB) — bit-exact with the oracle like the 4-wave 48+48 configuration."""
+    res = 256
+    ro = dict(RO, depth_resolution=Sc, depth_resolution_importance=Sf)
+    planes = T.make_planes(51, 1, 128, 128, scale=4.0, smooth=16)
+    raw = T.make_decoder_params(52, 1.0, 30.0)
+    o, d = hip.cameras.rays_from_label(hip.cameras.camera_label(-5.0, 140.0, 1.0, 30.0)[None], res)
+    jit, u = T.make_random_draws(53, 1, res * res, Sc, Sf)
+    mlp = hip.ops.prescale_mlp(*(torch.from_numpy(x).cuda() for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
+    st = {}
+    out = hip.ops.render(hip.ops.planes_to_nhwc(torch.from_numpy(planes).cuda()), o.cuda(), d.cuda(), torch.from_numpy(jit).cuda(),
+                         torch.from_numpy(u).cuda(), mlp, hip.ops.make_opts(ro, **KW), ray_tile_w=res, stats=st)
+    assert not st["small_launch_kernel"]
+    ref = oracle.render(planes, o.numpy(), d.numpy(), jit, u, oracle.prescale_mlp(*raw), oracle.make_opts(ro, **KW))
+    for name, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
+        assert np.array_equal(a.cpu().numpy(), b), name
+    check_properties(*(t.cpu().numpy() for t in out), ro)
