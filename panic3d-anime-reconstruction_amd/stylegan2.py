@@ -29,13 +29,23 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / np.sqrt(in_features)
         self.bias_gain = lr_multiplier
 
+    def _scaled(self, dtype):
+        """`weight * weight_gain`, `bias * bias_gain` (networks_stylegan2.py:121-127), computed once per parameter version:
+        the same two multiplications the reference does on every call (inference: the parameters do not change), so the
+        values are bit-identical.  Plain attributes, not buffers: the state_dict stays the reference's."""
+        key = (dtype, self.weight.data_ptr(), self.weight._version, None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        if getattr(self, "_scaled_key", None) != key:
+            w = self.weight.detach().to(dtype) * self.weight_gain
+            b = self.bias
+            if b is not None:
+                b = b.detach().to(dtype)
+                if self.bias_gain != 1:
+                    b = b * self.bias_gain
+            self._scaled_wb, self._scaled_key = (w, b), key
+        return self._scaled_wb
+
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
+        w, b = self._scaled(x.dtype)
         if self.activation == "linear" and b is not None:
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return ops.bias_act(x.matmul(w.t()).contiguous(), b, act=self.activation)

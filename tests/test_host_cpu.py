@@ -218,3 +218,20 @@ def test_outputs_png_and_pkl_formats(tmp_path):
     assert set(back) == {"verts", "faces", "normals", "values", "colors"} and back["faces"].dtype == np.int32
     with pytest.raises(RuntimeError):
         outputs.to_uint8_hwc(torch.zeros(2, 3, 4, 4))
+
+
+def test_fully_connected_scaled_weight_cache(P):
+    """FullyConnectedLayer caches weight * gain per parameter version: same values as the per-call multiplication, refreshed
+    when the parameters change (load_state_dict / in-place updates), absent from the state_dict."""
+    fc = P.stylegan2.FullyConnectedLayer(12, 7, lr_multiplier=0.5, bias_init=1.0)
+    x = torch.randn(3, 12, generator=torch.Generator().manual_seed(0))
+    ref = lambda: torch.addmm((fc.bias * fc.bias_gain).unsqueeze(0), x, (fc.weight * fc.weight_gain).t())
+    with torch.no_grad():
+        assert torch.equal(fc(x), ref())
+        k0 = fc._scaled_key
+        assert torch.equal(fc(x), ref()) and fc._scaled_key == k0
+        fc.weight.mul_(2.0)
+        assert torch.equal(fc(x), ref()) and fc._scaled_key != k0
+        fc.load_state_dict({"weight": torch.ones(7, 12), "bias": torch.zeros(7)})
+        assert torch.equal(fc(x), ref())
+    assert set(fc.state_dict()) == {"weight", "bias"}
