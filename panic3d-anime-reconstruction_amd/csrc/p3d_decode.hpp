@@ -32,6 +32,29 @@
 #define P3D_LDS_W1S 4192
 #define P3D_LDS_B1S 4256
 #define P3D_LDS_MLP_FLOATS 4260
+#ifdef P3D_EXPERIMENT_TABLE_ACT  // timing experiment (never shipped): cubic-Hermite activation tables in LDS
+#undef P3D_LDS_MLP_FLOATS
+#define P3D_TAB_N 320
+#define P3D_LDS_TAB_SP 4260                          // [321][4] softplus tail g(u) = log1p(exp(-u)), u = |x|, step 1/16
+#define P3D_LDS_TAB_SG (4260 + 4 * (P3D_TAB_N + 1))  // [321][4] sigmoid(u)
+#define P3D_LDS_MLP_FLOATS (4260 + 8 * (P3D_TAB_N + 1))
+P3D_DEV float p3d_tab_eval(const float* tab, float u) {
+    float t = __builtin_fminf(u, (float)P3D_TAB_N / 16.0f) * 16.0f;
+    int i = (int)t;
+    float f = t - (float)i;
+    const f32x4 c = *(const f32x4*)(tab + 4 * i);
+    return p3d_fma(p3d_fma(p3d_fma(c[3], f, c[2]), f, c[1]), f, c[0]);
+}
+#define P3D_ACT_SOFTPLUS(lds, x) (__builtin_fmaxf(x, 0.0f) + p3d_tab_eval((lds) + P3D_LDS_TAB_SP, __builtin_fabsf(x)))
+P3D_DEV float p3d_sigmoid_tab(const float* lds, float x) {
+    float s = p3d_tab_eval(lds + P3D_LDS_TAB_SG, __builtin_fabsf(x));
+    return x >= 0.0f ? s : 1.0f - s;
+}
+#define P3D_ACT_SIGMOID(lds, x) p3d_sigmoid_tab(lds, x)
+#else
+#define P3D_ACT_SOFTPLUS(lds, x) p3d_softplus(x)
+#define P3D_ACT_SIGMOID(lds, x) p3d_sigmoid(x)
+#endif
 
 #ifdef P3D_ABL_NOMFMA  // timing experiment: matrix-core work replaced by one VALU op
 P3D_DEV f32x16 p3d_fake_mfma(float a, float b, f32x16 c) { c[0] = p3d_fma(a, b, c[0]); return c; }
@@ -61,6 +84,18 @@ P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, c
         lds[P3D_LDS_B1P + idx] = b1[1 + p3d_rowof(r) + 4 * h];
     }
     if (threadIdx.x < 4) lds[P3D_LDS_B1S + threadIdx.x] = threadIdx.x == 0 ? b1[0] : 0.0f;
+#ifdef P3D_EXPERIMENT_TABLE_ACT
+    for (int i = threadIdx.x; i <= P3D_TAB_N; i += blockDim.x) {
+        const double hh = 1.0 / 16.0, u0 = i * hh, u1 = u0 + hh;
+        double g0 = log1p(exp(-u0)), g1 = log1p(exp(-u1)), dg0 = -1.0 / (1.0 + exp(u0)), dg1 = -1.0 / (1.0 + exp(u1));
+        double s0 = 1.0 / (1.0 + exp(-u0)), s1 = 1.0 / (1.0 + exp(-u1)), ds0 = s0 * (1 - s0), ds1 = s1 * (1 - s1);
+        if (i == P3D_TAB_N) { g0 = g1 = dg0 = dg1 = 0.0; s0 = s1 = 1.0; ds0 = ds1 = 0.0; }
+        float* a = lds + P3D_LDS_TAB_SP + 4 * i;
+        a[0] = (float)g0; a[1] = (float)(hh * dg0); a[2] = (float)(3 * (g1 - g0) - hh * (2 * dg0 + dg1)); a[3] = (float)(2 * (g0 - g1) + hh * (dg0 + dg1));
+        float* b = lds + P3D_LDS_TAB_SG + 4 * i;
+        b[0] = (float)s0; b[1] = (float)(hh * ds0); b[2] = (float)(3 * (s1 - s0) - hh * (2 * ds0 + ds1)); b[3] = (float)(2 * (s0 - s1) + hh * (ds0 + ds1));
+    }
+#endif
 }
 
 struct P3dPlaneGeom {
@@ -229,8 +264,8 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // Softplus: triplane.py:524
-        acc0[r] = p3d_softplus(acc0[r]);
-        acc1[r] = p3d_softplus(acc1[r]);
+        acc0[r] = P3D_ACT_SOFTPLUS(lds, acc0[r]);
+        acc1[r] = P3D_ACT_SOFTPLUS(lds, acc1[r]);
     }
     // ---- sigma row on the VALU: two half chains joined across the lane pair (triplane.py:543)
     const f32x4* w1s = (const f32x4*)(lds + P3D_LDS_W1S + h * 32);
@@ -269,7 +304,7 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
         const bool fs = (cfg.flags & P3D_FLAG_FORCE_SIGMOID) != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float sg = p3d_sigmoid(o[r]);
+            float sg = P3D_ACT_SIGMOID(lds, o[r]);
             rgb[r] = fs ? sg : sg * 1.002f - 0.001f;
         }
     }
