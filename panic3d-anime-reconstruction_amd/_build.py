@@ -20,6 +20,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash():
+    """sha256[:16] over the kernel sources and headers: identifies WHICH kernels a profile was captured from (the GPU box
+    has no .git; profiles/pmc_latest.json stores this and bench.py refuses a capture from other sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True

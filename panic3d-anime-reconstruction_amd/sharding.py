@@ -34,9 +34,11 @@ def frames_rgba(feat, wsum, res, out=None, channels_last=False):
 
 
 def gather_frames(local, counts=None, dst=0, force=False):
-    """Gather per-rank frame stacks [n_r,4,H,W] to rank `dst` in rank order.  Every rank pads to max(counts) so a single
-    fixed-size collective is issued per sweep (one large message per xGMI link rather than one per frame).
-    Returns the concatenated [sum n_r,4,H,W] tensor on dst, None elsewhere."""
+    """Gather per-rank frame stacks [n_r, ...] to rank `dst` in rank order: a TRUE gather — every rank sends its own frames
+    to dst once and nothing else moves (north_star: "RCCL gather over xGMI of final RGBA only").  Issued as one batch of
+    point-to-point operations (RCCL groups them: rank dst receives over its 7 xGMI links concurrently, each message exactly
+    counts[r] frames, written straight into its slice of the result — no padding, no staging copy).  A rank with no frames
+    (counts[r] == 0, local of shape [0, ...]) takes part without sending.  Returns [sum n_r, ...] on dst, None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -45,30 +47,27 @@ def gather_frames(local, counts=None, dst=0, force=False):
         allc = [torch.zeros_like(c) for _ in range(world)]
         dist.all_gather(allc, c)
         counts = [int(x.item()) for x in allc]
-    mx = max(counts)
-    buf = local
-    if local.shape[0] < mx:
-        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        buf = torch.cat([local, pad])
-    buf = buf.contiguous()
-    if dist.get_backend() == "nccl":
-        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, buf)
-        if rank != dst:
-            return None
-        parts = [out[r * mx:r * mx + counts[r]] for r in range(world)]
-    else:
-        lst = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, lst, dst=dst)
-        if rank != dst:
-            return None
-        parts = [lst[r][:counts[r]] for r in range(world)]
-    return torch.cat(parts)
+    if local.shape[0] != counts[rank]:
+        raise RuntimeError(f"rank {rank} holds {local.shape[0]} frames but counts[{rank}] = {counts[rank]}")
+    local = local.contiguous()
+    if rank != dst:
+        if counts[rank] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst)]):
+                w.wait()
+        return None
+    out = torch.empty((sum(counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    offs = [sum(counts[:r]) for r in range(world)]
+    ops_ = [dist.P2POp(dist.irecv, out[offs[r]:offs[r] + counts[r]], r) for r in range(world) if r != dst and counts[r] > 0]
+    reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+    out[offs[dst]:offs[dst] + counts[dst]].copy_(local)
+    for w in reqs:
+        w.wait()
+    return out
 
 
 def render_views_sharded(render_one, n_views, res, dst=0):
     """Render views [0, n_views) sharded over the ranks; `render_one(view_index) -> (feat, wsum)` for one view.
-    Returns [n_views,4,res,res] on rank dst."""
+    Returns [n_views,4,res,res] on rank dst.  Ranks beyond n_views render nothing and still take part in the gather."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = partition(n_views, world, rank)
@@ -76,8 +75,10 @@ def render_views_sharded(render_one, n_views, res, dst=0):
     for v in range(lo, hi):
         feat, wsum = render_one(v)
         frames.append(frames_rgba(feat, wsum, res))
-    local = torch.cat(frames) if frames else None
     counts = [partition(n_views, world, r)[1] - partition(n_views, world, r)[0] for r in range(world)]
-    if local is None:
-        raise RuntimeError("a rank received no views; use world_size <= n_views")
+    if frames:
+        local = torch.cat(frames)
+    else:  # more ranks than views: an empty stack of the right trailing shape (device: the process's current accelerator, if any)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        local = torch.empty((0, 4, res, res), dtype=torch.float32, device=dev)
     return gather_frames(local, counts, dst)

@@ -75,7 +75,10 @@ def density_grid_sharded(G, ws, cond, resolution=256, dst=0, **kw):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     a, b = sharding.partition(resolution, world, rank)
-    out = density_grid(G, ws, cond, resolution, lo=a * resolution ** 2, hi=b * resolution ** 2, **kw)
+    if b > a:
+        out = density_grid(G, ws, cond, resolution, lo=a * resolution ** 2, hi=b * resolution ** 2, **kw)
+    else:  # more ranks than grid slices: an empty slab that still takes part in the gather
+        out = {k: torch.empty((1, 0, 1), dtype=torch.float32, device=ws.device) for k in ("sigmas", "densities")}
     if world == 1:
         return out
     counts = [sharding.partition(resolution, world, r)[1] - sharding.partition(resolution, world, r)[0] for r in range(world)]

@@ -91,3 +91,44 @@ def golden_render_inputs(g):
               binarize_clouds=float(m["binarize"]) or None, force_sigmoid=bool(m["force_sigmoid"]))
     return dict(ro=ro, planes=planes, raw_mlp=raw, lr_mul=float(m["lr_mul"]), rays_o=g["rays_o"], rays_d=g["rays_d"],
                 jitter=jitter, u=u, kw=kw, meta=m)
+
+
+# ---- bench scenes (bench.py, tools/cpu_baseline_reference.py, tests/test_hip_fullsize.py share these builders) ---------------
+BENCH_KW = dict(triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)  # generate.py:56-57; OSGDecoder force_sigmoid
+
+
+def make_bench_scene(scene="canonical"):
+    """(planes [1,3,32,256,256] f32 numpy, raw decoder params) of a bench scene.
+
+    'canonical' = SURVEY.md §8(d) exactly: planes torch.randn(1,3,32,256,256, generator=seed 0); decoder = the reference's
+        OSGDecoder(32, {decoder_lr_mul: 1, decoder_output_dim: 32}) constructed under torch.manual_seed(0) — its
+        FullyConnectedLayers draw torch.randn([64,32]) then torch.randn([33,64]) and zero biases (networks_stylegan2.py:110-115,
+        triplane.py:521-526); tools/cpu_baseline_reference.py asserts that this restatement equals the reference constructor's
+        parameters bit for bit.  A fog: no ray ever turns opaque.
+    'surface' = the round-1 bench scene: 16x16 noise bilinearly upsampled + 10 % white noise, scale 4, sigma row x30, sigma
+        bias -45 — about half of the rays hit an opaque surface (character-like coverage), the others see empty space."""
+    if scene == "canonical":
+        planes = torch.randn(1, 3, 32, 256, 256, generator=torch.Generator().manual_seed(0)).numpy()
+        state = torch.random.get_rng_state()
+        torch.manual_seed(0)
+        w0 = torch.randn(64, 32)
+        w1 = torch.randn(33, 64)
+        torch.random.set_rng_state(state)
+        return planes, (w0.numpy(), np.zeros(64, np.float32), w1.numpy(), np.zeros(33, np.float32))
+    if scene == "surface":
+        g = torch.Generator().manual_seed(0)
+        low = torch.randn(3, 32, 16, 16, generator=g)
+        planes = torch.nn.functional.interpolate(low, size=(256, 256), mode="bilinear", align_corners=False)
+        planes = ((planes + 0.1 * torch.randn(3, 32, 256, 256, generator=g)) * 4.0).reshape(1, 3, 32, 256, 256).contiguous()
+        w0 = torch.randn(64, 32, generator=g)
+        b0 = torch.randn(64, generator=g) * 0.5
+        w1 = torch.randn(33, 64, generator=g)
+        b1 = torch.randn(33, generator=g) * 0.5
+        w1[0] *= 30.0
+        b1[0] = -45.0
+        return planes.numpy(), (w0.numpy(), b0.numpy(), w1.numpy(), b1.numpy())
+    raise ValueError(f"unknown bench scene {scene!r}")
+
+
+def bench_rendering_kwargs(Sc=48, Sf=48):
+    return dict(RENDERING_KWARGS, depth_resolution=int(Sc), depth_resolution_importance=int(Sf))

@@ -130,7 +130,7 @@ import panic3d_amd
 from panic3d_amd import sharding
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-res, n_views = 8, 5
+res, n_views = 8, {n_views}
 def render_one(v):  # stands in for the HIP render: a frame whose content identifies the view
     feat = torch.full((1, res * res, 32), float(v)); wsum = torch.full((1, res * res, 1), 0.5 + v)
     return feat, wsum
@@ -146,15 +146,25 @@ dist.destroy_process_group()
 """
 
 
-def test_view_sharding_gloo_world2(tmp_path):
+def _run_gather_worker(tmp_path, world, n_views, port):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT))
+    script.write_text(_WORKER.format(root=ROOT, n_views=n_views))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_view_sharding_gloo_world2(tmp_path):
+    _run_gather_worker(tmp_path, 2, 5, 29541)
+
+
+def test_view_sharding_more_ranks_than_views(tmp_path):
+    """A rank without views must not raise before the collective (the others would hang in it): it joins the gather with an
+    empty stack (sharding.py:80)."""
+    _run_gather_worker(tmp_path, 3, 2, 29543)
 
 
 def test_stylegan2_state_dict_matches_reference_names(P):

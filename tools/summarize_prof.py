@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 outputs (gpurun_out/<dir>) into small tracked files under profiles/.
+"""Condense the rocprofv3 outputs of tools/collect_profile.sh (gpurun_out/<tag>/) into small tracked files under profiles/.
 
-    python tools/summarize_prof.py <tag> <kernel_stats_dir> [<pmc_dir> ...]
+    python tools/summarize_prof.py <tag>
 
-Writes profiles/<tag>_kernel_stats.csv (kernel names truncated to 80 chars), profiles/<tag>_pmc.json (per-launch
-averages of every counter for the fused kernel k_render) and profiles/pmc_latest.json (HBM traffic per launch:
-FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE gets the gfx950 x2 correction of
-/opt/skills/guides/MI355X_MICROARCH.md §HBM because the gathers are 16-B-per-lane loads).
+Writes, per scene (canonical / surface) and mode (early = exact early-outs on = the default; noearly = every sample decoded):
+  profiles/<tag>_<scene>_<mode>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names cut to 80 chars)
+  profiles/<tag>_pmc.json                          per-launch averages of every counter for k_render + dispatch info
+  profiles/pmc_latest.json                         {scene: {kernel_src_sha, hbm_bytes_per_launch, bounds, source}} of the DEFAULT mode —
+                                                   bench.py prints it only when kernel_src_sha matches the sources it runs.
+Units / corrections: FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE gets the gfx950 x2 correction of
+/opt/skills/guides/MI355X_MICROARCH.md §HBM (the gathers are 16-B-per-lane loads); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+(÷8 = active GPU clocks of the launch); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x4 = clocks);
+SQ_VALU_MFMA_BUSY_CYCLES counts clocks.
 """
 import collections
 import csv
@@ -16,45 +21,91 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_CU, N_SIMD = 256, 1024
+
+
+def is_render(name):
+    return ("k_render<" in name or name.startswith("k_render(") or "k_render_pair" in name) and "finish" not in name
 
 
 def main():
-    tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    ks = glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))
-    if ks:
-        rows = list(csv.reader(open(ks[0])))
-        with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-            w = csv.writer(f)
-            for r in rows:
-                r[0] = r[0][:80]
-                w.writerow(r)
-    pmc = {}
-    meta = {}
-    for d in pmc_dirs:
-        for fn in glob.glob(os.path.join(d, "*counter_collection.csv")):
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    sha = open(os.path.join(src, "kernel_src_sha.txt")).read().strip()
+    allpmc, latest = {}, {}
+    for scene in ("canonical", "surface"):
+        for mode in ("early", "noearly"):
+            ks = glob.glob(os.path.join(src, f"stats_{scene}_{mode}", "**", "*kernel_stats.csv"), recursive=True)
+            kern_ns = None
+            if ks:
+                rows = list(csv.reader(open(ks[0])))
+                with open(os.path.join(prof, f"{tag}_{scene}_{mode}_kernel_stats.csv"), "w", newline="") as f:
+                    w = csv.writer(f)
+                    for r in rows:
+                        if is_render(r[0]):
+                            kern_ns = float(r[3])  # AverageNs
+                        r[0] = r[0][:80]
+                        w.writerow(r)
             acc = collections.defaultdict(list)
-            for r in csv.DictReader(open(fn)):
-                if ("k_render<" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_render(")) and "finish" not in r["Kernel_Name"]:
-                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
-                                              "LDS_Block_Size", "Scratch_Size")}
-            for k, v in acc.items():
-                pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-    if pmc:
-        out = {"kernel": "k_render", "dispatch": meta, "counters": pmc}
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
-            write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024
-            out["hbm_bytes_per_launch"] = fetch + write
-            out["fetch_bytes_corrected"] = fetch
-            out["write_bytes"] = write
-            json.dump({"hbm_bytes_per_launch": fetch + write, "source": f"profiles/{tag}_pmc.json"},
-                      open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"))
-        json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-    if ks:
-        print(open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")).read()[:1200])
-    print(json.dumps(pmc)[:1200])
+            meta = {}
+            for fn in glob.glob(os.path.join(src, f"pmc_{scene}_{mode}_*", "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fn)):
+                    if is_render(r["Kernel_Name"]):
+                        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+                                                  "LDS_Block_Size", "Scratch_Size")}
+            if not acc and kern_ns is None:
+                continue
+            c = {k: sum(v) / len(v) for k, v in acc.items()}
+            ent = {"dispatch": meta, "counters": {k: {"mean_per_launch": c[k], "launches": len(acc[k])} for k in c},
+                   "rocprof_kernel_avg_ms": None if kern_ns is None else kern_ns / 1e6}
+            b = {}
+            if "GRBM_GUI_ACTIVE" in c:
+                clk = c["GRBM_GUI_ACTIVE"] / 8
+                b["gpu_active_clocks"] = clk
+                if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+                    b["tcp_lookups_per_clk_per_cu"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (clk * N_CU)
+                    b["tcp_lookups_peak_measured"] = 1.6
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                    b["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (clk * N_SIMD)
+                if "SQ_INSTS_VALU" in c:
+                    b["valu_issue_frac_at_2clk_per_inst"] = (c["SQ_INSTS_VALU"] - c.get("SQ_INSTS_MFMA", 0.0)) * 2 / (clk * N_SIMD)
+                if "SQ_ACTIVE_INST_VALU" in c:
+                    b["valu_active_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (clk * N_SIMD)
+            if "SQ_WAVE_CYCLES" in c:
+                for k, nm in (("SQ_WAIT_INST_ANY", "wait_inst_frac_of_wave_cycles"), ("SQ_WAIT_ANY", "wait_any_frac_of_wave_cycles"),
+                              ("SQ_ACTIVE_INST_ANY", "active_inst_frac_of_wave_cycles")):
+                    if k in c:
+                        b[nm] = c[k] / c["SQ_WAVE_CYCLES"]
+            if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+                b["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+            b["counter_source"] = f"profiles/{tag}_pmc.json [{scene}/{mode}] (rocprofv3 --pmc, one group per pass)"
+            ent["bounds"] = b
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                ent["fetch_bytes_corrected"] = c["FETCH_SIZE"] * 1024 * 2
+                ent["write_bytes"] = c["WRITE_SIZE"] * 1024
+                ent["hbm_bytes_per_launch"] = ent["fetch_bytes_corrected"] + ent["write_bytes"]
+            allpmc[f"{scene}/{mode}"] = ent
+            if mode == "early":
+                latest[scene] = {"kernel_src_sha": sha, "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "bounds": b,
+                                 "rocprof_kernel_avg_ms": ent["rocprof_kernel_avg_ms"], "source": f"profiles/{tag}_pmc.json [{scene}/early]"}
+    json.dump({"tag": tag, "kernel_src_sha": sha, "captures": allpmc}, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1)
+    if latest:
+        json.dump(latest, open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
+    # the bench lines the runs themselves printed
+    lines = {}
+    for fn in sorted(glob.glob(os.path.join(src, "stats_*.json"))):
+        txt = [l for l in open(fn).read().splitlines() if l.startswith("{")]
+        if txt:
+            lines[os.path.basename(fn)[:-5]] = json.loads(txt[-1])
+    if lines:
+        json.dump(lines, open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+    for k, v in allpmc.items():
+        print(k, "kernel ms", v["rocprof_kernel_avg_ms"], json.dumps(v["bounds"]), "hbm", v.get("hbm_bytes_per_launch"))
+    if os.path.exists(os.path.join(src, "failures.txt")):
+        print(open(os.path.join(src, "failures.txt")).read())
 
 
 if __name__ == "__main__":
