@@ -32,46 +32,34 @@
 #define P3D_LDS_W1S 4192
 #define P3D_LDS_B1S 4256
 #define P3D_LDS_MLP_FLOATS 4260
-#ifdef P3D_EXPERIMENT_TABLE_ACT  // timing experiment (never shipped): cubic-Hermite activation tables in LDS
-#undef P3D_LDS_MLP_FLOATS
-#define P3D_TAB_N 320
-#define P3D_LDS_TAB_SP 4260                          // [321][4] softplus tail g(u) = log1p(exp(-u)), u = |x|, step 1/16
-#define P3D_LDS_TAB_SG (4260 + 4 * (P3D_TAB_N + 1))  // [321][4] sigmoid(u)
-#define P3D_LDS_MLP_FLOATS (4260 + 8 * (P3D_TAB_N + 1))
-P3D_DEV float p3d_tab_eval(const float* tab, float u) {
-    float t = __builtin_fminf(u, (float)P3D_TAB_N / 16.0f) * 16.0f;
-    int i = (int)t;
-    float f = t - (float)i;
-    const f32x4 c = *(const f32x4*)(tab + 4 * i);
-    return p3d_fma(p3d_fma(p3d_fma(c[3], f, c[2]), f, c[1]), f, c[0]);
-}
-#define P3D_ACT_SOFTPLUS(lds, x) (__builtin_fmaxf(x, 0.0f) + p3d_tab_eval((lds) + P3D_LDS_TAB_SP, __builtin_fabsf(x)))
-P3D_DEV float p3d_sigmoid_tab(const float* lds, float x) {
-    float s = p3d_tab_eval(lds + P3D_LDS_TAB_SG, __builtin_fabsf(x));
-    return x >= 0.0f ? s : 1.0f - s;
-}
-#define P3D_ACT_SIGMOID(lds, x) p3d_sigmoid_tab(lds, x)
-#else
-#define P3D_ACT_SOFTPLUS(lds, x) p3d_softplus(x)
-#define P3D_ACT_SIGMOID(lds, x) p3d_sigmoid(x)
-#endif
-
-#ifdef P3D_ABL_NOMFMA  // timing experiment: matrix-core work replaced by one VALU op
-P3D_DEV f32x16 p3d_fake_mfma(float a, float b, f32x16 c) { c[0] = p3d_fma(a, b, c[0]); return c; }
-#define P3D_MFMA(a, b, c) p3d_fake_mfma(a, b, c)
-#else
 #define P3D_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
-#endif
+
+// ---- tolerance mode of the FINAL pass (P3D_FLAG_FAST_COLOR) --------------------------------------------
+// Both layers on v_mfma_f32_32x32x16_f16 (16x the f32 MFMA rate) with every operand split into two f16 terms
+// (x = xh + xl, xh = f16(x) by truncation, xl = f16(x - xh)): x*w ~ xh*wh + xl*wh + xh*wl, fp32 accumulation — about 2^-21
+// relative per product — and the activations on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32).
+// Extra LDS image (only in the FAST kernels), in MFMA operand order, 16 B per lane:
+//   W0H [2 t][2 q][2 hi/lo][64 lanes][8 f16] : w0[32t + (l&31)][16(l>>5) + 8q + i]
+//   W1H [2 t][2 pp][2 hi/lo][64 lanes][8 f16]: w1[1 + (l&31)][32t + rowof(8pp + i) + 4(l>>5)]   (overlays W1A: the f32
+//                                               colour weights are never used by a FAST kernel)
+#define P3D_LDS_W0H P3D_LDS_MLP_FLOATS
+#define P3D_LDS_W1H P3D_LDS_W1A
+#define P3D_LDS_FAST_FLOATS (P3D_LDS_MLP_FLOATS + 2048)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define P3D_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 P3D_DEV int p3d_rowof(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // Cooperative load by the whole workgroup (blockDim.x threads).  Caller must __syncthreads() afterwards.
-P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, const float* w1, const float* b1) {
+// with_w1a = false: a FAST kernel, whose f16 colour weights overlay W1A (p3d_load_mlp_f16_to_lds).
+P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, const float* w1, const float* b1,
+                                 bool with_w1a = true) {
     for (int idx = threadIdx.x; idx < 2048; idx += blockDim.x) {
         int e = idx & 3, l = (idx >> 2) & 63, s4 = (idx >> 8) & 3, t = idx >> 10;
         int s = 4 * s4 + e, i = l & 31, h = l >> 5;
         lds[P3D_LDS_W0A + idx] = w0[(32 * t + i) * 32 + 16 * h + s];
-        lds[P3D_LDS_W1A + idx] = w1[(1 + i) * 64 + 32 * t + p3d_rowof(s) + 4 * h];
+        if (with_w1a) lds[P3D_LDS_W1A + idx] = w1[(1 + i) * 64 + 32 * t + p3d_rowof(s) + 4 * h];
     }
     for (int idx = threadIdx.x; idx < 64; idx += blockDim.x) {
         int r = idx & 15, t = (idx >> 4) & 1, h = idx >> 5;
@@ -84,18 +72,23 @@ P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, c
         lds[P3D_LDS_B1P + idx] = b1[1 + p3d_rowof(r) + 4 * h];
     }
     if (threadIdx.x < 4) lds[P3D_LDS_B1S + threadIdx.x] = threadIdx.x == 0 ? b1[0] : 0.0f;
-#ifdef P3D_EXPERIMENT_TABLE_ACT
-    for (int i = threadIdx.x; i <= P3D_TAB_N; i += blockDim.x) {
-        const double hh = 1.0 / 16.0, u0 = i * hh, u1 = u0 + hh;
-        double g0 = log1p(exp(-u0)), g1 = log1p(exp(-u1)), dg0 = -1.0 / (1.0 + exp(u0)), dg1 = -1.0 / (1.0 + exp(u1));
-        double s0 = 1.0 / (1.0 + exp(-u0)), s1 = 1.0 / (1.0 + exp(-u1)), ds0 = s0 * (1 - s0), ds1 = s1 * (1 - s1);
-        if (i == P3D_TAB_N) { g0 = g1 = dg0 = dg1 = 0.0; s0 = s1 = 1.0; ds0 = ds1 = 0.0; }
-        float* a = lds + P3D_LDS_TAB_SP + 4 * i;
-        a[0] = (float)g0; a[1] = (float)(hh * dg0); a[2] = (float)(3 * (g1 - g0) - hh * (2 * dg0 + dg1)); a[3] = (float)(2 * (g0 - g1) + hh * (dg0 + dg1));
-        float* b = lds + P3D_LDS_TAB_SG + 4 * i;
-        b[0] = (float)s0; b[1] = (float)(hh * ds0); b[2] = (float)(3 * (s1 - s0) - hh * (2 * ds0 + ds1)); b[3] = (float)(2 * (s0 - s1) + hh * (ds0 + ds1));
+}
+
+// FAST kernels: the f16 hi/lo operand images.  Call AFTER p3d_load_mlp_to_lds (W1H overlays W1A, which such a kernel never
+// reads) and before its __syncthreads().
+P3D_DEV void p3d_load_mlp_f16_to_lds(float* lds, const float* w0, const float* w1) {
+    _Float16* w0h = (_Float16*)(lds + P3D_LDS_W0H);
+    _Float16* w1h = (_Float16*)(lds + P3D_LDS_W1H);
+    for (int idx = threadIdx.x; idx < 2048; idx += blockDim.x) {  // idx = ((t*2 + q) * 64 + l) * 8 + i
+        const int i = idx & 7, l = (idx >> 3) & 63, q = (idx >> 9) & 1, t = idx >> 10;
+        const int m = l & 31, hh = l >> 5;
+        const float a = w0[(32 * t + m) * 32 + 16 * hh + 8 * q + i];
+        const float b = w1[(1 + m) * 64 + 32 * t + p3d_rowof(8 * q + i) + 4 * hh];
+        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+        const int o = (((t * 2 + q) * 2) * 64 + l) * 8 + i;  // hi image of chunk (t,q); the lo image follows 64 lanes later
+        w0h[o] = ah; w0h[o + 512] = (_Float16)(a - (float)ah);
+        w1h[o] = bh; w1h[o + 512] = (_Float16)(b - (float)bh);
     }
-#endif
 }
 
 struct P3dPlaneGeom {
@@ -132,14 +125,12 @@ P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t
     off[3] = (vx1 && vy1) ? base + row + 128u : P3D_OOB_OFFSET;
 }
 
+// The lane's 64 B of one tap as four 16-B loads.  (Rotating the 16-B slot by the quad index — which removes the L1 slot
+// conflicts a micro-benchmark shows, tools/ubench/l1_gather.hip — was measured in the kernel and does not pay: the gathers
+// are not what the kernel waits on; profiles/r02_notes.txt.)
 template <typename RSRC>
 P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
     f32x16 v;
-#ifdef P3D_ABL_NOLOAD  // timing experiment: no gather traffic
-    float f = __builtin_bit_cast(float, off);
-    v = (f32x16){f, f, f, f, f, f, f, f, f, f, f, f, f, f, f, f};
-    return v;
-#endif
     i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
     i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off + 16, 0, 0);
     i32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off + 32, 0, 0);
@@ -154,28 +145,6 @@ P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
 }
 
 P3D_DEV f32x16 p3d_bilerp(const float wgt[4], const f32x16& v00, const f32x16& v01, const f32x16& v10, const f32x16& v11) {
-    f32x16 f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float a = wgt[0] * v00[c];
-        a = p3d_fma(wgt[1], v01[c], a);
-        a = p3d_fma(wgt[2], v10[c], a);
-        a = p3d_fma(wgt[3], v11[c], a);
-        f[c] = a;
-    }
-    return f;
-}
-
-template <typename RSRC>
-P3D_DEV f32x16 p3d_sample_plane(RSRC rs, const P3dPlaneGeom& g, uint32_t plane_off, uint32_t chan_off, float gx,
-                                float gy) {
-    uint32_t off[4];
-    float wgt[4];
-    p3d_tap_offsets(g, plane_off, chan_off, gx, gy, off, wgt);
-    f32x16 v00 = p3d_load16(rs, off[0]);
-    f32x16 v01 = p3d_load16(rs, off[1]);
-    f32x16 v10 = p3d_load16(rs, off[2]);
-    f32x16 v11 = p3d_load16(rs, off[3]);
     f32x16 f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -206,41 +175,87 @@ struct P3dDecodeCfg {
 // rowof(r) + 4h  (channels {0-3,8-11,16-19,24-27} for h = 0, {4-7,12-15,20-23,28-31} for h = 1).
 // live = false on a lane: its gathers are suppressed (see p3d_tap_offsets) and its outputs are garbage except that the
 // position-only crop mask still applies.
+// compiler barrier that makes 16 values "observed" at this point of the program (no instruction is emitted)
+P3D_DEV void p3d_pin16(f32x16& v) {
+    asm volatile("" : "+v"(v.s0), "+v"(v.s1), "+v"(v.s2), "+v"(v.s3), "+v"(v.s4), "+v"(v.s5), "+v"(v.s6), "+v"(v.s7), "+v"(v.s8),
+                      "+v"(v.s9), "+v"(v.sa), "+v"(v.sb), "+v"(v.sc), "+v"(v.sd), "+v"(v.se), "+v"(v.sf) : : "memory");
+}
+#ifndef P3D_GATHER_DEPTH
+#define P3D_GATHER_DEPTH 4  // taps in flight per lane (2 / 3 / 4 / 6 measured within 3 % of each other: profiles/r02_notes.txt)
+#endif
+// This lane's 16 interpolated feature channels (16h .. 16h+15) of the sample at (px,py,pz): the three bilinear plane samples
+// and their mean (renderer.py:68-81, triplane.py:530).
+template <typename RSRC>
+P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz,
+                                   bool live) {
+    const int h = __lane_id() >> 5;
+    const uint32_t chan_off = (uint32_t)h * 64u;
+    float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
+    // generate_planes / project_onto_planes: renderer.py:26-66
+    // Tap-granular software pipeline: P3D_GATHER_DEPTH of the 12 taps (16 registers each) are in flight while the oldest one
+    // is folded into its plane's bilinear sum, in the contract's order (nw, ne, sw, se; plane 0 + plane 1, + plane 2, x 1/3).
+    // The depth bounds the live tap registers (the compiler would otherwise hoist all 48 loads = 192 VGPRs).
+    float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
+    uint32_t of[12];
+    float wg[12];
+    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of, wg, live);
+    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of + 4, wg + 4, live);
+    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of + 8, wg + 8, live);
+    f32x16 tap[P3D_GATHER_DEPTH];
+#pragma unroll
+    for (int k = 0; k < P3D_GATHER_DEPTH; ++k) tap[k] = p3d_load16(rs, of[k]);
+    f32x16 X, f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 v = tap[k % P3D_GATHER_DEPTH];
+        if ((k & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) f[c] = wg[k] * v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) f[c] = p3d_fma(wg[k], v[c], f[c]);
+        }
+        if (k == 3) X = f;
+        if (k == 7) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) X[c] = X[c] + f[c];
+        }
+        if (k == 11) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) X[c] = (X[c] + f[c]) * P3D_THIRD;  // triplane.py:530 mean(1)
+        }
+        // pin the partial sums here: without it the compiler sinks all the arithmetic below the last load (sched_barrier only
+        // orders machine instructions that already sit on either side of it) and every tap stays live
+        p3d_pin16(f);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + P3D_GATHER_DEPTH < 12) tap[k % P3D_GATHER_DEPTH] = p3d_load16(rs, of[k + P3D_GATHER_DEPTH]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return X;
+}
+
+// masks on raw sigma: renderer.py:138-153,187-198
+P3D_DEV float p3d_apply_masks(const P3dDecodeCfg& cfg, float px, float pz, float sigma) {
+    if (cfg.flags & P3D_FLAG_CROP) {
+        if (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit) sigma = P3D_SIGMA_MASKED;
+    }
+    if (cfg.flags & (P3D_FLAG_CULL | P3D_FLAG_BINARIZE)) {
+        float a = 1.0f - p3d_exp_nonpos(-p3d_softplus(sigma - 1.0f));
+        if (cfg.flags & P3D_FLAG_BINARIZE)
+            sigma = (a < cfg.cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
+        else if (a < cfg.cull_thresh)
+            sigma = P3D_SIGMA_MASKED;
+    }
+    return sigma;
+}
+
 template <bool WANT_RGB, typename RSRC>
 P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                              float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
     const int lane = __lane_id();
     const int h = lane >> 5;
-    const uint32_t chan_off = (uint32_t)h * 64u;
-    float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
-    // generate_planes / project_onto_planes: renderer.py:26-66
-    // Plane-at-a-time software pipeline: the taps of plane p+1 are in flight while plane p is interpolated, which bounds
-    // the live tap registers to 2 x 64 (the compiler would otherwise hoist all 48 loads = 192 VGPRs).
-    float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
-    uint32_t of0[4], of1[4], of2[4];
-    float wg0[4], wg1[4], wg2[4];
-    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of0, wg0, live);
-    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of1, wg1, live);
-    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of2, wg2, live);
-    f32x16 a00 = p3d_load16(rs, of0[0]), a01 = p3d_load16(rs, of0[1]), a10 = p3d_load16(rs, of0[2]), a11 = p3d_load16(rs, of0[3]);
-    f32x16 b00 = p3d_load16(rs, of1[0]), b01 = p3d_load16(rs, of1[1]), b10 = p3d_load16(rs, of1[2]), b11 = p3d_load16(rs, of1[3]);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 X = p3d_bilerp(wg0, a00, a01, a10, a11);
-    __builtin_amdgcn_sched_barrier(0);
-    a00 = p3d_load16(rs, of2[0]); a01 = p3d_load16(rs, of2[1]); a10 = p3d_load16(rs, of2[2]); a11 = p3d_load16(rs, of2[3]);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        f32x16 f1 = p3d_bilerp(wg1, b00, b01, b10, b11);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) X[c] = X[c] + f1[c];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        f32x16 f2 = p3d_bilerp(wg2, a00, a01, a10, a11);
-#pragma unroll
-        for (int c = 0; c < 16; ++c) X[c] = (X[c] + f2[c]) * P3D_THIRD;  // triplane.py:530 mean(1)
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
 
     // ---- layer 1 on the matrix cores: acc[t][r] = b0[n] + sum_k w0[n][k] X[k], n = 32t + rowof(r) + 4h
     const f32x4* b0p = (const f32x4*)(lds + P3D_LDS_B0P + h * 32);
@@ -264,8 +279,8 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // Softplus: triplane.py:524
-        acc0[r] = P3D_ACT_SOFTPLUS(lds, acc0[r]);
-        acc1[r] = P3D_ACT_SOFTPLUS(lds, acc1[r]);
+        acc0[r] = p3d_softplus(acc0[r]);
+        acc1[r] = p3d_softplus(acc1[r]);
     }
     // ---- sigma row on the VALU: two half chains joined across the lane pair (triplane.py:543)
     const f32x4* w1s = (const f32x4*)(lds + P3D_LDS_W1S + h * 32);
@@ -304,16 +319,118 @@ P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, c
         const bool fs = (cfg.flags & P3D_FLAG_FORCE_SIGMOID) != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float sg = P3D_ACT_SIGMOID(lds, o[r]);
+            float sg = p3d_sigmoid(o[r]);
             rgb[r] = fs ? sg : sg * 1.002f - 0.001f;
         }
     }
-    // ---- masks on raw sigma: renderer.py:138-153,187-198
+    sigma_out = p3d_apply_masks(cfg, px, pz, sigma);
+}
+
+// ---- tolerance-mode decode (P3D_FLAG_FAST_COLOR, final pass only) -----------------------------------------------------
+// two f16 terms of 8 values: hi = x truncated to f16 (v_cvt_pkrtz), lo = f16(x - hi)
+P3D_DEV void p3d_split_f16x8(const float* x, f16x8& hi, f16x8& lo) {
+    uint32_t uh[4], ul[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const f16x2 ph = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+        const float ra = a - (float)ph[0], rb = b - (float)ph[1];
+        uh[i] = __builtin_bit_cast(uint32_t, ph);
+        ul[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(f16x8, (u32x4){uh[0], uh[1], uh[2], uh[3]});
+    lo = __builtin_bit_cast(f16x8, (u32x4){ul[0], ul[1], ul[2], ul[3]});
+}
+// softplus / sigmoid on the hardware transcendentals (v_exp_f32 = 2^x, v_log_f32 = log2, v_rcp_f32; ~1 ulp each)
+P3D_DEV float p3d_softplus_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(x) * P3D_LOG2E);
+    return p3d_fma(__builtin_amdgcn_logf(1.0f + e), 0x1.62e430p-1f, __builtin_fmaxf(x, 0.0f));
+}
+P3D_DEV float p3d_sigmoid_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(-x * P3D_LOG2E);  // +inf for x < -88: 1 / inf = 0
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Same interface and lane layout as p3d_decode_wave<true>; lds must also hold the f16 images (p3d_load_mlp_f16_to_lds).
+// Domain: |interpolated feature| and hidden activations below the f16 range (65504); results agree with the exact decode to
+// ~1e-6 (sigma, relative to the magnitude of the sum's terms) / ~3e-7 (colours).
+template <typename RSRC>
+P3D_DEV void p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
+                                  float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
+    const int lane = __lane_id();
+    const int h = lane >> 5;
+    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
+    float xs[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) xs[c] = X[c];
+    f16x8 xh0, xl0, xh1, xl1;
+    p3d_split_f16x8(xs, xh0, xl0);
+    p3d_split_f16x8(xs + 8, xh1, xl1);
+    // ---- layer 1: acc[t] = b0 + W0 X, K = 32 as two chunks of 16 (lane (j,h) supplies channels 16h + 8q + i)
+    const f32x4* b0p = (const f32x4*)(lds + P3D_LDS_B0P + h * 32);
+    f32x16 acc0, acc1;
+    {
+        f32x4 q0 = b0p[0], q1 = b0p[1], q2 = b0p[2], q3 = b0p[3];
+        f32x4 r0 = b0p[4], r1 = b0p[5], r2 = b0p[6], r3 = b0p[7];
+        acc0 = (f32x16){q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        acc1 = (f32x16){r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    }
+    const f16x8* w0h = (const f16x8*)(lds + P3D_LDS_W0H) + lane;  // [(t*2+q)*2 + hi/lo][64 lanes]
+    {
+        const f16x8 a00h = w0h[0 * 64], a00l = w0h[1 * 64], a01h = w0h[2 * 64], a01l = w0h[3 * 64];
+        const f16x8 a10h = w0h[4 * 64], a10l = w0h[5 * 64], a11h = w0h[6 * 64], a11l = w0h[7 * 64];
+        acc0 = P3D_MFMA_H(a00h, xl0, acc0); acc1 = P3D_MFMA_H(a10h, xl0, acc1);
+        acc0 = P3D_MFMA_H(a00l, xh0, acc0); acc1 = P3D_MFMA_H(a10l, xh0, acc1);
+        acc0 = P3D_MFMA_H(a01h, xl1, acc0); acc1 = P3D_MFMA_H(a11h, xl1, acc1);
+        acc0 = P3D_MFMA_H(a01l, xh1, acc0); acc1 = P3D_MFMA_H(a11l, xh1, acc1);
+        acc0 = P3D_MFMA_H(a00h, xh0, acc0); acc1 = P3D_MFMA_H(a10h, xh0, acc1);
+        acc0 = P3D_MFMA_H(a01h, xh1, acc0); acc1 = P3D_MFMA_H(a11h, xh1, acc1);
+    }
+    float hs[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // Softplus: triplane.py:524
+        hs[r] = p3d_softplus_hw(acc0[r]);
+        hs[16 + r] = p3d_softplus_hw(acc1[r]);
+    }
+    // ---- sigma row on the VALU, fp32 weights and activations (triplane.py:543)
+    const f32x4* w1s = (const f32x4*)(lds + P3D_LDS_W1S + h * 32);
+    float sa = (h == 0) ? lds[P3D_LDS_B1S] : 0.0f;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+        f32x4 w = w1s[s4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sa = p3d_fma(w[e], hs[4 * s4 + e], sa);
+    }
+    float sigma = sa + p3d_partner(sa);
+    // ---- layer 2 rows 1..32: K = 64 as four chunks (t, pp): lane (j,h) supplies neurons 32t + rowof(8pp + i) + 4h
+    {
+        const f32x4* b1p = (const f32x4*)(lds + P3D_LDS_B1P + h * 16);
+        f32x4 q0 = b1p[0], q1 = b1p[1], q2 = b1p[2], q3 = b1p[3];
+        f32x16 o = (f32x16){q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        const f16x8* w1h = (const f16x8*)(lds + P3D_LDS_W1H) + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f16x8 hh, hl;
+            p3d_split_f16x8(hs + 8 * c, hh, hl);
+            const f16x8 ah = w1h[(2 * c) * 64], al = w1h[(2 * c + 1) * 64];
+            o = P3D_MFMA_H(ah, hl, o);
+            o = P3D_MFMA_H(al, hh, o);
+            o = P3D_MFMA_H(ah, hh, o);
+        }
+        const bool fs = (cfg.flags & P3D_FLAG_FORCE_SIGMOID) != 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sg = p3d_sigmoid_hw(o[r]);
+            rgb[r] = fs ? sg : sg * 1.002f - 0.001f;
+        }
+    }
+    // ---- masks (hardware transcendentals here too)
     if (cfg.flags & P3D_FLAG_CROP) {
         if (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit) sigma = P3D_SIGMA_MASKED;
     }
     if (cfg.flags & (P3D_FLAG_CULL | P3D_FLAG_BINARIZE)) {
-        float a = 1.0f - p3d_exp_nonpos(-p3d_softplus(sigma - 1.0f));
+        float a = 1.0f - __builtin_amdgcn_exp2f(-p3d_softplus_hw(sigma - 1.0f) * P3D_LOG2E);
         if (cfg.flags & P3D_FLAG_BINARIZE)
             sigma = (a < cfg.cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
         else if (a < cfg.cull_thresh)

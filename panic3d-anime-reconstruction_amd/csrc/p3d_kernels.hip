@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "p3d_decode.hpp"
 
 #define P3D_WAVES_PER_WG 4
@@ -266,10 +268,15 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 //   the neighbour >= ~794); that is checked on the exact weights and, if it ever happens, the sample is decoded after
 //   all — results are bit-identical by construction.
 // the host picks the workgroup size (1, 2 or 4 waves) that fills the CU's 160 KB of LDS best
-template <int NF, bool DUMP>
+// FAST (P3D_FLAG_FAST_COLOR): the FINAL pass decodes in tolerance mode (p3d_decode_wave_fast); the coarse pass, and with it
+// the importance resampling (inverse-CDF indices, fine depths, merged depth order), stays on the exact contract.
+// EARLY: the exact early-outs (compile-time, so that the measurement / dump variant is the plain uniform loop).
+template <int NF, bool DUMP, bool FAST, bool EARLY>
 __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParams p) {
+    static_assert(!(DUMP && EARLY), "dumps need every sample decoded");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
+    if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     // XCD-aware block swizzle: hardware places block b on XCD b % 8; give each XCD a contiguous range of tiles so that
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     const int nwaves = blockDim.x >> 6;
     long long tile = bs * nwaves + wave;
     if (tile >= p.ntiles) return;  // no workgroup barrier below this line
-    float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;  // per-wave rows, 16-B aligned
+    float* wl = lds + (FAST ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4 + (size_t)wave * p.lds_rows * 32;  // per-wave rows, 16-B aligned
 
     const int Sc = p.Sc, Sf = p.Sf, S = Sc + Sf;
     long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     const float* pbase = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
     auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
     const P3dDecodeCfg cfg = p.cfg;
-    const bool early = !DUMP && !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);
+    constexpr bool early = EARLY;
     const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0;
     int ndec = 0;  // decode steps this wave executed (statistics)
 
@@ -323,10 +330,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     float* tcA = wl;             // [Sc]            coarse depths
     float* wcA = tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
     float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;  // [Sf] sorted fine depths
+    uint32_t* mkA = (uint32_t*)(wl + (size_t)(p.lds_rows - ((Sc + 31) >> 5)) * 32);  // [ceil(Sc/32)] known-masked bits of the coarse samples
     const bool dump = DUMP && active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
     bool unsorted = false;
+    float tcmin = __builtin_inff(), tcmax = -__builtin_inff();  // extrema of the coarse depths
     {
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
@@ -337,6 +346,8 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
             tcA[i * 32 + j] = t;
             unsorted |= (t < prev);
             prev = t;
+            tcmin = __builtin_fminf(tcmin, t);
+            tcmax = __builtin_fmaxf(tcmax, t);
             if constexpr (DUMP) if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
         }
     }
@@ -345,19 +356,24 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
         // ---- coarse pass, densities only -> ray-marcher weights: renderer.py:179-211
         MarchState st;
         st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+        uint32_t mword = 0;  // bit i & 31: coarse sample i is KNOWN to carry sigma = -1000 (cropped, or really decoded and masked)
         for (int i = 0; i < Sc; ++i) {
             float t = tcA[i * 32 + j];
             float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
             float sigma = P3D_SIGMA_MASKED;
-            bool skip = false, live = true;
+            bool skip = false, live = true, cropped = false;
             if (early) {
-                bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+                cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
                 live = !(cropped || st.Td < 1e-60);  // a cropped sample is -1000 by position; a dead ray's weights are 0
                 skip = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skip) {
                 f32x16 dummy;
                 p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+            }
+            if (early) {  // a lane whose gathers were suppressed (dead ray) decoded garbage: its sample is NOT known to be masked
+                mword |= (cropped || (live && sigma == P3D_SIGMA_MASKED)) ? (1u << (i & 31)) : 0u;
+                if ((i & 31) == 31 || i == Sc - 1) { mkA[(i >> 5) * 32 + j] = mword; mword = 0; }
             }
             if constexpr (DUMP) if (dump && p.dumps.sigma_coarse) p.dumps.sigma_coarse[ray * Sc + i] = sigma;
             if (i > 0) {
@@ -428,76 +444,126 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
         // reversed two neighbours (practically never) — then sort it too.
         if (__builtin_amdgcn_ballot_w64(unsorted) != 0) p3d_lds_insertion_sort(tcA, Sc, j);
     }
-    // ---- final pass: merge on the fly (ties: coarse first = stable), decode every sample, composite [rgb | xyz]:
-    //      renderer.py:243-259, ray_marcher.py:25-57
+    // ---- final pass: merge on the fly (ties: coarse first = stable), decode, composite [rgb | xyz]:
+    //      renderer.py:243-259, ray_marcher.py:25-57.
+    // Every lane walks ITS OWN merged list.  With the early-outs on, a lane first consumes — without a decode — every sample
+    // whose sigma = -1000 is already known (cropped by position, or a coarse sample the coarse pass really decoded and found
+    // masked) while the previous sample's sigma is <= 602: the interval's softplus argument is then <= -200, rho = alpha = w = 0
+    // and Td * (double)(1.0f + 1e-10f) = Td, i.e. the marcher update is exactly the identity (include/p3d_numerics.h); only
+    // prev_t / prev_sigma move.  A dead ray (Td < 1e-60: every later weight is exactly 0) drops all its remaining samples.
+    // What is left — the samples that can matter — is decoded one per wave-step until every lane has finished, so a tile of
+    // rays that miss the subject runs ~Sf/2 steps instead of Sc + Sf.  A consumed sample's colour is fetched after all if one
+    // of its interval weights turns out non-zero (sigma of a neighbour >= ~794): results are bit-identical by construction.
     MarchState st;
     st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
     f32x16 C, prev_rgb;
-    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
+    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
     {
         int ci = 0, fi = 0;
         float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
-        bool prev_skipped = false;
-        for (int m = 0; m < S; ++m) {
-            bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
-            const float t = take_c ? ta : tb;
+        // the extrema of all depths of the ray (the global clamp range, ray_marcher.py:50); the fine list is sorted
+        tmin = __builtin_fminf(tcmin, tb);
+        tmax = __builtin_fmaxf(tcmax, (Sf > 0) ? tfA[(Sf - 1) * 32 + j] : -__builtin_inff());
+        bool prev_skipped = false, first = true, done = false;
+        int m = 0;  // samples of this lane consumed so far (dump index)
+        auto is_cropped = [&](float t) {
+            const float px = ox + t * dx, pz = oz + t * dz;
+            return f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+        };
+        auto advance = [&](bool take_c) {  // pop the head of the coarse or of the fine list
             ci += take_c ? 1 : 0;
             fi += take_c ? 0 : 1;
             if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
             else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
-            tmin = __builtin_fminf(tmin, t);
-            tmax = __builtin_fmaxf(tmax, t);
+            done = (ci >= Sc) && (fi >= Sf);
+        };
+        for (int it = 0;; ++it) {
+            if constexpr (!EARLY) {
+                if (it >= S) break;  // every lane takes exactly one sample per step: the plain uniform loop
+            }
+            if (early) {
+                while (!done) {
+                    if (st.Td < 1e-60) { done = true; break; }
+                    const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+                    const float t = take_c ? ta : tb;
+                    bool known = is_cropped(t);
+                    if (!known && take_c && Sf > 0) known = (mkA[(ci >> 5) * 32 + j] >> (ci & 31)) & 1u;  // Sf == 0: no coarse pass ran
+                    if (!(known && (first || st.prev_sigma <= 602.0f))) break;
+                    advance(take_c);
+                    st.prev_t = t; st.prev_sigma = P3D_SIGMA_MASKED;
+                    prev_skipped = true; first = false;
+                    ++m;
+                }
+            }
+            if constexpr (EARLY) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            }
+            const bool have = EARLY ? !done : true;
+            const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+            const float t = take_c ? ta : tb;
             const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            bool known = false;  // sigma = -1000 known without a decode (reached here only behind a sigma > 602)
+            if (early && have) {
+                known = is_cropped(t);
+                if (!known && take_c && Sf > 0) known = (mkA[(ci >> 5) * 32 + j] >> (ci & 31)) & 1u;  // Sf == 0: no coarse pass ran
+            }
+            if (have) advance(take_c);
             float sigma = P3D_SIGMA_MASKED;
             f32x16 rgb;
 #pragma unroll
             for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
-            bool skipped = false, live = true;
-            if (early) {
-                bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
-                live = !(cropped || st.Td < 1e-60);
-                skipped = __builtin_amdgcn_ballot_w64(live) == 0;
-            }
-            if (!skipped) {
-                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+            const bool live = have && !known;
+            bool skipped = true;
+            if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
-                skipped = !live;  // per lane: a lane whose gathers were suppressed has no colour either
+                skipped = !live;  // per lane: a lane whose gathers were suppressed has no colour
+                if (known) sigma = P3D_SIGMA_MASKED;
             }
             if constexpr (DUMP) {
                 if (dump && p.dumps.depths_sorted) p.dumps.depths_sorted[ray * S + m] = t;
                 if (dump && p.dumps.sigma_sorted) p.dumps.sigma_sorted[ray * S + m] = sigma;
             }
-            if (m > 0) {
-                float tm;
-                float w = p3d_march_weight(st, t, sigma, tm);
-                if (early) {  // exactness guard: a skipped endpoint whose interval weight is non-zero needs its real colour
-                    if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
-                        float s2;
-                        f32x16 c2;
-                        p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
-                        if (prev_skipped) prev_rgb = c2;
-                        prev_skipped = false;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(skipped && w != 0.0f) != 0) {
-                        float s2;
-                        p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
-                        skipped = false;
-                    }
+            // (the guard decodes below are wave-level operations: every lane must reach them, also the ones without a sample)
+            const bool marching = have && !first;
+            float w = 0.0f, tm = 0.0f;
+            if (marching) w = p3d_march_weight(st, t, sigma, tm);
+            const float ppx = ox + st.prev_t * dx, ppy = oy + st.prev_t * dy, ppz = oz + st.prev_t * dz;
+            if (early) {  // exactness guard: a skipped endpoint whose interval weight is non-zero needs its real colour
+                if (__builtin_amdgcn_ballot_w64(marching && prev_skipped && w != 0.0f) != 0) {
+                    float s2;
+                    f32x16 c2;
+                    if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                    else p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                    if (prev_skipped) prev_rgb = c2;
+                    prev_skipped = false;
                 }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
-                Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
-                Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
-                Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
-                st.W = st.W + w;
-                st.D = p3d_fma(w, tm, st.D);
+                if (__builtin_amdgcn_ballot_w64(marching && skipped && w != 0.0f) != 0) {
+                    float s2;
+                    if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                    else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                    skipped = false;
+                }
             }
-            st.prev_t = t; st.prev_sigma = sigma;
-            prev_rgb = rgb;
-            prev_skipped = skipped;
-            ppx = px; ppy = py; ppz = pz;
+            if (have) {
+                if (!first) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+                    Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+                    Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+                    Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                    st.W = st.W + w;
+                    st.D = p3d_fma(w, tm, st.D);
+                }
+                st.prev_t = t; st.prev_sigma = sigma;
+                prev_rgb = rgb;
+                prev_skipped = skipped;
+                first = false;
+                ++m;
+            }
         }
     }
     // ---- outputs.  white_back and the [-1,1] rescale are per ray (ray_marcher.py:52-55); the depth clamp is global.
@@ -1022,6 +1088,24 @@ static inline int p3d_check_launch() {
     return e == hipSuccess ? P3D_OK : (int)e;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (kernel, device): raise it only when a launch needs more than any
+// earlier one did (one call per kernel instantiation in steady state instead of one per launch).
+template <typename K>
+static hipError_t p3d_ensure_dynamic_lds(K kernel, size_t bytes) {
+    static std::atomic<size_t> granted[64];  // per instantiation, indexed by device ordinal
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<size_t>& g = granted[dev & 63];
+    if (bytes <= g.load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) {
+        size_t cur = g.load(std::memory_order_relaxed);
+        while (cur < bytes && !g.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    }
+    return e;
+}
+
 static P3dDecodeCfg make_cfg(const p3d_opts* o) {
     P3dDecodeCfg c;
     c.coord_scale = o->coord_scale;
@@ -1129,12 +1213,13 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     p.ntiles = p.tiles_per_img * N;
     // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
     const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
-    p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0);
+    p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0) + ((Sc + 31) >> 5);  // + the known-masked bits of the coarse samples
     int nwaves = P3D_RENDER_WAVES;
     // small ray counts (e.g. the pipeline's 128^2 rays = 512 tiles): shrink the workgroup so that every CU gets work
     while (nwaves > 1 && p.ntiles / nwaves < 2 * 256) nwaves >>= 1;
     size_t lds_bytes;
-    const size_t lds_fixed = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4, lds_wave = (size_t)p.lds_rows * 128;
+    const bool fast = (opts->flags & P3D_FLAG_FAST_COLOR) != 0 && Sf > 0;
+    const size_t lds_fixed = (size_t)((fast ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4) * 4, lds_wave = (size_t)p.lds_rows * 128;
     if (nwaves == P3D_RENDER_WAVES) {
         // large launch: the workgroup shape (4, 2 or 1 waves, as many workgroups as fit) that puts most waves on a CU, at
         // most 8 (two per SIMD: the register cap); ties go to the LARGER workgroup.  48+48: 2 x 4 waves; 64+64: 3 x 2 instead of
@@ -1159,7 +1244,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     const bool dmp = dumps != nullptr;
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
-    if (!dmp && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
+    if (!dmp && !fast && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
         else p.tiles_per_img = (R + 15) / 16;
         p.ntiles = p.tiles_per_img * N;
@@ -1173,8 +1258,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         hipError_t e2 = hipSuccess;
 #define P3D_LAUNCH2(NFV)                                                                                             \
     do {                                                                                                             \
-        e2 = hipFuncSetAttribute((const void*)k_render_pair<NFV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                 (int)lds_bytes);                                                                    \
+        e2 = p3d_ensure_dynamic_lds(k_render_pair<NFV>, lds_bytes);                                                  \
         if (e2 == hipSuccess) hipLaunchKernelGGL((k_render_pair<NFV>), grid2, blk2, lds_bytes, st, p);              \
     } while (0)
         if (nf == 64) P3D_LAUNCH2(64);
@@ -1192,13 +1276,18 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     p.swz = 16;  // measured: 8..64 within 0.5 %, 1..4 and >= 256 about 1-3 % slower
     dim3 grid((unsigned)blocks), blk(64 * nwaves);
     hipError_t e = hipSuccess;
-#define P3D_LAUNCH(NFV, DV)                                                                                          \
+#define P3D_LAUNCH(NFV, DV, FV, EV)                                                                                  \
     do {                                                                                                             \
-        e = hipFuncSetAttribute((const void*)k_render<NFV, DV>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                (int)lds_bytes);                                                                     \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, DV>), grid, blk, lds_bytes, st, p);                  \
+        e = p3d_ensure_dynamic_lds(k_render<NFV, DV, FV, EV>, lds_bytes);                                            \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, DV, FV, EV>), grid, blk, lds_bytes, st, p);          \
     } while (0)
-#define P3D_LAUNCH_P(NFV) do { if (dmp) P3D_LAUNCH(NFV, true); else P3D_LAUNCH(NFV, false); } while (0)
+#define P3D_LAUNCH_F(NFV, FV)                                                                                        \
+    do {                                                                                                             \
+        if (dmp) P3D_LAUNCH(NFV, true, FV, false);                                                                   \
+        else if (opts->flags & P3D_FLAG_NO_EARLY_OUT) P3D_LAUNCH(NFV, false, FV, false);                             \
+        else P3D_LAUNCH(NFV, false, FV, true);                                                                       \
+    } while (0)
+#define P3D_LAUNCH_P(NFV) do { if (fast) P3D_LAUNCH_F(NFV, true); else P3D_LAUNCH_F(NFV, false); } while (0)
     if (nf == 64) P3D_LAUNCH_P(64);
     else if (nf == 128) P3D_LAUNCH_P(128);
     else P3D_LAUNCH_P(0);

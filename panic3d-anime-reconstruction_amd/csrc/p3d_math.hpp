@@ -58,9 +58,6 @@ P3D_DEV float p3d_log1p01(float z) {
 
 // torch Softplus(beta=1, threshold=20).  No threshold select: for x > 20 the sum already rounds to x (p3d_numerics.h).
 P3D_DEV float p3d_softplus(float x) {
-#ifdef P3D_ABL_NOTRANS  // timing experiment: no transcendental polynomials
-    return __builtin_fmaxf(x, 0.0f);
-#endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
     return __builtin_fmaxf(x, 0.0f) + p3d_log1p01(z);
 }
@@ -77,9 +74,6 @@ P3D_DEV float p3d_rcp12(float d) {
 }
 
 P3D_DEV float p3d_sigmoid(float x) {
-#ifdef P3D_ABL_NOTRANS
-    return x * 0.25f + 0.5f;
-#endif
     float z = p3d_exp_nonpos(-__builtin_fabsf(x));
     float r = p3d_rcp12(1.0f + z);
     return (x >= 0.0f) ? r : z * r;

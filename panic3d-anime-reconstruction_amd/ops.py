@@ -33,7 +33,7 @@ def _p(t):
 
 
 def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_clouds=None, force_sigmoid=False,
-              early_out=True, small_launch_kernel=True):
+              early_out=True, small_launch_kernel=True, fast_color=False):
     """rendering_kwargs + ImportanceRenderer.forward arguments (renderer.py:162) -> p3d_opts.
     The double -> binary32 conversions are the ones include/p3d_numerics.h states."""
     ro = rendering_options
@@ -68,6 +68,8 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= _lib.P3D_FLAG_NO_EARLY_OUT
     if not small_launch_kernel:  # keep small launches on the 32-rays-per-wave kernel (tests)
         flags |= _lib.P3D_FLAG_NO_PAIR
+    if fast_color:  # opt-in tolerance mode of the final pass (include/panic3d_hip.h P3D_FLAG_FAST_COLOR)
+        flags |= _lib.P3D_FLAG_FAST_COLOR
     rs, re = float(ro["ray_start"]), float(ro["ray_end"])
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
@@ -256,7 +258,8 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         steps = int(ws[8:16].view(torch.int64).item())
         tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)
         tiles = (R // 32) * N if tiled else -(-R // 32) * N
-        pair = not dumps and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
+        fast = bool(opts.flags & _lib.P3D_FLAG_FAST_COLOR) and Sf > 0
+        pair = not dumps and not fast and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
         if pair:  # 16 rays x 2 samples per wave-step
             tiles = (R // 16) * N if tiled else -(-R // 16) * N
             full = tiles * ((-(-Sc // 2) + -(-(Sc + Sf) // 2)) if Sf > 0 else -(-Sc // 2))

@@ -20,6 +20,7 @@ for scene in $SCENES; do
     FL="--scene $scene"; [ "$mode" = noearly ] && FL="$FL --no-early-out"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_${scene}_${mode}" -o r -- $B $FL --steps 30 --warmup 3 \
       > "$OUT/stats_${scene}_${mode}.json" 2> "$OUT/stats_${scene}_${mode}.log"
+    [ "${PMC:-1}" = 0 ] && continue
     for grp in sq tcp fetch write; do
       case $grp in
         sq)    C="SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ;;
