@@ -24,6 +24,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
+ * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
+#define P3D_ABI_VERSION 3
+
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
 #define P3D_E_RANGE (-2)     /* Sc/Sf/H/W/C outside what the kernels support */
@@ -44,6 +48,10 @@ extern "C" {
                                    coarse pass — hence the inverse-CDF indices, the fine depths and the merged depth order —
                                    stays on the exact contract; feat / depth / wsum / xyz agree with it to fp32 tolerance
                                    (tests/test_hip_parity.py::test_fast_color_*). */
+#define P3D_FLAG_PER_VIEW_CLAMP 1024 /* p3d_render_f32: clamp each of the N images' depths to that image's own [min t, max t] instead
+                                        of the call's (ray_marcher.py:49-50 takes torch.min/max over the whole batch).  For callers that
+                                        batch what the reference renders as N separate calls (generate.py's view loop): the batched
+                                        launch then reproduces the per-view results bit for bit, depth included. */
 #define P3D_FLAG_SHARED_PLANES 64 /* planes holds ONE image [1][3][H][W][32] shared by all N batches of rays / points (many
                                     views of one subject in one launch; the reference would pass planes.expand(N, ...)) */
 
@@ -110,7 +118,9 @@ int p3d_grid_density_f32(const float* planes_nhwc, int H, int W, int grid_n, int
  * ray_tile_w: image width in rays if the R rays are a row-major ray_tile_w x (R/ray_tile_w) image (enables 8x4 screen
  * tiles per wavefront), 0 for an unstructured ray list.  Outputs feat [N][R][32], depth [N][R], wsum [N][R],
  * xyz [N][R][3].  workspace: p3d_render_workspace_bytes bytes of device memory: u32[0..1] = order-mapped global depth
- * min / max, u64 at byte 8 = number of wave-level decode steps the launch executed (statistics; 32 samples each). */
+ * min / max, u64 at byte 8 = number of wave-level decode steps the launch executed (statistics; 32 samples each), then one
+ * min / max pair per view.  Depth clamp scope (ray_marcher.py:49-50): the whole call, like the reference's batch of N images;
+ * with P3D_FLAG_PER_VIEW_CLAMP each image is clamped to its own range (N views batched by the caller = N calls of the reference). */
 size_t p3d_render_workspace_bytes(int N, int64_t R, int Sc, int Sf);
 int p3d_render_f32(const float* planes_nhwc, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
                    int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
@@ -122,8 +132,13 @@ int p3d_render_f32(const float* planes_nhwc, int N, int H, int W, const float* r
 int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta, int S, const float* jitter, int64_t NR,
                               float* out_depths, void* stream);
 
+/* torch.min(depths), torch.max(depths) of ray_marcher.py:50 — the one cross-ray dependency of the path — as its own entry
+ * point: depths [n] -> out_minmax [2] (device).  workspace: >= 16 bytes of device memory. */
+int p3d_depth_minmax_f32(const float* depths, int64_t n, float* out_minmax, void* workspace, size_t workspace_bytes, void* stream);
+
 /* MipRayMarcher2.run_forward (ray_marcher.py:25-57).  colors [NR][S][K], sigma [NR][S], depths [NR][S] ->
- * out_rgb [NR][K], out_depth [NR], out_weights [NR][S-1] (may be NULL).  workspace: 16 bytes (global depth min/max). */
+ * out_rgb [NR][K], out_depth [NR], out_weights [NR][S-1] (may be NULL).  workspace: p3d_composite_workspace_bytes bytes. */
+size_t p3d_composite_workspace_bytes(int64_t NR, int S, int K);
 int p3d_composite_f32(const float* colors, const float* sigma, const float* depths, int64_t NR, int S, int K,
                       int white_back, float* out_rgb, float* out_depth, float* out_weights, void* workspace,
                       void* stream);
@@ -144,12 +159,22 @@ int p3d_unify_perm_f32(const float* depths_coarse, const float* depths_fine, int
  * demodulate: multiply the output by rsqrt(sum (w*s)^2 + 1e-8) (:70-73); noise: NULL, [OH*OW] (noise_const * strength)
  * or [N][OH*OW] (noise_per_sample = 1), added before the bias (:95-96); bias [O] or NULL; up 1 or 2 (up = 2: stride-2
  * transposed conv + 4x4 FIR `fir` = setup_filter([1,3,3,1]) flipped and multiplied by up^2, conv2d_resample.py:114-128);
- * act 0 linear / 1 lrelu(alpha); then *gain and clamp (< 0: none) as bias_act.py:93-122.  y [N][O][H*up][W*up]. */
+ * act 0 linear / 1 lrelu(alpha); then *gain and clamp (< 0: none) as bias_act.py:93-122.  y [N][O][H*up][W*up].
+ * demod_coefs: NULL, or the [N][O] coefficients already computed by p3d_demod_coefs_f32 (then no per-call reduction over the
+ * weights is launched); ignored unless demodulate. */
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up);
 int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
-                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
-                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                      int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias,
+                      int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* The demodulation coefficients (networks_stylegan2.py:70-73) of L modulated convolutions in one launch:
+ * d[n][o] = rsqrt(sum_i W2[o][i] * styles[n][i]^2 + 1e-8) with W2[o][i] = sum over the taps of w[o][i][.]^2, which the caller
+ * caches per layer (it changes only with the weights).  w2 / styles / d hold the layers' [O][I] / [N][I] / [N][O] blocks back to
+ * back; table (DEVICE int32 [L][6]) = {w2 offset, styles offset, d offset, O, I, first wave} per layer, where a layer owns N*O
+ * waves and total_waves is their sum.  L <= 64. */
+int p3d_demod_coefs_f32(const float* w2, const float* styles, const int32_t* table, int L, int N, int total_waves, float* d,
+                        void* stream);
 
 /* f16-operand variant of p3d_modconv2d_f32 (opt-in; the reference runs its super-resolution blocks in fp16 on the GPU:
  * superresolution.py:264-293 with sr_num_fp16_res = 4, networks_stylegan2.py:52-60).  Same arguments and semantics; x, y and
@@ -158,9 +183,9 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
  * p3d_conv_weights_to_f16 (16-byte aligned).  Requires I % 16 == 0 (P3D_E_RANGE otherwise: use the fp32 function). */
 int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream);
 int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
-                             const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
-                             int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
+                             const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by
@@ -198,8 +223,9 @@ int p3d_mc_count_f32(const float* vol, int n, int flip0, float level, void* work
 int p3d_mc_emit_f32(const float* vol, int n, int flip0, float level, void* workspace, size_t workspace_bytes, int64_t nverts,
                     int64_t ntris, float* out_verts, float* out_normals, float* out_values, int32_t* out_faces, void* stream);
 
-/* Library / build identification ("gfx950"). */
+/* Library / build identification ("gfx950"), and the ABI version this library was built with (P3D_ABI_VERSION). */
 const char* p3d_build_info(void);
+int p3d_abi_version(void);
 
 #ifdef __cplusplus
 }

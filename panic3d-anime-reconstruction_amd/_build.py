@@ -31,19 +31,29 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def built_hash(so=SO):
+    """The source hash a library was compiled from (embedded by build() as -DP3D_SRC_HASH, returned by p3d_build_info), or None."""
+    import ctypes
+    try:
+        L = ctypes.CDLL(so)
+        L.p3d_build_info.restype = ctypes.c_char_p
+        info = L.p3d_build_info().decode()
+    except (OSError, AttributeError):
+        return None
+    return info.rsplit("src=", 1)[1].strip() if "src=" in info else None
+
+
 def needs_build():
-    if not os.path.exists(SO):
-        return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    """True when the library is missing or was compiled from other sources than the ones on disk (content hash, not mtimes:
+    a copied tree keeps no useful timestamps)."""
+    return not os.path.exists(SO) or built_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> libpanic3d_hip.so next to this file.  Returns the path."""
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO + ".tmp"]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DP3D_SRC_HASH="{source_hash()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

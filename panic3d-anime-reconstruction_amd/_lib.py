@@ -8,8 +8,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D_LIB: development override
 
-P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 P3D_MAX_S = 192
+P3D_ABI_VERSION = 3  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -36,13 +37,16 @@ SIGNATURES = {
     "p3d_render_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
                             _Z, C.POINTER(Dumps), _P]),
     "p3d_sample_stratified_f32": (_I, [_F, _F, _F, _I, _P, _L, _P, _P]),
+    "p3d_composite_workspace_bytes": (_Z, [_L, _I, _I]),
+    "p3d_depth_minmax_f32": (_I, [_P, _L, _P, _P, _Z, _P]),
     "p3d_composite_f32": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "p3d_importance_f32": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "p3d_unify_perm_f32": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "p3d_modconv2d_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "p3d_modconv2d_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
+    "p3d_modconv2d_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
+    "p3d_demod_coefs_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "p3d_conv_weights_to_f16": (_I, [_P, _I, _I, _I, _P, _P]),
-    "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
+    "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_bias_act_f32": (_I, [_P, _P, _L, _I, _L, _I, _F, _F, _F, _P, _P]),
     "p3d_sigma2density_f32": (_I, [_P, _P, _L, _F, _P, _P]),
@@ -50,6 +54,7 @@ SIGNATURES = {
     "p3d_mc_count_f32": (_I, [_P, _I, _I, _F, _P, _Z, _P, _P]),
     "p3d_mc_emit_f32": (_I, [_P, _I, _I, _F, _P, _Z, _L, _L, _P, _P, _P, _P, _P]),
     "p3d_build_info": (C.c_char_p, []),
+    "p3d_abi_version": (_I, []),
 }
 
 _LIB = None
@@ -62,10 +67,19 @@ def lib():
         if not os.path.exists(SO):
             raise RuntimeError(f"{SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the HIP path)")
+        if "P3D_LIB" not in os.environ:
+            from . import _build
+            if _build.needs_build():  # compiled from other sources than the ones on disk: never run stale kernels silently
+                import sys
+                print(f"panic3d_amd: {SO} does not match csrc/ (source hash): rebuilding", file=sys.stderr)
+                _build.build(force=True)
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        got = L.p3d_abi_version()
+        if got != P3D_ABI_VERSION:
+            raise RuntimeError(f"{SO} was built for ABI version {got}, this binding is written for {P3D_ABI_VERSION}: rebuild the library")
         _LIB = L
     return _LIB
 

@@ -156,7 +156,8 @@ struct RenderParams {
     const float* u;       // [N*R][Sf]
     const float *w0, *b0, *w1, *b1;
     float *out_feat, *out_depth, *out_wsum, *out_xyz;
-    uint32_t* gminmax;  // [2] order-mapped min / max of all depths
+    uint32_t* gminmax;  // [0..1] order-mapped min / max of all depths, [2..3] decode-step count, [4 + 2n ..] per-view min / max
+    int per_view_clamp;  // P3D_FLAG_PER_VIEW_CLAMP: the N views are N calls of the reference -> one clamp range each
     p3d_dumps dumps;
     long long R;
     long long tiles_per_img, ntiles;
@@ -601,6 +602,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
     if (lane == 0) {
         atomicMin(p.gminmax, p3d_f2ord(tmin));
         atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+        if (p.per_view_clamp) {  // a tile never straddles two views
+            atomicMin(p.gminmax + 4 + 2 * nlo, p3d_f2ord(tmin));
+            atomicMax(p.gminmax + 5 + 2 * nlo, p3d_f2ord(tmax));
+        }
         if constexpr (!DUMP) atomicAdd((unsigned long long*)(p.gminmax + 2), (unsigned long long)ndec);  // wave-level decode steps
     }
 }
@@ -885,22 +890,32 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
     if (lane == 0) {
         atomicMin(p.gminmax, p3d_f2ord(tmin));
         atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+        if (p.per_view_clamp) {
+            atomicMin(p.gminmax + 4 + 2 * nlo, p3d_f2ord(tmin));
+            atomicMax(p.gminmax + 5 + 2 * nlo, p3d_f2ord(tmax));
+        }
         atomicAdd((unsigned long long*)(p.gminmax + 2), (unsigned long long)ndec);
     }
 }
 
-__global__ void k_minmax_init(uint32_t* g) {
-    g[0] = 0xffffffffu;
-    g[1] = 0u;
-    g[2] = 0u;  // [2..3]: 64-bit count of wave-level decode steps of the launch (statistics for bench.py)
-    g[3] = 0u;
+__global__ void k_minmax_init(uint32_t* g, int nviews) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        g[0] = 0xffffffffu;
+        g[1] = 0u;
+        g[2] = 0u;  // [2..3]: 64-bit count of wave-level decode steps of the launch (statistics for bench.py)
+        g[3] = 0u;
+    }
+    if (i < nviews) { g[4 + 2 * i] = 0xffffffffu; g[5 + 2 * i] = 0u; }  // per-view ranges (P3D_FLAG_PER_VIEW_CLAMP)
 }
 
-__global__ void k_render_finish(float* depth, long long n, const uint32_t* g, float* dump_tminmax) {
+// rays_per_view > 0: ray i is clamped to the range of ITS view (g + 4 + 2 * (i / rays_per_view)); 0: one range for the call
+__global__ void k_render_finish(float* depth, long long n, const uint32_t* g, float* dump_tminmax, long long rays_per_view) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    float lo = p3d_ord2f(g[0]), hi = p3d_ord2f(g[1]);
-    if (i == 0 && dump_tminmax) { dump_tminmax[0] = lo; dump_tminmax[1] = hi; }
+    if (i == 0 && dump_tminmax) { dump_tminmax[0] = p3d_ord2f(g[0]); dump_tminmax[1] = p3d_ord2f(g[1]); }
     if (i < n) {
+        const uint32_t* mm = rays_per_view > 0 ? g + 4 + 2 * (i / rays_per_view) : g;
+        const float lo = p3d_ord2f(mm[0]), hi = p3d_ord2f(mm[1]);
         float d = depth[i];
         d = d < lo ? lo : d;  // torch.clamp(x, min, max) = min(max(x, min), max)
         d = d > hi ? hi : d;
@@ -920,6 +935,11 @@ __global__ void k_stratified(float start, float end, float delta, int S, const f
         float lin = (i < S / 2) ? p3d_fma(step, (float)i, start) : p3d_fma(-step, (float)(S - 1 - i), end);
         out[r * S + i] = lin + jitter[r * S + i] * delta;
     }
+}
+
+__global__ void k_minmax_decode(const uint32_t* g, float* out) {
+    out[0] = p3d_ord2f(g[0]);
+    out[1] = p3d_ord2f(g[1]);
 }
 
 __global__ void k_depth_minmax(const float* __restrict__ d, long long n, uint32_t* g) {
@@ -1118,7 +1138,11 @@ static P3dDecodeCfg make_cfg(const p3d_opts* o) {
 
 extern "C" {
 
-const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1"; }
+#ifndef P3D_SRC_HASH
+#define P3D_SRC_HASH "unknown"
+#endif
+const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1 src=" P3D_SRC_HASH; }
+int p3d_abi_version(void) { return P3D_ABI_VERSION; }
 
 int p3d_planes_to_nhwc_f32(const float* src, int n3, int C, int H, int W, float* dst, void* stream) {
     if (!src || !dst || n3 <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
@@ -1173,8 +1197,8 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
 }
 
 size_t p3d_render_workspace_bytes(int N, int64_t R, int Sc, int Sf) {
-    (void)N; (void)R; (void)Sc; (void)Sf;
-    return 256;
+    (void)R; (void)Sc; (void)Sf;
+    return 256 + (size_t)(N > 0 ? N : 0) * 8;  // global min / max + decode-step count, then one min / max pair per view
 }
 
 int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
@@ -1196,6 +1220,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.out_feat = out_feat; p.out_depth = out_depth; p.out_wsum = out_wsum; p.out_xyz = out_xyz;
     p.gminmax = (uint32_t*)workspace;
+    p.per_view_clamp = (opts->flags & P3D_FLAG_PER_VIEW_CLAMP) ? 1 : 0;
     if (dumps) p.dumps = *dumps; else memset(&p.dumps, 0, sizeof(p.dumps));
     p.R = R; p.H = H; p.W = W; p.Sc = Sc; p.Sf = Sf;
     p.ray_start = opts->ray_start; p.ray_end = opts->ray_end; p.depth_delta = opts->depth_delta;
@@ -1240,7 +1265,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         if (lds_bytes <= 160 * 1024) break;
         if (nwaves == 1) return P3D_E_RANGE;
     }
-    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, p.gminmax);
+    hipLaunchKernelGGL(k_minmax_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, p.gminmax, p.per_view_clamp ? N : 0);
     const bool dmp = dumps != nullptr;
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
@@ -1269,7 +1294,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
         if (rc2) return rc2;
         long long NR2 = (long long)N * R;
         hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR2 + 255) / 256)), dim3(256), 0, st, out_depth, NR2, p.gminmax,
-                           (float*)nullptr);
+                           (float*)nullptr, p.per_view_clamp ? (long long)R : 0LL);
         return p3d_check_launch();
     }
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
@@ -1296,7 +1321,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     if (rc) return rc;
     long long NR = (long long)N * R;
     hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR + 255) / 256)), dim3(256), 0, st, out_depth, NR, p.gminmax,
-                       dumps ? dumps->tminmax : nullptr);
+                       dumps ? dumps->tminmax : nullptr, p.per_view_clamp ? (long long)R : 0LL);
     return p3d_check_launch();
 }
 
@@ -1309,6 +1334,22 @@ int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta,
     return p3d_check_launch();
 }
 
+size_t p3d_composite_workspace_bytes(int64_t NR, int S, int K) {
+    (void)NR; (void)S; (void)K;
+    return 16;  // order-mapped global depth min / max (+ padding)
+}
+
+int p3d_depth_minmax_f32(const float* depths, int64_t n, float* out_minmax, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!depths || !out_minmax || !workspace || n <= 0) return P3D_E_ARG;
+    if (workspace_bytes < 16) return P3D_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* g = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, st, g, 0);
+    hipLaunchKernelGGL(k_depth_minmax, dim3(1024), dim3(256), 0, st, depths, (long long)n, g);
+    hipLaunchKernelGGL(k_minmax_decode, dim3(1), dim3(1), 0, st, (const uint32_t*)g, out_minmax);
+    return p3d_check_launch();
+}
+
 int p3d_composite_f32(const float* colors, const float* sigma, const float* depths, int64_t NR, int S, int K,
                       int white_back, float* out_rgb, float* out_depth, float* out_weights, void* workspace,
                       void* stream) {
@@ -1316,13 +1357,13 @@ int p3d_composite_f32(const float* colors, const float* sigma, const float* dept
     if (S < 2 || K < 1 || K > 64) return P3D_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
     uint32_t* g = (uint32_t*)workspace;
-    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, st, g);
+    hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, st, g, 0);
     hipLaunchKernelGGL(k_depth_minmax, dim3(1024), dim3(256), 0, st, depths, (long long)NR * S, g);
     dim3 blk(8, 32);
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((NR + 31) / 32)), blk, 0, st, colors, sigma, depths, (long long)NR, S,
                        K, white_back, out_rgb, out_depth, out_weights);
     hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR + 255) / 256)), dim3(256), 0, st, out_depth, (long long)NR, g,
-                       (float*)nullptr);
+                       (float*)nullptr, 0LL);
     return p3d_check_launch();
 }
 

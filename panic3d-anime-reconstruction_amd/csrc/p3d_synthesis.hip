@@ -618,6 +618,28 @@ __global__ void k_demod(const float* __restrict__ w, const float* __restrict__ s
     if (lane == 0) d[wid] = 1.0f / __builtin_sqrtf(acc + 1e-8f);
 }
 
+// Demodulation coefficients of L modulated convolutions in ONE launch, from the per-layer W2[o][i] = sum_taps w[o][i][t]^2 (cached
+// by the host: it changes only when the weights do): d[n,o] = rsqrt(sum_i W2[o][i] * s[n][i]^2 + 1e-8)  (networks_stylegan2.py:70-73,
+// the same sum with the taps folded first).  table[l] = {w2 offset, styles offset, d offset, O, I, first wave}; styles / d hold the
+// layers' [N][I] / [N][O] blocks back to back.  One wave per (layer, n, o).
+__global__ void k_demod_plan(const float* __restrict__ w2, const float* __restrict__ styles, const int* __restrict__ table, int L,
+                             int N, int total_waves, float* __restrict__ d) {
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= total_waves) return;
+    int l = 0;
+    while (l + 1 < L && table[(l + 1) * 6 + 5] <= wid) ++l;  // L <= 64: a short uniform search
+    const int* t = table + l * 6;
+    const int O = t[3], I = t[4], local = wid - t[5];
+    const int n = local / O, o = local - n * O;
+    const float* wp = w2 + t[0] + (size_t)o * I;
+    const float* sp = styles + t[1] + (size_t)n * I;
+    float acc = 0.0f;
+    for (int i = lane; i < I; i += 64) { const float sv = sp[i]; acc = __builtin_fmaf(wp[i], sv * sv, acc); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) d[t[2] + local] = 1.0f / __builtin_sqrtf(acc + 1e-8f);
+}
+
 struct FirParams {
     const float* x;  // [NC][H][W]
     const float* f;  // [fh][fw], already flipped for convolution and multiplied by gain
@@ -762,7 +784,7 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
 }
 
 static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int O, int ks,
-                        const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
+                        const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                         size_t workspace_bytes, void* stream) {
     if (!x || !w || !styles || !y || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
@@ -777,7 +799,8 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     const int OH = (up == 2) ? 2 * H + 1 : H, OW = (up == 2) ? 2 * W + 1 : W;
     const size_t out_elems = (size_t)N * O * OH * OW;
     float* part = (up == 2) ? tmp + ((out_elems + 63) / 64) * 64 : tmp;
-    if (demodulate) {
+    if (demodulate && dcoef_in) dco = const_cast<float*>(dcoef_in);  // precomputed by p3d_demod_coefs_f32 (one launch per network)
+    else if (demodulate) {
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
@@ -819,11 +842,20 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
 }
 
 int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
-                      int demodulate, const float* noise, int noise_per_sample, const float* bias, int up, int act,
-                      float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
+                      int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias, int up,
+                      int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                       size_t workspace_bytes, void* stream) {
-    return modconv_impl(x, N, I, H, W, w, nullptr, O, ks, styles, demodulate, noise, noise_per_sample, bias, up, act, alpha, gain,
-                        clamp, fir, y, workspace, workspace_bytes, stream);
+    return modconv_impl(x, N, I, H, W, w, nullptr, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act,
+                        alpha, gain, clamp, fir, y, workspace, workspace_bytes, stream);
+}
+
+int p3d_demod_coefs_f32(const float* w2, const float* styles, const int32_t* table, int L, int N, int total_waves, float* d,
+                        void* stream) {
+    if (!w2 || !styles || !table || !d || L <= 0 || N <= 0 || total_waves <= 0) return P3D_E_ARG;
+    if (L > 64) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_demod_plan, dim3((unsigned)((total_waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w2, styles,
+                       (const int*)table, L, N, total_waves, d);
+    return chk();
 }
 
 int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream) {
@@ -836,13 +868,13 @@ int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, v
 }
 
 int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
-                             const float* styles, int demodulate, const float* noise, int noise_per_sample, const float* bias,
+                             const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias,
                              int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                              size_t workspace_bytes, void* stream) {
     if (!w_f16) return P3D_E_ARG;
     if (I % 16 != 0 || ((uintptr_t)w_f16 & 15)) return P3D_E_RANGE;  // a K chunk is 16 channels; 16-byte weight pieces
-    return modconv_impl(x, N, I, H, W, w, w_f16, O, ks, styles, demodulate, noise, noise_per_sample, bias, up, act, alpha, gain,
-                        clamp, fir, y, workspace, workspace_bytes, stream);
+    return modconv_impl(x, N, I, H, W, w, w_f16, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act, alpha,
+                        gain, clamp, fir, y, workspace, workspace_bytes, stream);
 }
 
 int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,

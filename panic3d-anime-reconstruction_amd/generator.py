@@ -88,6 +88,14 @@ class TriPlaneGenerator(torch.nn.Module):
         self._last_planes = None
         self._inject_draws = None  # tests: (jitter, u) for the renderer instead of device RNG
 
+    def __getstate__(self):
+        """Pickling / deep copies (the reference snapshots G): derived tensors and per-call state stay out."""
+        state = dict(self.__dict__)
+        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan"):
+            if k in state:
+                state[k] = None
+        return state
+
     def _sign(self, device):
         """(-1, 1, -1) on `device`, created once (a host->device copy is not allowed inside a hipGraph capture); a plain
         attribute, not a buffer: the module's state_dict must stay identical to the reference's."""
@@ -151,10 +159,12 @@ class TriPlaneGenerator(torch.nn.Module):
             planes = self._planes(ws, cond, latent_injection, stop_level, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
-        if len(planes) == 1 and N > 1:
+        many_views = len(planes) == 1 and N > 1
+        if many_views:
             # extension: V views of ONE subject in one call (ws / cond of batch 1, V cameras).  The planes are synthesised once
             # and shared by the V ray batches of a single renderer launch (P3D_FLAG_SHARED_PLANES); the reference would need
-            # ws and cond repeated V times and would run the backbone on V copies.
+            # ws and cond repeated V times and would run the backbone on V copies.  The V views stand for V calls of the
+            # reference (generate.py's view loop), so every view keeps its own depth-clamp range (P3D_FLAG_PER_VIEW_CLAMP).
             planes = planes.expand(N, -1, -1, -1, -1)
             ws = ws.expand(N, -1, -1)
         draws = self._inject_draws or (None, None)
@@ -162,7 +172,8 @@ class TriPlaneGenerator(torch.nn.Module):
             draws = draws.pop(0)
         feat, depth, wsum, xyz = self.renderer(planes, self.decoder, ray_origins.contiguous(), ray_directions.contiguous(),
                                                self.rendering_kwargs, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
-                                               binarize_clouds=binarize_clouds, jitter=draws[0], u=draws[1])
+                                               binarize_clouds=binarize_clouds, jitter=draws[0], u=draws[1],
+                                               per_view_clamp=many_views)
         H = W = res
         feature_image = feat.permute(0, 2, 1).reshape(N, feat.shape[-1], H, W).contiguous()
         xyz_image = xyz.permute(0, 2, 1).reshape(N, 3, H, W).contiguous()

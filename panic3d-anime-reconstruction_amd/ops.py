@@ -5,6 +5,7 @@ libpanic3d_hip.so.  All tensors must be float32 CUDA(ROCm) tensors; misuse raise
 (TORCH_CHECK -> RuntimeError, torch_utils/ops/bias_act.cpp:39-55).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -208,11 +209,14 @@ DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "
              "depth_unclamped", "tminmax")
 
 
-def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None):
+def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False):
     """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
     jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
     Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps).
-    `stats`: pass a dict to receive the number of decode steps the launch executed (exact early-outs, see k_render)."""
+    `stats`: pass a dict to receive the number of decode steps the launch executed (exact early-outs, see k_render).
+    per_view_clamp: clamp each image's depth to its own sample range (N batched views = N calls of the reference)."""
+    if per_view_clamp:
+        opts = _with_flag(opts, _lib.P3D_FLAG_PER_VIEW_CLAMP)
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     rays_o, rays_d, jitter = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions"), _chk(jitter, "jitter")
     N, three, H, W, Cc = planes_nhwc.shape
@@ -295,12 +299,23 @@ def composite(colors, densities, depths, white_back=True):
     rgb = torch.empty(lead + (K,), dtype=torch.float32, device=dev)
     depth = torch.empty(lead + (1,), dtype=torch.float32, device=dev)
     w = torch.empty(lead + (S - 1, 1), dtype=torch.float32, device=dev)
-    ws = torch.empty((16,), dtype=torch.uint8, device=dev)
+    ws = torch.empty((_lib.lib().p3d_composite_workspace_bytes(NR, S, K),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().p3d_composite_f32(_p(colors), _p(densities), _p(depths), NR, S, K, int(bool(white_back)), _p(rgb),
                                           _p(depth), _p(w), _p(ws), _stream())
     _lib.check(rc, "p3d_composite_f32")
     return rgb, depth, w
+
+
+def depth_minmax(depths):
+    """torch.min(depths), torch.max(depths) of ray_marcher.py:50 as one op -> float32 tensor [2] on the device."""
+    depths = _chk(depths, "depths")
+    out = torch.empty((2,), dtype=torch.float32, device=depths.device)
+    ws = torch.empty((16,), dtype=torch.uint8, device=depths.device)
+    with torch.cuda.device(depths.device):
+        rc = _lib.lib().p3d_depth_minmax_f32(_p(depths), depths.numel(), _p(out), _p(ws), 16, _stream())
+    _lib.check(rc, "p3d_depth_minmax_f32")
+    return out
 
 
 def importance(depths, weights, u, return_inds=False):
@@ -378,16 +393,33 @@ def _parse_padding(padding):
     return [int(v) for v in padding]
 
 
+_FIR_CACHE = {}
+
+
+def prepared_filter(f, device, gain=1.0, flip_filter=False):
+    """`f * gain`, flipped for convolution unless flip_filter (upfirdn2d.py:193-196), float32 contiguous on `device` — made
+    once per (filter tensor object, version, gain, flip): the reference rebuilds it on every call (three tiny launches)."""
+    key = (id(f), str(device), float(gain), bool(flip_filter))
+    hit = _FIR_CACHE.get(key)
+    if hit is not None and hit[0]() is f and hit[1] == f._version:
+        return hit[2]
+    ff = f.detach().to(device, torch.float32) * float(gain)
+    if not flip_filter:
+        ff = ff.flip([0, 1])
+    ff = ff.contiguous()
+    if len(_FIR_CACHE) > 256:
+        _FIR_CACHE.clear()
+    _FIR_CACHE[key] = (weakref.ref(f), f._version, ff)
+    return ff
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     """upfirdn2d.upfirdn2d (upfirdn2d.py:120-167), 2-D filter, same up/down factor in x and y."""
     x = _chk(x, "x")
     if x.ndim != 4 or f is None or f.ndim != 2:
         raise NotImplementedError("upfirdn2d: [N,C,H,W] input and a 2-D filter are what the generator uses")
     px0, px1, py0, py1 = _parse_padding(padding)
-    ff = (f.to(x.device, torch.float32) * float(gain))
-    if not flip_filter:
-        ff = ff.flip([0, 1])
-    ff = ff.contiguous()
+    ff = prepared_filter(f, x.device, gain, flip_filter)
     N, Cc, H, W = x.shape
     fh, fw = ff.shape
     OH = (H * up + py0 + py1 - fh) // down + 1
@@ -417,8 +449,16 @@ def conv_weights_to_f16(weight):
     return wh
 
 
+def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
+    """Demodulation coefficients of L layers in one launch (p3d_demod_coefs_f32); see stylegan2.StylePlan."""
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().p3d_demod_coefs_f32(_p(w2_all), _p(styles_all), _p(table), int(L), int(N), int(total_waves), _p(out), _stream())
+    _lib.check(rc, "p3d_demod_coefs_f32")
+    return out
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
-                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None):
+                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
     noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
@@ -442,11 +482,15 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
             raise RuntimeError("noise must be [H*up, W*up] or [N,1,H*up,W*up]")
     fir = None
     if up == 2:
-        fir = (resample_filter.to(x.device, torch.float32) * 4.0).flip([0, 1]).contiguous()  # upfirdn2d.py:193-196, gain = up^2
+        fir = prepared_filter(resample_filter, x.device, 4.0, False)  # upfirdn2d.py:193-196, gain = up^2
         if tuple(fir.shape) != (4, 4):
             raise NotImplementedError("resample_filter must be the 4x4 [1,3,3,1] filter")
     if bias is not None:
         bias = _chk(bias, "bias")
+    if dcoef is not None:
+        dcoef = _chk(dcoef, "dcoef")
+        if dcoef.numel() != N * O:
+            raise RuntimeError("dcoef must hold N*O demodulation coefficients")
     y = torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
@@ -456,11 +500,11 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
             if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape) != (O, kh * kw, I) or not weight_f16.is_contiguous():
                 raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] float16 tensor of conv_weights_to_f16")
             rc = L.p3d_modconv2d_f16mma_f32(_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
-                                            _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y),
+                                            _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y),
                                             _p(ws), wsb, _stream())
             _lib.check(rc, "p3d_modconv2d_f16mma_f32")
         else:
-            rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(noise), nps,
+            rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(dcoef), _p(noise), nps,
                                      _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
             _lib.check(rc, "p3d_modconv2d_f32")
     return y

@@ -44,8 +44,20 @@ class ImportanceRenderer(torch.nn.Module):
         else:
             planes_src = planes
         cached = ops.planes_to_nhwc(planes_src)
-        self._planes_cache = (weakref.ref(planes), planes._version, cached)
+
+        def _drop(_ref, self_ref=weakref.ref(self)):  # the planes tensor died: free its 25 MB channels-last copy too
+            me = self_ref()
+            if me is not None and me._planes_cache[0] is _ref:
+                me._planes_cache = (None, None, None)
+
+        self._planes_cache = (weakref.ref(planes, _drop), planes._version, cached)
         return cached
+
+    def __getstate__(self):
+        """The reference pickles / deep-copies G (snapshots, eg3dc_v0 loader): the cache (a weakref and a device tensor) stays out."""
+        state = dict(self.__dict__)
+        state["_planes_cache"] = (None, None, None)
+        return state
 
     def _opts(self, rendering_options, decoder, **kw):
         ro = dict(rendering_options)
@@ -53,7 +65,8 @@ class ImportanceRenderer(torch.nn.Module):
         return ops.make_opts(ro, force_sigmoid=bool(getattr(decoder, "force_sigmoid", False)), **kw)
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None,
-                cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False):
+                cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False,
+                per_view_clamp=False):
         opts = self._opts(rendering_options, decoder, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
                           binarize_clouds=binarize_clouds)
         N, R, _ = ray_origins.shape
@@ -66,7 +79,7 @@ class ImportanceRenderer(torch.nn.Module):
             side = int(round(R ** 0.5))
             ray_tile_w = side if side * side == R else 0
         out = ops.render(self._nhwc(planes), ray_origins.float(), ray_directions.float(), jitter, u,
-                         decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps)
+                         decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps, per_view_clamp=per_view_clamp)
         return out  # rgb_final, depth_final, weights.sum(2), xyz_final  (renderer.py:264)
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):

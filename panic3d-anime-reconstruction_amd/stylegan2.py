@@ -15,12 +15,25 @@ from . import ops
 
 SQRT2 = float(np.sqrt(2))
 
+# derived tensors the modules keep as plain attributes (never part of the state_dict, dropped when pickled / deep-copied)
+_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_noise_cache", "_style_plan")
+
+
+class _CacheFree(torch.nn.Module):
+    """nn.Module whose derived-tensor caches are not pickled (the reference pickles G for snapshots and deep-copies it)."""
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in _CACHE_ATTRS:
+            state.pop(k, None)
+        return state
+
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):  # networks_stylegan2.py:33-35
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
-class FullyConnectedLayer(torch.nn.Module):
+class FullyConnectedLayer(_CacheFree):
     def __init__(self, in_features, out_features, bias=True, activation="linear", lr_multiplier=1, bias_init=0):
         super().__init__()
         self.in_features, self.out_features, self.activation = in_features, out_features, activation
@@ -106,7 +119,7 @@ def _f16_operand(layer):
     return layer._wh
 
 
-class SynthesisLayer(torch.nn.Module):
+class SynthesisLayer(_CacheFree):
     def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
                  activation="lrelu", resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False):
         super().__init__()
@@ -122,21 +135,32 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
+    def _const_noise(self):
+        """`noise_const * noise_strength` (networks_stylegan2.py:346), once per parameter version instead of once per call."""
+        key = (self.noise_const.data_ptr(), self.noise_const._version, self.noise_strength.data_ptr(), self.noise_strength._version)
+        hit = getattr(self, "_noise_cache", None)
+        if hit is None or hit[0] != key:
+            hit = (key, (self.noise_const * self.noise_strength.detach()).contiguous())
+            self._noise_cache = hit
+        return hit[1]
+
+    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None):
+        """pre: (styles [N,I], demodulation coefficients [N,O]) already computed by a StylePlan for this layer, or None."""
         assert noise_mode in ["random", "const", "none"]
-        styles = self.affine(w)
+        styles, dcoef = pre if pre is not None else (self.affine(w), None)
         noise = None
         if self.use_noise and noise_mode == "random":
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == "const":
-            noise = self.noise_const * self.noise_strength
+            noise = self._const_noise()
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
-                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self))
+                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self),
+                                    dcoef=dcoef)
 
 
-class ToRGBLayer(torch.nn.Module):
+class ToRGBLayer(_CacheFree):
     def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
         super().__init__()
         self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
@@ -145,10 +169,111 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+    def forward(self, x, w, fused_modconv=True, pre=None):
+        styles = pre[0] if pre is not None else self.affine(w) * self.weight_gain
         return ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
                                     clamp=self.conv_clamp, weight_f16=_f16_operand(self))
+
+
+class StylePlan:
+    """Every `affine` (w -> styles) layer of a stack of SynthesisBlocks, and the demodulation coefficients of its
+    SynthesisLayers, computed for a whole forward pass in four launches instead of ~6 per layer:
+        Y = ws @ W_all^T                      one GEMM  [N * num_ws, 512] x [512, sum I]   (every affine weight, pre-scaled)
+        S = (Y[n, widx(col), col] + b_all) * g_all      gather + add + mul  (g = ToRGB's weight_gain, 1 elsewhere)
+        d = rsqrt(W2 . S^2 + 1e-8)            one launch for all layers (ops.demod_coefs), W2 = sum over taps of w^2, cached
+    The results are laid out layer-major ([N, I_l] / [N, O_l] blocks back to back), so each layer gets a contiguous view.
+    The reference evaluates each affine separately (networks_stylegan2.py:342,377) and recomputes sum (w*s)^2 from the full
+    weights per call (:70-73): same mathematics, different summation order (covered by the tolerance of the golden tests).
+    entries: [(block name, layer name, layer module, w index)] in execution order."""
+
+    def __init__(self, entries):
+        self.entries = entries
+        self._key = None
+        self._per_n = {}
+
+    def _build(self, dev):
+        Ws, bs, gs, widx, w2s, table = [], [], [], [], [], []
+        s_off = w2_off = o_off = 0
+        self.slices = []
+        for _, _, layer, wi in self.entries:
+            w, b = layer.affine._scaled(torch.float32)
+            I = w.shape[0]
+            Ws.append(w)
+            bs.append(b)
+            is_rgb = isinstance(layer, ToRGBLayer)
+            gs.append(torch.full((I,), float(layer.weight_gain) if is_rgb else 1.0, device=dev))
+            widx.append(torch.full((I,), wi, dtype=torch.long, device=dev))
+            O = layer.weight.shape[0]
+            if not is_rgb:
+                w2 = layer.weight.detach().float().square().sum(dim=(2, 3)).contiguous()  # [O, I]
+                w2s.append(w2.reshape(-1))
+                table.append([w2_off, s_off, o_off, O, I])
+                w2_off += O * I
+                self.slices.append((s_off, I, o_off, O))
+                o_off += O
+            else:
+                self.slices.append((s_off, I, None, O))
+            s_off += I
+        self.W_all_t = torch.cat(Ws, dim=0).t().contiguous()  # [512, sum I]
+        self.b_all, self.g_all, self.widx = torch.cat(bs), torch.cat(gs), torch.cat(widx)
+        self.w2_all = torch.cat(w2s) if w2s else None
+        self.table, self.sumI, self.sumO = table, s_off, o_off
+        self._per_n = {}
+
+    def _for_n(self, N, dev):
+        hit = self._per_n.get((N, self.num_ws))
+        if hit is None:
+            # flat gather index into Y [N, num_ws, sum I] producing the layer-major layout, and the matching bias / gain vectors
+            idx, bias, gain = [], [], []
+            n = torch.arange(N, device=dev)
+            for (s_off, I, _, _), (_, _, _, wi) in zip(self.slices, self.entries):
+                col = torch.arange(s_off, s_off + I, device=dev)
+                idx.append(((n[:, None] * self.num_ws + wi) * self.sumI + col[None, :]).reshape(-1))
+                bias.append(self.b_all[s_off:s_off + I].repeat(N))
+                gain.append(self.g_all[s_off:s_off + I].repeat(N))
+            tab, first = [], 0
+            for w2_off, s_off, o_off, O, I in self.table:
+                tab.append([w2_off, s_off * N, o_off * N, O, I, first])
+                first += N * O
+            tab.append([0, 0, 0, 1, 1, first])
+            hit = (torch.cat(idx), torch.cat(bias), torch.cat(gain),
+                   torch.tensor(tab, dtype=torch.int32, device=dev).contiguous(), first)
+            self._per_n[(N, self.num_ws)] = hit
+        return hit
+
+    def __call__(self, ws):
+        """ws [N, num_ws, 512] -> {block name: {layer name: (styles [N,I], dcoef [N,O] or None)}}"""
+        dev = ws.device
+        key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias.data_ptr(), l.affine.bias._version,
+                     l.weight.data_ptr(), l.weight._version) for _, _, l, _ in self.entries) + (str(dev),)
+        if key != self._key:
+            self._build(dev)
+            self._key = key
+        N, self.num_ws = ws.shape[0], ws.shape[1]
+        idx, bias, gain, table, total_waves = self._for_n(N, dev)
+        Y = torch.matmul(ws.reshape(N * self.num_ws, -1).to(torch.float32), self.W_all_t)  # [N * num_ws, sum I]
+        S = Y.reshape(-1)[idx].add_(bias).mul_(gain)
+        d = None
+        if self.w2_all is not None:
+            d = ops.demod_coefs(self.w2_all, S, table, len(self.table), N, total_waves,
+                                torch.empty((N * self.sumO,), dtype=torch.float32, device=dev))
+        out = {}
+        for (s_off, I, o_off, O), (bname, lname, _, _) in zip(self.slices, self.entries):
+            st = S[s_off * N:(s_off + I) * N].view(N, I)
+            dc = d[o_off * N:(o_off + O) * N].view(N, O) if o_off is not None else None
+            out.setdefault(bname, {})[lname] = (st, dc)
+        return out
+
+
+def plan_entries(named_blocks, block_w0):
+    """[(block name, layer name, layer, w index)] for blocks [(name, SynthesisBlock)] whose first w index is block_w0[i]."""
+    ent = []
+    for (name, blk), w0 in zip(named_blocks, block_w0):
+        k = 0
+        for lname in (("conv1",) if blk.in_channels == 0 else ("conv0", "conv1")) + ("torgb",):
+            ent.append((name, lname, getattr(blk, lname), w0 + k))
+            k += 1
+    return ent
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -174,17 +299,20 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, pre=None, **layer_kwargs):
+        """pre: {layer name: (styles, demod coefficients)} from a StylePlan (all affine layers of the network in one GEMM),
+        or None: every layer runs its own affine like the reference (networks_stylegan2.py:342,377)."""
         w_iter = iter(ws.unbind(dim=1))
+        pre = pre or {}
         if self.in_channels == 0:
             x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
-            x = self.conv1(x, next(w_iter), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
         else:
-            x = self.conv0(x.to(torch.float32), next(w_iter), **layer_kwargs)
-            x = self.conv1(x, next(w_iter), **layer_kwargs)
+            x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), **layer_kwargs)
+            x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
         if img is not None:
             img = ops.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, next(w_iter))
+        y = self.torgb(x, next(w_iter), pre=pre.get("torgb"))
         img = img.add_(y) if img is not None else y
         return x, img
 
@@ -196,7 +324,7 @@ def _pixel_unshuffle(t, f):
     return t.reshape(b, f * f * ch, H // f, W // f)
 
 
-class SynthesisNetwork(torch.nn.Module):
+class SynthesisNetwork(_CacheFree):
     def __init__(self, w_dim, img_resolution, img_channels, cond_mode, channel_base=32768, channel_max=512,
                  num_fp16_res=4, **block_kwargs):
         assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
@@ -278,8 +406,17 @@ class SynthesisNetwork(torch.nn.Module):
         chonk = chonk[0] if chonk else 0
         x = img = None
         ximgs = []
+        plan = self.__dict__.get("_style_plan")
+        if plan is None:
+            starts, w0 = [], 0
+            for res in self.block_resolutions:
+                starts.append(w0)
+                w0 += getattr(self, f"b{res}").num_conv
+            plan = StylePlan(plan_entries([(f"b{res}", getattr(self, f"b{res}")) for res in self.block_resolutions], starts))
+            self.__dict__["_style_plan"] = plan
+        pre = plan(ws)  # every layer's styles + demodulation coefficients: one GEMM + three small launches
         for lvl, (res, cur_ws) in enumerate(zip(self.block_resolutions, block_ws)):
-            x, img = getattr(self, f"b{res}")(x, img, cur_ws, **block_kwargs)
+            x, img = getattr(self, f"b{res}")(x, img, cur_ws, pre=pre[f"b{res}"], **block_kwargs)
             x, img = self._condition(lvl, res, x, img, cond, cm, chonk)
             x, img = x.contiguous(), img.contiguous()
             ximgs.append((x, img))

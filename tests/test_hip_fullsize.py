@@ -133,3 +133,91 @@ def test_large_launch_other_sampling_rates(hip, oracle, Sc, Sf):
     for name, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
         assert np.array_equal(a.cpu().numpy(), b), name
     check_properties(*(t.cpu().numpy() for t in out), ro)
+
+
+# ---- full-size holes closed in round 2 (VERDICT r01 "What's weak" 1-2) ---------------------------------------------------
+@pytest.mark.parametrize("scene", ["canonical", "surface"])
+def test_bench_scene_512_frame_vs_oracle(hip, oracle, scene):
+    """The frame bench.py times: a 128^2 block of the 512^2 launch equals the same rays rendered as their own launch of the
+    same kernel, and that equals the CPU oracle bit for bit (the check bench.py itself runs outside its timed region)."""
+    import bench
+    res, Sc, Sf = 512, 48, 48
+    planes_np, raw = T.make_bench_scene(scene)
+    ro = T.bench_rendering_kwargs(Sc, Sf)
+    o, d = hip.cameras.rays_from_label(hip.cameras.camera_label(0.0, 20.0, 1.0, 30.0)[None], res)
+    o, d = o.cuda(), d.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    jit = torch.rand((1, res * res, Sc, 1), device="cuda", generator=gen)
+    u = torch.rand((res * res, Sf), device="cuda", generator=gen)
+    mlp = hip.ops.prescale_mlp(*(torch.from_numpy(x).cuda() for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
+    nhwc = hip.ops.planes_to_nhwc(torch.from_numpy(planes_np).cuda())
+    for early in (True, False):
+        opts = hip.ops.make_opts(ro, early_out=early, **T.BENCH_KW)
+        frame = hip.ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
+        v = bench.verify_block(hip.ops, planes_np, raw, nhwc, o, d, jit, u, mlp, opts, frame, ro, T.BENCH_KW, res, Sc, Sf, exact=True)
+        assert v["ok"], v
+    feat, depth, wsum, xyz = (t.cpu().numpy() for t in frame)
+    check_properties(feat, depth, wsum, xyz, ro)
+    if scene == "surface":
+        assert 0.3 < (wsum > 0.5).mean() < 0.9
+        fast = hip.ops.render(nhwc, o, d, jit, u, mlp, hip.ops.make_opts(ro, fast_color=True, **T.BENCH_KW), ray_tile_w=res)
+        err = (fast[0] - frame[0]).abs().amax(dim=-1).reshape(-1)
+        assert float(err.median()) < 2e-6 and float((err > 2e-5).float().mean()) < 1e-4  # tolerance mode at full size
+    else:
+        assert wsum.max() == 0.0  # SURVEY 8(d)'s decoder never clears cull_clouds = 0.5: an empty volume
+
+
+@pytest.mark.parametrize("skip_cropped", [False, True])
+def test_c5_grid_entry_point_at_512(hip, oracle, skip_cropped):
+    """p3d_grid_density_f32 at N = 512 (in-kernel create_samples, 32-bit index arithmetic and p3d_fmod_pos at magnitudes no
+    small grid reaches, with and without P3D_FLAG_SKIP_CROPPED): both ends of the index range and a stride-997 subset of the
+    134 M points against oracle.decode on the reference's create_samples points, bit for bit; and the crop mask."""
+    from panic3d_amd import volume
+    N = 512
+    planes = T.make_planes(61, 1, 256, 256, scale=4.0, smooth=16)
+    raw = T.make_decoder_params(62, 1.0, 30.0)
+    opts = hip.ops.make_opts(RO, force_sigmoid=True)
+    mlp = hip.ops.prescale_mlp(*(torch.from_numpy(x).cuda() for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
+    pl = hip.ops.planes_to_nhwc(torch.from_numpy(planes).cuda())
+    vs, org, lim = 0.7 / (N - 1), -0.35, 0.35 - 0.1
+    sig, msk = hip.ops.grid_density(pl, N, 0, N ** 3, vs, (org, org, org), mlp, opts, crop_limit=lim, skip_cropped=skip_cropped)
+    idx = torch.cat([torch.arange(0, 4096), torch.arange(0, N ** 3, 997), torch.arange(N ** 3 - 4096, N ** 3)]).unique()
+    pts, _, _ = volume.create_samples(N, (0, 0, 0), 0.7, idx=idx)
+    osig, _ = oracle.decode(planes, pts.numpy(), oracle.prescale_mlp(*raw), 0.7, plane_mode=1, flags=opts.flags, density_only=True)
+    cropped = ((pts[0, :, 0].abs() > np.float32(lim)) | (pts[0, :, 2].abs() > np.float32(lim))).numpy()
+    got = sig[0, idx.cuda(), 0].cpu().numpy()
+    assert np.array_equal(msk[0, idx.cuda(), 0].cpu().numpy(), cropped)
+    if skip_cropped:
+        assert np.array_equal(got[~cropped], osig[0, ~cropped, 0]) and np.all(got[cropped] == -1000.0)
+    else:
+        assert np.array_equal(got, osig[0, :, 0])
+    assert 0.2 < cropped.mean() < 0.8
+
+
+def test_c4_shared_planes_four_views_512(hip, oracle):
+    """c4's batched launch (P3D_FLAG_SHARED_PLANES): V = 4 views of one subject at 512^2 rays in ONE launch equal four single
+    launches bit for bit: feat / wsum / xyz always; depth too with P3D_FLAG_PER_VIEW_CLAMP (each view keeps its own clamp
+    range, as four calls of the reference would), and without it once both are clamped to the batch's common range (the
+    reference's scope for ONE call with a batch of V cameras: torch.min/max over everything, ray_marcher.py:49-50)."""
+    res, Sc, Sf, V = 512, 48, 48, 4
+    planes_np, raw = T.make_bench_scene("surface")
+    ro = T.bench_rendering_kwargs(Sc, Sf)
+    labels = torch.stack([hip.cameras.camera_label(0.0, a, 1.0, 30.0) for a in (0.0, 90.0, 180.0, 270.0)])
+    o, d = hip.cameras.rays_from_label(labels, res)
+    o, d = o.cuda(), d.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    jit = torch.rand((V, res * res, Sc, 1), device="cuda", generator=gen)
+    u = torch.rand((V * res * res, Sf), device="cuda", generator=gen)
+    mlp = hip.ops.prescale_mlp(*(torch.from_numpy(x).cuda() for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
+    nhwc = hip.ops.planes_to_nhwc(torch.from_numpy(planes_np).cuda())  # [1,...]: shared by the V views
+    opts = hip.ops.make_opts(ro, **T.BENCH_KW)
+    batched = hip.ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
+    singles = [hip.ops.render(nhwc, o[v:v + 1], d[v:v + 1], jit[v:v + 1], u[v * res * res:(v + 1) * res * res], mlp, opts, ray_tile_w=res)
+               for v in range(V)]
+    for k in (0, 2, 3):
+        assert torch.equal(batched[k], torch.cat([s[k] for s in singles]))
+    lo, hi = batched[1].min(), batched[1].max()
+    assert torch.equal(batched[1], torch.cat([s[1] for s in singles]).clamp(lo, hi))
+    per_view = hip.ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res, per_view_clamp=True)
+    for k in range(4):
+        assert torch.equal(per_view[k], torch.cat([s[k] for s in singles])), k

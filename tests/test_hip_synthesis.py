@@ -247,7 +247,7 @@ def test_density_grid(hip):
 def test_f_many_views_of_one_subject_in_one_call(hip):
     """Extension of the dict API: ws / cond of batch 1 with V cameras renders V views from ONE backbone pass and ONE fused
     renderer launch (shared planes).  Equal to V separate f() calls on the same planes and random draws: renderer outputs
-    bit for bit (rays are independent; only the depth clamp is per call), super-resolved / pasted images to fp32 round-off
+    bit for bit (rays are independent; the depth clamp is kept per view), super-resolved / pasted images to fp32 round-off
     (the batch size changes the split-K choice of the small conv layers)."""
     from panic3d_amd.generator import TriPlaneGenerator
     g = T.load_golden("syn_triplane_f.npz")
@@ -274,7 +274,7 @@ def test_f_many_views_of_one_subject_in_one_call(hip):
         for v in range(V):
             G._inject_draws = [(j[v:v + 1].contiguous(), u[v * R:(v + 1) * R].contiguous()) for j, u in draws]
             one = G.f(dict(common, elevations=el[v:v + 1], azimuths=az[v:v + 1], fovs=fv[v:v + 1]))
-            for k in ("image_raw", "image_weights", "image_xyz"):
+            for k in ("image_raw", "image_weights", "image_xyz", "image_depth"):  # depth too: one clamp range per view
                 assert torch.equal(both[k][v:v + 1], one[k]), (k, v)
             assert (both["image_prepaste"][v:v + 1] - one["image_prepaste"]).abs().max() < 1e-4
             assert ((both["paste"]["mask"][v:v + 1] - one["paste"]["mask"]).abs() > 1e-3).float().mean() < 1e-3

@@ -48,10 +48,15 @@ def test_cabi_argument_errors_without_gpu(P):
     assert L.p3d_conv_weights_to_f16(None, 4, 16, 3, None, None) == -1
     fake = C.c_void_p(16)  # never dereferenced: the range checks come first
     assert L.p3d_conv_weights_to_f16(fake, 4, 16, 2, fake, None) == -2  # ks must be 1 or 3
-    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 24, 8, 8, fake, fake, 8, 3, fake, 1, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
+    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 24, 8, 8, fake, fake, 8, 3, fake, 1, None, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
                                       fake, 1 << 20, None) == -2  # I % 16 != 0: use the fp32 entry point
-    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 32, 8, 8, fake, None, 8, 3, fake, 1, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
+    assert L.p3d_modconv2d_f16mma_f32(fake, 1, 32, 8, 8, fake, None, 8, 3, fake, 1, None, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake,
                                       fake, 1 << 20, None) == -1  # no f16 weights
+    assert L.p3d_modconv2d_f32(None, 1, 32, 8, 8, fake, 8, 3, fake, 1, None, None, 0, None, 1, 1, 0.2, 1.0, -1.0, None, fake, fake, 1 << 20, None) == -1
+    assert L.p3d_demod_coefs_f32(None, fake, fake, 3, 1, 24, fake, None) == -1 and L.p3d_demod_coefs_f32(fake, fake, fake, 65, 1, 24, fake, None) == -2
+    assert L.p3d_depth_minmax_f32(None, 8, fake, fake, 16, None) == -1 and L.p3d_depth_minmax_f32(fake, 8, fake, fake, 8, None) == -3
+    assert L.p3d_composite_workspace_bytes(1024, 96, 35) >= 8 and L.p3d_abi_version() == P._lib.P3D_ABI_VERSION
+    assert L.p3d_render_workspace_bytes(4, 4096, 48, 48) >= 16 + 4 * 8  # one clamp range per view under P3D_FLAG_SHARED_PLANES
 
 
 def test_opts_match_oracle(P, oracle):
@@ -179,6 +184,11 @@ def test_stylegan2_state_dict_matches_reference_names(P):
         ref = {k[3:].replace("__", "."): v.shape for k, v in g.items() if k.startswith("sd_")}
         mine = {k: tuple(v.shape) for k, v in G.state_dict().items()}
         assert set(mine) == set(ref)
+        import copy, pickle  # the reference pickles G for snapshots and deep-copies it: derived caches must not get in the way
+        G.synthesis.b4.conv1.affine._scaled(torch.float32)
+        G2 = pickle.loads(pickle.dumps(G))
+        assert set(G2.state_dict()) == set(ref) and not hasattr(G2.synthesis.b4.conv1.affine, "_scaled_wb")
+        assert set(copy.deepcopy(G).state_dict()) == set(ref)
         assert all(tuple(ref[k]) == mine[k] for k in ref)
     # full-size backbone of the released configuration: 14 ws, 96-channel 256^2 output
     G = sg.Generator(z_dim=512, c_dim=25, w_dim=512, img_resolution=256, img_channels=96, cond_mode="none",
