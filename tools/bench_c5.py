@@ -12,6 +12,7 @@ import numpy as np, torch, torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=512)
 ap.add_argument("--crop", type=float, default=None, help="triplane_crop (generate.py uses 0.1): masked points are not decoded")
+ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered sigma grid (must not depend on the world size)")
 a = ap.parse_args()
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(lrank)
@@ -32,6 +33,9 @@ lo, hi = sharding.partition(N, world, rank)  # slab of the slowest grid axis
 counts = [sharding.partition(N, world, r)[1] - sharding.partition(N, world, r)[0] for r in range(world)]
 
 
+LAST = {}
+
+
 def run():
     if a.crop is None:
         sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts), None
@@ -41,6 +45,7 @@ def run():
     fmsk = None if msk is None else sharding.gather_frames(msk.view(torch.uint8).reshape(hi - lo, N * N), counts, 0)
     if rank != 0:
         return None
+    LAST["sigma"] = full
     dens = ops.sigma2density(full.reshape(N, N, N), None if fmsk is None else fmsk.reshape(N, N, N), None)
     return ops.marching_cubes(dens, 0.5, flip0=True)
 
@@ -60,7 +65,11 @@ for _ in range(K):
 t1 = sync()
 if rank == 0:
     dt = (t1 - t0) / K
-    print(json.dumps({"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "triplane_crop": a.crop, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
-                      "verts": int(out[0].shape[0]), "faces": int(out[1].shape[0])}))
+    res = {"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "triplane_crop": a.crop, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
+           "verts": int(out[0].shape[0]), "faces": int(out[1].shape[0])}
+    if a.check:
+        import hashlib
+        res["sha256"] = hashlib.sha256(LAST["sigma"].cpu().numpy().tobytes()).hexdigest()
+    print(json.dumps(res))
 if dist.is_initialized():
     dist.destroy_process_group()

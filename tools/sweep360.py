@@ -16,6 +16,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=120)
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--batch", type=int, default=1, help="views per launch (planes shared by the batch: P3D_FLAG_SHARED_PLANES)")
+ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered [views,4,res,res] tensor: every view draws from "
+                "its own seeded generator (the reference seeds each view: _train/eg3dc/util/eg3dc_v0.py:72), so the hash must be the "
+                "same for every world size and batch size")
 a = ap.parse_args()
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(lrank)
@@ -44,11 +47,16 @@ with torch.no_grad():
         planes = G.synthesis(ws, {}, noise_mode="const").view(1, 3, 32, 256, 256) * 4.0
         return ops.planes_to_nhwc(planes.contiguous())
 
+    def view_draws(v):  # per-view seeded draws (the reference's order: rand_like [1,R,Sc,1] then rand [R,Sf]): independent of
+        g = torch.Generator(device=dev).manual_seed(1000 + v)  # which rank renders the view and of how views are batched
+        return torch.rand((1, R, 48, 1), device=dev, generator=g), torch.rand((R, 48), device=dev, generator=g)
+
     def render_one(v, n=1):
         o, d = cameras.rays_from_label(labels[v:v + n], res)
-        jit = torch.rand((n, R, 48, 1), device=dev)
-        u = torch.rand((n * R, 48), device=dev)
-        feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)  # nhwc is [1,...]: shared by the n views
+        dr = [view_draws(v + k) for k in range(n)]
+        jit, u = torch.cat([x[0] for x in dr]), torch.cat([x[1] for x in dr])
+        # nhwc is [1,...]: shared by the n views; each view keeps its own depth-clamp range, like n calls of the reference
+        feat, depth, wsum, xyz = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res, per_view_clamp=True)
         return feat, wsum
 
     def render_local_batched():
@@ -71,7 +79,11 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
 if rank == 0:
     assert frames.shape == (a.views, 4, res, res)
-    print(json.dumps({"config": "c4", "views": a.views, "res": res, "batch": a.batch, "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
-                      "rays_per_s": a.views * R / dt, "alpha_mean": float(frames[:, 3].mean())}))
+    out = {"config": "c4", "views": a.views, "res": res, "batch": a.batch, "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
+           "rays_per_s": a.views * R / dt, "alpha_mean": float(frames[:, 3].mean())}
+    if a.check:
+        import hashlib
+        out["sha256"] = hashlib.sha256(frames.cpu().numpy().tobytes()).hexdigest()
+    print(json.dumps(out))
 if dist.is_initialized():
     dist.destroy_process_group()
