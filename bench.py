@@ -46,6 +46,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 L1_PEAK_LOOKUPS = 1.6   # 16-B lane requests per clock per CU the TCP serves (tools/ubench/gather_coalesce.hip, measured)
 
 
+def alg_bytes(R, Sc, Sf):
+    """ALGORITHMIC bytes of one launch: (Sc + Sf) * 1536 + 172 per ray."""
+    return R * ((Sc + Sf) * 1536 + 172)
+
+
 def make_scene(dev, seed, res, azim, scene="surface"):
     """(planes, raw decoder, ray origins, ray directions) as CPU tensors — used by the tools/ benchmarks (c5, mesh, small views)."""
     import panic3d_amd as P
@@ -172,7 +177,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-early-out", action="store_true", help="decode every sample in the timed region too")
-    ap.add_argument("--fast-color", action="store_true", help="P3D_FLAG_FAST_COLOR: tolerance-mode final pass (opt-in)")
+    ap.add_argument("--exact", action="store_true", help="time the exact-contract final pass (bit-identical to the CPU oracle) instead "
+                    "of the default tolerance mode (P3D_FLAG_FAST_COLOR: f16 two-term MFMA + hardware transcendentals in the final pass)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,9 +207,8 @@ def main():
     o_c, d_c = P.cameras.rays_from_label(label[None], res)
     planes, o, d = torch.from_numpy(planes_np).to(dev), o_c.to(dev), d_c.to(dev)
     mlp = ops.prescale_mlp(*(torch.from_numpy(x).to(dev) for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
-    okw = dict(kw)
-    if a.fast_color:
-        okw["fast_color"] = True
+    fast = not a.exact
+    okw = dict(kw, fast_color=fast)
     opts = ops.make_opts(ro, early_out=not a.no_early_out, **okw)
     opts_full = ops.make_opts(ro, early_out=False, **okw)
 
@@ -269,20 +274,30 @@ def main():
         st = {}
         frame = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res, stats=st)
         exec_frac = st["decode_steps"] / st["decode_steps_full"]
+        def time_kernel(op, n):
+            for _ in range(3):
+                ops.render(nhwc, o, d, jit, u, mlp, op, ray_tile_w=res)
+            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for e0, e1 in ev2:
+                e0.record()
+                ops.render(nhwc, o, d, jit, u, mlp, op, ray_tile_w=res)
+                e1.record()
+            torch.cuda.synchronize()
+            return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev2]))
+
+        other = None
         if a.no_early_out:
             full_ms = kern_ms
         elif a.roofline_steps <= 0:  # profiling passes: only the timed region's launches exist
             full_ms = None
         else:
-            for _ in range(3):
-                ops.render(nhwc, o, d, jit, u, mlp, opts_full, ray_tile_w=res)
-            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.roofline_steps)]
-            for e0, e1 in ev2:
-                e0.record()
-                ops.render(nhwc, o, d, jit, u, mlp, opts_full, ray_tile_w=res)
-                e1.record()
-            torch.cuda.synchronize()
-            full_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev2]))
+            full_ms = time_kernel(opts_full, a.roofline_steps)
+            # the other final-pass mode (exact contract <-> tolerance mode) beside the timed one, early-outs on and off
+            okw2 = dict(kw, fast_color=not fast)
+            other = {"mode": "exact" if fast else "fast_color",
+                     "kernel_ms": time_kernel(ops.make_opts(ro, early_out=True, **okw2), a.roofline_steps),
+                     "kernel_ms_no_early_out": time_kernel(ops.make_opts(ro, early_out=False, **okw2), a.roofline_steps)}
+            other["frac"] = alg_bytes(R, Sc, Sf) / (other["kernel_ms_no_early_out"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         rays = world * R * a.steps
         bytes_per_ray = (Sc + Sf) * 1536 + 172
         alg = R * bytes_per_ray
@@ -297,7 +312,10 @@ def main():
                 "frac_definition": "algorithmic bytes / kernel time with the early-outs DISABLED (all samples decoded) / peak",
                 "frac_executed": achieved_exec / HBM_PEAK_GBS, "decode_steps_executed_frac": exec_frac,
                 "speedup_from_exact_early_outs": full_ms / kern_ms if full_ms else None,
-                "algorithmic_bytes_per_launch": alg, "kernel_src_sha": src_sha}
+                "algorithmic_bytes_per_launch": alg, "kernel_src_sha": src_sha,
+                "final_pass_mode": "fast_color (tolerance: f16 two-term MFMA + hardware exp2/log2/rcp; coarse pass and inverse-CDF "
+                                   "indices exact)" if fast else "exact (bit-identical to the arithmetic contract / CPU oracle)",
+                "other_mode": other}
         if pmc:
             roof["bounds"] = pmc.get("bounds")
             roof["pmc_source"] = pmc.get("source")
@@ -314,7 +332,7 @@ def main():
                                       "round-1 surface scene: smooth-blob planes, strong sigma row (~55 % of rays hit a surface)")
                                    + ", crop=0.1 cull=0.5 white_back, step = transpose + rand draws + fused render + depth clamp"
                                    + ("; after the K steps ONE gather of all ranks' RGBA frames to rank 0, inside the timed region" if launched else "")
-                                   + ("; P3D_FLAG_FAST_COLOR" if a.fast_color else ""),
+                                   + ("; final pass in tolerance mode (P3D_FLAG_FAST_COLOR)" if fast else "; exact-contract final pass"),
                        "scene": a.scene, "rays_per_step_per_gpu": R, "samples_per_ray": Sc + Sf, "parallelism": f"views x{world}"},
             "roofline": roof,
             "wsum_mean": float(ws.mean().item()), "hit_fraction": float((ws > 0.5).float().mean().item()),
@@ -323,7 +341,7 @@ def main():
             out["per_rank"] = per_rank
         if not a.no_verify:
             out["verify"] = verify_block(ops, planes_np, raw, nhwc, o, d, jit, u, mlp, opts, frame, ro, kw, res, Sc, Sf,
-                                         exact=not a.fast_color)
+                                         exact=not fast)
             if not out["verify"]["ok"]:
                 print(json.dumps(out))
                 raise SystemExit("bench.py: the rendered frame does not match the oracle")

@@ -43,8 +43,9 @@ extern "C" {
 #define P3D_FLAG_NO_PAIR 256 /* p3d_render_f32: never use the small-launch kernel (16 rays x 2 samples per wave); tests */
 #define P3D_FLAG_SKIP_CROPPED 128 /* p3d_grid_density_f32 with out_cropmask: points whose crop mask fires are not decoded and get
                                      out_sigma = -1000 (get_eg3d_volume overwrites their density anyway, eg3d_metrics3d.py:155-159) */
-#define P3D_FLAG_FAST_COLOR 512 /* p3d_render_f32, opt-in TOLERANCE mode of the final pass: both decoder layers on f16 MFMA with
-                                   two-term operand splits (~2^-21 per product) and hardware exp2 / log2 / rcp activations.  The
+#define P3D_FLAG_FAST_COLOR 512 /* p3d_render_f32: the caller ACCEPTS fp32-tolerance colours, so the final pass may run in its
+                                   tolerance mode: both decoder layers on f16 MFMA with two-term operand splits (~2^-21 per
+                                   product) and hardware exp2 / log2 / rcp activations (small launches stay on the exact kernel).  The
                                    coarse pass — hence the inverse-CDF indices, the fine depths and the merged depth order —
                                    stays on the exact contract; feat / depth / wsum / xyz agree with it to fp32 tolerance
                                    (tests/test_hip_parity.py::test_fast_color_*). */

@@ -1269,12 +1269,14 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     const bool dmp = dumps != nullptr;
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
-    if (!dmp && !fast && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
+    // (P3D_FLAG_FAST_COLOR is a permission, not an obligation: this kernel has no tolerance variant and its exact results are
+    // trivially within any tolerance)
+    if (!dmp && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
         else p.tiles_per_img = (R + 15) / 16;
         p.ntiles = p.tiles_per_img * N;
         nwaves = P3D_RENDER_WAVES;
-        for (;; nwaves >>= 1) {
+        for (;; nwaves >>= 1) {  // (always the exact kernel's LDS image)
             lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
             if (lds_bytes <= 160 * 1024) break;
             if (nwaves == 1) return P3D_E_RANGE;

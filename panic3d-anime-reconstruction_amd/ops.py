@@ -262,8 +262,7 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         steps = int(ws[8:16].view(torch.int64).item())
         tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)
         tiles = (R // 32) * N if tiled else -(-R // 32) * N
-        fast = bool(opts.flags & _lib.P3D_FLAG_FAST_COLOR) and Sf > 0
-        pair = not dumps and not fast and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
+        pair = not dumps and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
         if pair:  # 16 rays x 2 samples per wave-step
             tiles = (R // 16) * N if tiled else -(-R // 16) * N
             full = tiles * ((-(-Sc // 2) + -(-(Sc + Sf) // 2)) if Sf > 0 else -(-Sc // 2))

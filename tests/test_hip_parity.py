@@ -299,7 +299,7 @@ def test_shared_planes_many_views_one_launch(hip, oracle):
     Dec.net = [FC(raw[0], raw[1], 32), None, FC(raw[2], raw[3], 64)]
     r = hip.ImportanceRenderer(use_triplane=bool(inp["ro"]["use_triplane"]))
     kw = {k: v for k, v in inp["kw"].items() if k != "force_sigmoid"}
-    out = r(dev(planes1).expand(2, -1, -1, -1, -1), Dec(), o, d, inp["ro"], jitter=jit, u=u, **kw)
+    out = r(dev(planes1).expand(2, -1, -1, -1, -1), Dec(), o, d, inp["ro"], jitter=jit, u=u, exact=True, **kw)
     for a, b in zip(out, ref):
         assert np.array_equal(a.cpu().numpy(), b)
 
