@@ -194,6 +194,13 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
 int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,
                       int padx1, int pady0, int pady1, float* y, void* stream);
 
+/* upsample2d of the skip image fused with the ToRGB accumulation of SynthesisBlock.forward (networks_stylegan2.py:476-478:
+ * `img = upsample2d(img, resample_filter); img = img.add_(y)`): y = upfirdn2d(x, up = 2, pad [2,1,2,1], f4x4) + add, the FIR in
+ * polyphase form with the generic operator's summation order (bit-identical to p3d_upfirdn2d_f32).  x [NC][H][W];
+ * f4x4: the 4x4 filter already flipped and multiplied by up^2; add [NC][2H][2W] or NULL; y [NC][2H][2W].  Needs 2W % 4 == 0 and
+ * 16-byte aligned add / y (P3D_E_RANGE otherwise: use p3d_upfirdn2d_f32). */
+int p3d_upsample2d_add_f32(const float* x, int64_t NC, int H, int W, const float* f4x4, const float* add, float* y, void* stream);
+
 /* bias_act (torch_utils/ops/bias_act.py:54-88; plugin signature bias_act.cpp:36): y = clamp(act(x + b[c]) * gain), x viewed
  * as [outer][C][inner]; act 0 linear / 1 lrelu(alpha); b may be NULL; clamp < 0: none. */
 int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64_t inner, int act, float alpha, float gain,

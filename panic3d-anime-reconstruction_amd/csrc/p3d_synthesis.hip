@@ -586,8 +586,18 @@ struct ReduceParams {
 __global__ void k_splitk_reduce(ReduceParams p) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.per_slice) return;
+    // slice-ordered sum (deterministic); the loads of 8 slices are issued together — a deep split of a tiny map (64 slices of
+    // 8192 outputs) is otherwise one exposed load latency per slice
     float v = p.part[idx];
-    for (int k = 1; k < p.ksplit; ++k) v += p.part[(size_t)k * p.per_slice + idx];
+    int k = 1;
+    for (; k + 8 <= p.ksplit; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p.part[(size_t)(k + u) * p.per_slice + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; k < p.ksplit; ++k) v += p.part[(size_t)k * p.per_slice + idx];
     if (p.epilogue) {
         long long no = idx / p.OHW;
         int pix = (int)(idx - no * p.OHW), ch = (int)(no % p.O);
@@ -687,6 +697,52 @@ __global__ void k_upfirdn2d(FirParams p) {
     p.y[idx] = acc;
 }
 
+// upsample2d of the skip image (networks_stylegan2.py:476 -> upfirdn2d.py:341-350: up 2, pad [2,1,2,1], 4x4 filter) in polyphase
+// form — only the 2x2 taps that meet non-zero samples of the zero-inserted input, in the generic kernel's order (fy, then fx,
+// ascending), so the sums are bit-identical to k_upfirdn2d — fused with `img.add_(y)` (:478): out = upsample(x) + add.
+// One thread = 4 consecutive output pixels of a row (OW % 4 == 0).
+__global__ __launch_bounds__(256) void k_upsample2x_add(const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ add,
+                                                         float* __restrict__ y, long long NC, int H, int W) {
+    const int OW = 2 * W, OH = 2 * H, QW = OW >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NC * OH * QW) return;
+    const int q = (int)(idx % QW);
+    const int Y = (int)((idx / QW) % OH);
+    const long long nc = idx / ((long long)QW * OH);
+    const float* xc = x + nc * H * W;
+    float ff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ff[i] = f[i];
+    float out[4];
+    const int fy0 = Y & 1;  // taps fy0, fy0 + 2 meet rows u = (Y + fy - 2) / 2
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int X = 4 * q + j;
+        const int fx0 = j & 1;  // X & 1
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int fy = fy0 + 2 * a, u = (Y + fy - 2) >> 1;  // arithmetic shift: -1 for the row above the image
+            if (u < 0 || u >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int fx = fx0 + 2 * b, v = (X + fx - 2) >> 1;
+                if (v < 0 || v >= W) continue;
+                acc = __builtin_fmaf(fy0 ? (fx0 ? ff[(1 + 2 * a) * 4 + 1 + 2 * b] : ff[(1 + 2 * a) * 4 + 2 * b])
+                                         : (fx0 ? ff[(2 * a) * 4 + 1 + 2 * b] : ff[(2 * a) * 4 + 2 * b]),
+                                     xc[(size_t)u * W + v], acc);
+            }
+        }
+        out[j] = acc;
+    }
+    const size_t o = ((size_t)nc * OH + Y) * OW + 4 * q;
+    if (add) {
+        const float4 a4 = *reinterpret_cast<const float4*>(add + o);
+        out[0] += a4.x; out[1] += a4.y; out[2] += a4.z; out[3] += a4.w;
+    }
+    *reinterpret_cast<float4*>(y + o) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 // 4x4 FIR without resampling (the filter pass after the stride-2 transposed conv), LDS-tiled: a 256-thread block produces
 // a 32x32 output tile of one (n,c) plane from a 35x35 input tile; each thread computes a 2x2 output block from a 5x5 LDS
 // window.  Every input element is read from HBM/L2 once (the generic kernel above re-reads each 16 times through L1).
@@ -768,7 +824,9 @@ static void launch_conv(ConvParams p, hipStream_t st) {
 static int choose_ksplit(int N, int I, int O, int GH, int GW) {
     long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
-    while (ks < 16 && wgs * ks < 512 && I / (ks * 2) >= 64) ks *= 2;
+    // down to ONE 8-channel chunk per workgroup: at batch 1 the 4^2..16^2 layers are a weight stream (9.4 MB for 512 -> 512 x 3x3)
+    // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/r02_notes.txt
+    while (ks < 64 && wgs * ks < 512 && I / (ks * 2) >= 8) ks *= 2;
     return ks;
 }
 
@@ -891,6 +949,15 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
     q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1;
     long long total = q.NC * q.OH * q.OW;
     hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
+    return chk();
+}
+
+int p3d_upsample2d_add_f32(const float* x, int64_t NC, int H, int W, const float* f4x4, const float* add, float* y, void* stream) {
+    if (!x || !f4x4 || !y || NC <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if ((2 * W) % 4 != 0 || (((uintptr_t)y | (uintptr_t)add) & 15)) return P3D_E_RANGE;  // float4 rows: use p3d_upfirdn2d_f32 otherwise
+    const long long total = (long long)NC * (2 * H) * ((2 * W) / 4);
+    hipLaunchKernelGGL(k_upsample2x_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, f4x4, add, y,
+                       (long long)NC, H, W);
     return chk();
 }
 

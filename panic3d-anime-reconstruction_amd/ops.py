@@ -438,6 +438,26 @@ def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1):
     return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * up * up)
 
 
+def upsample2d_add(x, f, add=None):
+    """`upsample2d(x, f)` (up = 2, the 4x4 resample filter) fused with the `img.add_(y)` that follows it in SynthesisBlock.forward
+    (networks_stylegan2.py:476-478): returns upsample2d(x, f) + add in one launch (polyphase FIR, same bits as upfirdn2d)."""
+    x = _chk(x, "x")
+    N, Cc, H, W = x.shape
+    if tuple(f.shape) != (4, 4) or (2 * W) % 4 != 0:
+        y = upsample2d(x, f)
+        return y if add is None else y.add_(add)
+    ff = prepared_filter(f, x.device, 4.0, False)
+    if add is not None:
+        add = _chk(add, "add")
+        if tuple(add.shape) != (N, Cc, 2 * H, 2 * W):
+            raise RuntimeError("add must be [N,C,2H,2W]")
+    y = torch.empty((N, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().p3d_upsample2d_add_f32(_p(x), N * Cc, H, W, _p(ff), _p(add), _p(y), _stream())
+    _lib.check(rc, "p3d_upsample2d_add_f32")
+    return y
+
+
 def conv_weights_to_f16(weight):
     """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer)."""
     weight = _chk(weight, "weight")

@@ -22,7 +22,7 @@ from . import ops
 # The final pass of the fused renderer may run in its tolerance mode (P3D_FLAG_FAST_COLOR: f16 two-term MFMA + hardware
 # transcendentals; 15 % faster at 512^2 x 96, PSNR > 90 dB against the exact path, inverse-CDF indices untouched — DESIGN.md
 # §4.6).  The reference itself only promises "minor hardware variations" between GPUs (readme.md:74).  Set to False (or pass
-# exact=True to forward) for results that are bit-identical to the arithmetic contract / the CPU oracle.
+# exact=True to forward) for results that are bit-identical to the arithmetic contract (include/p3d_numerics.h).
 DEFAULT_FAST_COLOR = True
 
 

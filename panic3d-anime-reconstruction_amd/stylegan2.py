@@ -310,10 +310,9 @@ class SynthesisBlock(torch.nn.Module):
         else:
             x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), **layer_kwargs)
             x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
-        if img is not None:
-            img = ops.upsample2d(img, self.resample_filter)
         y = self.torgb(x, next(w_iter), pre=pre.get("torgb"))
-        img = img.add_(y) if img is not None else y
+        # img = upsample2d(img, resample_filter); img = img.add_(y) (networks_stylegan2.py:476-478) in one launch
+        img = ops.upsample2d_add(img, self.resample_filter, y) if img is not None else y
         return x, img
 
 
