@@ -3,7 +3,8 @@
 
     python tools/summarize_prof.py <tag>
 
-Writes, per scene (canonical / surface) and mode (early = exact early-outs on = the default; noearly = every sample decoded):
+Writes, per scene (canonical / surface) and mode (early = the default launch: tolerance-mode final pass, exact early-outs on;
+noearly = every sample decoded; exact_early / exact_noearly = the same with the exact-contract final pass, bench.py --exact):
   profiles/<tag>_<scene>_<mode>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names cut to 80 chars)
   profiles/<tag>_pmc.json                          per-launch averages of every counter for k_render + dispatch info
   profiles/pmc_latest.json                         {scene: {kernel_src_sha, hbm_bytes_per_launch, bounds, source}} of the DEFAULT mode —
@@ -36,7 +37,7 @@ def main():
     sha = open(os.path.join(src, "kernel_src_sha.txt")).read().strip()
     allpmc, latest = {}, {}
     for scene in ("canonical", "surface"):
-        for mode in ("early", "noearly"):
+        for mode in ("early", "noearly", "exact_early", "exact_noearly"):
             ks = glob.glob(os.path.join(src, f"stats_{scene}_{mode}", "**", "*kernel_stats.csv"), recursive=True)
             kern_ns = None
             if ks:
