@@ -22,6 +22,9 @@
 
 #define P3D_WAVES_PER_WG 4
 #define P3D_RENDER_WAVES 4  // k_render workgroup (two workgroups per CU -> two waves per SIMD)
+#ifndef P3D_RENDER_OCC
+#define P3D_RENDER_OCC 2    // waves per SIMD the register allocation of k_render is held to (launch_bounds) and the host packs for
+#endif
 #define P3D_WG (64 * P3D_WAVES_PER_WG)
 
 // =====================================================================================================================
@@ -273,7 +276,7 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
 // the importance resampling (inverse-CDF indices, fine depths, merged depth order), stays on the exact contract.
 // EARLY: the exact early-outs (compile-time, so that the measurement / dump variant is the plain uniform loop).
 template <int NF, bool DUMP, bool FAST, bool EARLY>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParams p) {
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_render(RenderParams p) {
     static_assert(!(DUMP && EARLY), "dumps need every sample decoded");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
@@ -443,7 +446,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render(RenderParam
         }
         // unify_samples (renderer.py:289-301) merges two sorted lists; the stratified list is sorted unless rounding
         // reversed two neighbours (practically never) — then sort it too.
-        if (__builtin_amdgcn_ballot_w64(unsorted) != 0) p3d_lds_insertion_sort(tcA, Sc, j);
+        if (__builtin_amdgcn_ballot_w64(unsorted) != 0) {
+            p3d_lds_insertion_sort(tcA, Sc, j);
+            if (early) {  // the known-masked bits are indexed by ORIGINAL coarse index: forget them (practically never taken)
+                for (int i = 0; i < ((Sc + 31) >> 5); ++i) mkA[i * 32 + j] = 0u;
+            }
+        }
     }
     // ---- final pass: merge on the fly (ties: coarse first = stable), decode, composite [rgb | xyz]:
     //      renderer.py:243-259, ray_marcher.py:25-57.
@@ -1254,7 +1262,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
             const size_t per_wg = lds_fixed + w * lds_wave;
             if (per_wg > 160 * 1024) continue;
             int wgs = (int)((160 * 1024) / per_wg);
-            int waves = wgs * w > 8 ? 8 / w * w : wgs * w;
+            int waves = wgs * w > 4 * P3D_RENDER_OCC ? 4 * P3D_RENDER_OCC / w * w : wgs * w;
             if (waves > best_waves) { best_waves = waves; best = w; }
         }
         if (best == 0) return P3D_E_RANGE;
