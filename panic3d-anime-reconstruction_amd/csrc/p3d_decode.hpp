@@ -53,12 +53,14 @@ P3D_DEV int p3d_rowof(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // Cooperative load by the whole workgroup (blockDim.x threads).  Caller must __syncthreads() afterwards.
 // with_w1a = false: a FAST kernel, whose f16 colour weights overlay W1A (p3d_load_mlp_f16_to_lds).
+// with_w0a = false: a tolerance-mode kernel that never runs the exact layer 1 either (the density query): its `lds` base may
+// then point P3D_LDS_B0P floats BEFORE the allocation (nothing below P3D_LDS_B0P is touched).
 P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, const float* w1, const float* b1,
-                                 bool with_w1a = true) {
+                                 bool with_w1a = true, bool with_w0a = true) {
     for (int idx = threadIdx.x; idx < 2048; idx += blockDim.x) {
         int e = idx & 3, l = (idx >> 2) & 63, s4 = (idx >> 8) & 3, t = idx >> 10;
         int s = 4 * s4 + e, i = l & 31, h = l >> 5;
-        lds[P3D_LDS_W0A + idx] = w0[(32 * t + i) * 32 + 16 * h + s];
+        if (with_w0a) lds[P3D_LDS_W0A + idx] = w0[(32 * t + i) * 32 + 16 * h + s];
         if (with_w1a) lds[P3D_LDS_W1A + idx] = w1[(1 + i) * 64 + 32 * t + p3d_rowof(s) + 4 * h];
     }
     for (int idx = threadIdx.x; idx < 64; idx += blockDim.x) {
@@ -76,7 +78,7 @@ P3D_DEV void p3d_load_mlp_to_lds(float* lds, const float* w0, const float* b0, c
 
 // FAST kernels: the f16 hi/lo operand images.  Call AFTER p3d_load_mlp_to_lds (W1H overlays W1A, which such a kernel never
 // reads) and before its __syncthreads().
-P3D_DEV void p3d_load_mlp_f16_to_lds(float* lds, const float* w0, const float* w1) {
+P3D_DEV void p3d_load_mlp_f16_to_lds(float* lds, const float* w0, const float* w1, bool with_w1h = true) {
     _Float16* w0h = (_Float16*)(lds + P3D_LDS_W0H);
     _Float16* w1h = (_Float16*)(lds + P3D_LDS_W1H);
     for (int idx = threadIdx.x; idx < 2048; idx += blockDim.x) {  // idx = ((t*2 + q) * 64 + l) * 8 + i
@@ -87,7 +89,7 @@ P3D_DEV void p3d_load_mlp_f16_to_lds(float* lds, const float* w0, const float* w
         const _Float16 ah = (_Float16)a, bh = (_Float16)b;
         const int o = (((t * 2 + q) * 2) * 64 + l) * 8 + i;  // hi image of chunk (t,q); the lo image follows 64 lanes later
         w0h[o] = ah; w0h[o + 512] = (_Float16)(a - (float)ah);
-        w1h[o] = bh; w1h[o + 512] = (_Float16)(b - (float)bh);
+        if (with_w1h) { w1h[o] = bh; w1h[o + 512] = (_Float16)(b - (float)bh); }
     }
 }
 
@@ -183,27 +185,15 @@ P3D_DEV void p3d_pin16(f32x16& v) {
 #ifndef P3D_GATHER_DEPTH
 #define P3D_GATHER_DEPTH 4  // taps in flight per lane (2 / 3 / 4 / 6 measured within 3 % of each other: profiles/r02_notes.txt)
 #endif
-// This lane's 16 interpolated feature channels (16h .. 16h+15) of the sample at (px,py,pz): the three bilinear plane samples
-// and their mean (renderer.py:68-81, triplane.py:530).
-template <typename RSRC>
-P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz,
-                                   bool live) {
-    const int h = __lane_id() >> 5;
-    const uint32_t chan_off = (uint32_t)h * 64u;
-    float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
-    // generate_planes / project_onto_planes: renderer.py:26-66
-    // Tap-granular software pipeline: P3D_GATHER_DEPTH of the 12 taps (16 registers each) are in flight while the oldest one
-    // is folded into its plane's bilinear sum, in the contract's order (nw, ne, sw, se; plane 0 + plane 1, + plane 2, x 1/3).
-    // The depth bounds the live tap registers (the compiler would otherwise hoist all 48 loads = 192 VGPRs).
-    float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
-    uint32_t of[12];
-    float wg[12];
-    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of, wg, live);
-    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of + 4, wg + 4, live);
-    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of + 8, wg + 8, live);
+// Tap-granular software pipeline over the 12 taps of a sample (3 planes x nw, ne, sw, se): P3D_GATHER_DEPTH taps (16 registers
+// each) are in flight while the oldest one is folded into its plane's bilinear sum, in the contract's order (nw, ne, sw, se;
+// plane 0 + plane 1, + plane 2, x 1/3).  The depth bounds the live tap registers (the compiler would otherwise hoist all 48
+// loads = 192 VGPRs).  load(k) returns this lane's 16 channels of tap k.
+template <typename LOAD>
+P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
     f32x16 tap[P3D_GATHER_DEPTH];
 #pragma unroll
-    for (int k = 0; k < P3D_GATHER_DEPTH; ++k) tap[k] = p3d_load16(rs, of[k]);
+    for (int k = 0; k < P3D_GATHER_DEPTH; ++k) tap[k] = load(k);
     f32x16 X, f;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -229,10 +219,174 @@ P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDeco
         // orders machine instructions that already sit on either side of it) and every tap stays live
         p3d_pin16(f);
         __builtin_amdgcn_sched_barrier(0);
-        if (k + P3D_GATHER_DEPTH < 12) tap[k % P3D_GATHER_DEPTH] = p3d_load16(rs, of[k + P3D_GATHER_DEPTH]);
+        if (k + P3D_GATHER_DEPTH < 12) tap[k % P3D_GATHER_DEPTH] = load(k + P3D_GATHER_DEPTH);
     }
     __builtin_amdgcn_sched_barrier(0);
     return X;
+}
+
+// This lane's 16 interpolated feature channels (16h .. 16h+15) of the sample at (px,py,pz): the three bilinear plane samples
+// and their mean (renderer.py:68-81, triplane.py:530), gathered straight from the planes (per-lane L1 gathers).
+template <typename RSRC>
+P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz,
+                                   bool live) {
+    const int h = __lane_id() >> 5;
+    const uint32_t chan_off = (uint32_t)h * 64u;
+    float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;  // renderer.py:77
+    // generate_planes / project_onto_planes: renderer.py:26-66
+    float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
+    uint32_t of[12];
+    float wg[12];
+    p3d_tap_offsets(g, 0u, chan_off, qx, qy, of, wg, live);
+    p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of + 4, wg + 4, live);
+    p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of + 8, wg + 8, live);
+    return p3d_fold_taps(wg, [&](int k) { return p3d_load16(rs, of[k]); });
+}
+
+// ---- LDS-staged gather for the regular-grid query (north_star's "LDS-staged plane tiles") -------------------------------
+// The 32 consecutive grid points of a wave-step (one grid row: x and y fixed, z advancing by about half a texel) read 384
+// taps that fall on ~80 distinct texels: a 2 x 2..3 block of plane (x,y) and two 2 x ~18 strips of the planes that carry z.
+// The vector L1's service time per gather instruction is what bounds the density query, so the wave loads each
+// plane's texel box ONCE, coalesced (whole 128-byte lines, <= 15 loads per lane instead of 48), parks it in its own LDS region
+// and gathers the taps from there.  Same values (out-of-plane texels are stored as zeros), same arithmetic: bit-identical.
+#define P3D_BOX_TEXELS 40                                  // texels per plane box (xspan * yspan must fit)
+#define P3D_BOX_STRIDE 144u                                // bytes per parked texel: 128 + 16 of padding, so that consecutive texels
+                                                           // start 36 banks apart and the 16 lanes of a ds_read_b128 group (<= 8
+                                                           // neighbouring texels x 4 banks) never collide
+#define P3D_BOX_PLANE_FLOATS (P3D_BOX_TEXELS * 36)
+#define P3D_BOX_FLOATS_PER_WAVE (3 * P3D_BOX_PLANE_FLOATS)  // 16.9 KB per wave
+
+struct P3dBox { int xmin, ymin, xspan, yspan; };  // wave-uniform
+
+// texel of the (nw) tap of one plane; inr as in p3d_tap_offsets
+P3D_DEV void p3d_plane_texel(const P3dPlaneGeom& g, float gx, float gy, int& x0, int& y0, bool& inr) {
+    const float ix = (gx + 1.0f) * g.halfW - 0.5f, iy = (gy + 1.0f) * g.halfH - 0.5f;
+    inr = (ix > -1.0f) && (ix < g.fW) && (iy > -1.0f) && (iy < g.fH);
+    x0 = (int)__builtin_floorf(ix);
+    y0 = (int)__builtin_floorf(iy);
+}
+
+// Box of one plane from the first and the last sample of the tile (the coordinates are monotone along a grid row), verified
+// against every lane.  Returns false (wave-uniform) when the taps do not fit: the caller then gathers directly.
+P3D_DEV bool p3d_make_box(int x0, int y0, bool inr, P3dBox& b) {
+    const int xa = __builtin_amdgcn_readlane(x0, 0), xb = __builtin_amdgcn_readlane(x0, 31);
+    const int ya = __builtin_amdgcn_readlane(y0, 0), yb = __builtin_amdgcn_readlane(y0, 31);
+    b.xmin = xa < xb ? xa : xb;
+    b.ymin = ya < yb ? ya : yb;
+    const int xmax = xa < xb ? xb : xa, ymax = ya < yb ? yb : ya;
+    b.xspan = xmax - b.xmin + 2;
+    b.yspan = ymax - b.ymin + 2;
+    const bool inside = inr && x0 >= b.xmin && x0 <= xmax && y0 >= b.ymin && y0 <= ymax;
+    return __builtin_amdgcn_ballot_w64(!inside) == 0 && b.xspan * b.yspan <= P3D_BOX_TEXELS;
+}
+
+// All 64 lanes: load the box of one plane (<= 40 texels = 320 16-byte pieces, 5 per lane) into registers.
+template <typename RSRC>
+P3D_DEV void p3d_box_load(RSRC rs, const P3dPlaneGeom& g, uint32_t plane_off, const P3dBox& b, i32x4 v[5]) {
+    const int lane = __lane_id();
+    const int npieces = b.xspan * b.yspan * 8, H = (int)g.fH;
+    const float inv = 1.0f / (float)b.xspan;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int f = lane + 64 * r, tex = f >> 3, piece = f & 7;
+        const int by = (int)(((float)tex + 0.5f) * inv);  // tex / xspan for the small integers involved
+        const int bx = tex - by * b.xspan;
+        const int x = b.xmin + bx, y = b.ymin + by;
+        const bool ok = f < npieces && x >= 0 && x < g.W && y >= 0 && y < H;  // out-of-plane texels: zeros (padding_mode='zeros')
+        const uint32_t off = ok ? plane_off + (uint32_t)((y * g.W + x) * 128 + piece * 16) : P3D_OOB_OFFSET;
+        v[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    }
+}
+P3D_DEV void p3d_box_store(float* box_plane /* this wave's region of one plane */, const i32x4 v[5]) {
+    const int lane = __lane_id();
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int f = lane + 64 * r;  // piece f = texel (f >> 3), 16-byte piece (f & 7)
+        *(i32x4*)((char*)box_plane + (f >> 3) * P3D_BOX_STRIDE + (f & 7) * 16) = v[r];
+    }
+}
+
+// tap byte offsets inside the wave's box region + bilinear weights of one plane (cf. p3d_tap_offsets)
+P3D_DEV void p3d_tap_offsets_box(const P3dPlaneGeom& g, const P3dBox& b, uint32_t region_off, uint32_t chan_off, float gx, float gy,
+                                 uint32_t off[4], float wgt[4], bool live) {
+    float ix = (gx + 1.0f) * g.halfW - 0.5f;
+    float iy = (gy + 1.0f) * g.halfH - 0.5f;
+    bool inr = live && (ix > -1.0f) && (ix < g.fW) && (iy > -1.0f) && (iy < g.fH);
+    float fx0 = __builtin_floorf(ix), fy0 = __builtin_floorf(iy);
+    float wx1 = ix - fx0, wy1 = iy - fy0;
+    float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    wgt[0] = inr ? wy0 * wx0 : 0.0f;
+    wgt[1] = inr ? wy0 * wx1 : 0.0f;
+    wgt[2] = inr ? wy1 * wx0 : 0.0f;
+    wgt[3] = inr ? wy1 * wx1 : 0.0f;
+    // the caller has verified that every lane's texel lies inside the box (p3d_make_box); a lane that is not live carries zero
+    // weights and reads the box origin
+    const int tx = inr ? (int)fx0 - b.xmin : 0, ty = inr ? (int)fy0 - b.ymin : 0;
+    const uint32_t base = region_off + chan_off + (uint32_t)(ty * b.xspan + tx) * P3D_BOX_STRIDE;
+    const uint32_t row = (uint32_t)b.xspan * P3D_BOX_STRIDE;
+    off[0] = base; off[1] = base + P3D_BOX_STRIDE; off[2] = base + row; off[3] = base + row + P3D_BOX_STRIDE;
+}
+P3D_DEV f32x16 p3d_lds16(const float* box, uint32_t off) {
+    const f32x4* q = (const f32x4*)((const char*)box + off);
+    const f32x4 fa = q[0], fb = q[1], fc = q[2], fd = q[3];
+    f32x16 v;
+    v.s0 = fa.x; v.s1 = fa.y; v.s2 = fa.z; v.s3 = fa.w;
+    v.s4 = fb.x; v.s5 = fb.y; v.s6 = fb.z; v.s7 = fb.w;
+    v.s8 = fc.x; v.s9 = fc.y; v.sa = fc.z; v.sb = fc.w;
+    v.sc = fd.x; v.sd = fd.y; v.se = fd.z; v.sf = fd.w;
+    return v;
+}
+
+// The staged gather in two halves, so that the caller can keep the NEXT tile's box loads in flight (in registers) while it
+// decodes the current tile:
+//   p3d_stage_plan   boxes of a tile (wave-uniform) + the 15 box loads per lane issued into registers; false = does not fit
+//   p3d_stage_commit registers -> this wave's LDS region (the previous tile's taps must have been consumed)
+//   p3d_gather_features_boxed  the taps from LDS, folded like p3d_gather_features (same values, same arithmetic)
+struct P3dStage {
+    P3dBox b[3];
+    i32x4 v[15];
+};
+template <typename RSRC>
+P3D_DEV bool p3d_stage_plan(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz, P3dStage& st) {
+    const float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;
+    const float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
+    int x0, y0;
+    bool inr, fits;
+    p3d_plane_texel(g, qx, qy, x0, y0, inr);
+    fits = p3d_make_box(x0, y0, inr, st.b[0]);
+    p3d_plane_texel(g, qx, qz, x0, y0, inr);
+    fits = p3d_make_box(x0, y0, inr, st.b[1]) && fits;
+    p3d_plane_texel(g, g2x, g2y, x0, y0, inr);
+    fits = p3d_make_box(x0, y0, inr, st.b[2]) && fits;
+    if (!fits) return false;
+    p3d_box_load(rs, g, 0u, st.b[0], st.v);
+    p3d_box_load(rs, g, g.plane_bytes, st.b[1], st.v + 5);
+    p3d_box_load(rs, g, 2u * g.plane_bytes, st.b[2], st.v + 10);
+    return true;
+}
+P3D_DEV void p3d_stage_commit(float* box, const P3dStage& st) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous tile's tap reads come first
+    __builtin_amdgcn_wave_barrier();
+    p3d_box_store(box, st.v);
+    p3d_box_store(box + P3D_BOX_PLANE_FLOATS, st.v + 5);
+    p3d_box_store(box + 2 * P3D_BOX_PLANE_FLOATS, st.v + 10);
+    // the box is written and read by different lanes of this wave only: LDS operations of a wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+P3D_DEV f32x16 p3d_gather_features_boxed(const float* box, const P3dBox b[3], const P3dPlaneGeom& g, const P3dDecodeCfg& cfg,
+                                         float px, float py, float pz, bool live) {
+    const int h = __lane_id() >> 5;
+    const uint32_t chan_off = (uint32_t)h * 64u;
+    const float qx = px * cfg.coord_scale, qy = py * cfg.coord_scale, qz = pz * cfg.coord_scale;
+    const float g2x = cfg.plane_mode ? qy : qz, g2y = cfg.plane_mode ? qz : qx;
+    uint32_t of[12];
+    float wg[12];
+    p3d_tap_offsets_box(g, b[0], 0u, chan_off, qx, qy, of, wg, live);
+    p3d_tap_offsets_box(g, b[1], P3D_BOX_PLANE_FLOATS * 4u, chan_off, qx, qz, of + 4, wg + 4, live);
+    p3d_tap_offsets_box(g, b[2], 2u * P3D_BOX_PLANE_FLOATS * 4u, chan_off, g2x, g2y, of + 8, wg + 8, live);
+    return p3d_fold_taps(wg, [&](int k) { return p3d_lds16(box, of[k]); });
 }
 
 // masks on raw sigma: renderer.py:138-153,187-198
@@ -250,12 +404,23 @@ P3D_DEV float p3d_apply_masks(const P3dDecodeCfg& cfg, float px, float pz, float
     return sigma;
 }
 
+// The decoder on already gathered features X (this lane's 16 channels), then the masks.
+template <bool WANT_RGB>
+P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                 f32x16& rgb);
+
 template <bool WANT_RGB, typename RSRC>
 P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                              float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
+    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
+    p3d_decode_features<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
+}
+
+template <bool WANT_RGB>
+P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                 f32x16& rgb) {
     const int lane = __lane_id();
     const int h = lane >> 5;
-    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
 
     // ---- layer 1 on the matrix cores: acc[t][r] = b0[n] + sum_k w0[n][k] X[k], n = 32t + rowof(r) + 4h
     const f32x4* b0p = (const f32x4*)(lds + P3D_LDS_B0P + h * 32);
@@ -355,12 +520,22 @@ P3D_DEV float p3d_sigmoid_hw(float x) {
 // Same interface and lane layout as p3d_decode_wave<true>; lds must also hold the f16 images (p3d_load_mlp_f16_to_lds).
 // Domain: |interpolated feature| and hidden activations below the f16 range (65504); results agree with the exact decode to
 // ~1e-6 (sigma, relative to the magnitude of the sum's terms) / ~3e-7 (colours).
-template <typename RSRC>
+template <bool WANT_RGB>
+P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                      f32x16& rgb);
+
+template <bool WANT_RGB = true, typename RSRC>
 P3D_DEV void p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                                   float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
+    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
+    p3d_decode_features_fast<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
+}
+
+template <bool WANT_RGB>
+P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                      f32x16& rgb) {
     const int lane = __lane_id();
     const int h = lane >> 5;
-    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
     float xs[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) xs[c] = X[c];
@@ -404,7 +579,7 @@ P3D_DEV void p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom&
     }
     float sigma = sa + p3d_partner(sa);
     // ---- layer 2 rows 1..32: K = 64 as four chunks (t, pp): lane (j,h) supplies neurons 32t + rowof(8pp + i) + 4h
-    {
+    if constexpr (WANT_RGB) {
         const f32x4* b1p = (const f32x4*)(lds + P3D_LDS_B1P + h * 16);
         f32x4 q0 = b1p[0], q1 = b1p[1], q2 = b1p[2], q3 = b1p[3];
         f32x16 o = (f32x16){q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};

@@ -74,6 +74,11 @@ struct DecodeParams {
     int grid_n;
     long long grid_lo;
     float vsize, goff0, goff1, goff2;
+    // grid mode, XCD-banded tile order (0: plain order): the grid's middle axis is cut into 8 bands, one per XCD (workgroup b runs
+    // on XCD b % 8), so that an XCD keeps re-reading ITS eighth of the plane that both fast axes index — 1 MB instead of the whole
+    // 8.4 MB plane per slice of the slow axis, which no 4 MB L2 holds (measured: DESIGN.md §4.3)
+    int band_rows;      // rows of one band inside one slice of the slowest axis (grid_n / 8), 0 = off
+    int tiles_per_row;  // grid_n / 32
     P3dDecodeCfg cfg;
 };
 
@@ -86,31 +91,45 @@ P3D_DEV float p3d_fmod_pos(float a, float b) {
     return r < 0.0f ? r + b : r;
 }
 
-template <bool WANT_RGB>
+// STAGED (grid mode, density only): every wave-step first tries to park the texel boxes its 32 points touch in LDS and gathers
+// the taps from there (p3d_gather_features_staged); tiles whose taps do not fit (a tile that straddles two grid rows) take the
+// direct path.  Dynamic LDS: the MLP image + P3D_BOX_FLOATS_PER_WAVE floats per wave.
+// FASTD (P3D_FLAG_FAST_COLOR on the grid query): the tolerance-mode decoder (f16 two-term MFMA + hardware transcendentals).
+template <bool WANT_RGB, bool STAGED, bool FASTD>
 __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[P3D_LDS_MLP_FLOATS];
-    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    static_assert(!(FASTD && WANT_RGB), "the tolerance-mode point decoder is density-only");
+    extern __shared__ __attribute__((aligned(16))) float lds_alloc[];
+    // FASTD (density only) needs neither of the fp32 weight images nor the f16 colour weights: the LDS image starts at the biases
+    // (P3D_LDS_B0P) and `lds` points that many floats before the allocation, so that every P3D_LDS_* offset still applies
+    float* lds = FASTD ? lds_alloc - P3D_LDS_B0P : lds_alloc;
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FASTD, !FASTD);
+    if constexpr (FASTD) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    float* box = lds + (FASTD ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4 + (STAGED ? wave * P3D_BOX_FLOATS_PER_WAVE : 0);
+    (void)box;
     P3dPlaneGeom g;
     g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
     g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
-    // grid-stride over tiles of 32 points; a tile never straddles two images
-    for (long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave; tile < p.ntiles;
-         tile += (long long)gridDim.x * P3D_WAVES_PER_WG) {
+    const long long stride = (long long)gridDim.x * P3D_WAVES_PER_WG;
+
+    // everything a tile needs before its decode: sample position, flags, plane resource
+    struct Tile {
+        long long n, m;
+        bool active, skip, any;
+        float px, py, pz;
+    };
+    auto setup = [&](long long tile, Tile& t) {
         long long n = 0, tl = tile;
         if (p.tiles_per_img != p.ntiles) { n = tile / p.tiles_per_img; tl = tile - n * p.tiles_per_img; }  // uniform; 1 image: no 64-bit division
-        long long m = tl * 32 + j;
-        bool active = m < p.M;
-        long long mc = active ? m : p.M - 1;
-        unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
-        const float* base = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
-        auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
-        float px, py, pz;
-        bool skip = false;
+        t.n = n;
+        t.m = tl * 32 + j;
+        t.active = t.m < p.M;
+        const long long mc = t.active ? t.m : p.M - 1;
+        t.skip = false;
         if (p.coords) {
             const float* c = p.coords + ((size_t)n * p.M + mc) * 3;
-            px = c[0]; py = c[1]; pz = c[2];
+            t.px = c[0]; t.py = c[1]; t.pz = c[2];
         } else {  // the same float arithmetic as the reference's create_samples (float division: fractional carries are kept)
             // idx < grid_n^3 <= 2^31 (the host checks grid_n <= 1290): 32-bit index arithmetic; (float)idx rounds like torch's
             const unsigned idx = (unsigned)(p.grid_lo + mc);
@@ -119,25 +138,26 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
             const float q1 = f / fn;
             const float s1 = p3d_fmod_pos(q1, fn);
             const float s0 = p3d_fmod_pos(q1 / fn, fn);
-            px = s0 * p.vsize + p.goff0; py = s1 * p.vsize + p.goff1; pz = s2 * p.vsize + p.goff2;
+            t.px = s0 * p.vsize + p.goff0; t.py = s1 * p.vsize + p.goff1; t.pz = s2 * p.vsize + p.goff2;
             if (p.out_cropmask) {
-                const bool cropped = __builtin_fabsf(px) > p.mask_limit || __builtin_fabsf(pz) > p.mask_limit;
-                if (active && h == 0) p.out_cropmask[m] = cropped ? 1 : 0;
-                if (p.cfg.flags & P3D_FLAG_SKIP_CROPPED) skip = cropped;
+                const bool cropped = __builtin_fabsf(t.px) > p.mask_limit || __builtin_fabsf(t.pz) > p.mask_limit;
+                if (t.active && h == 0) p.out_cropmask[t.m] = cropped ? 1 : 0;
+                if (p.cfg.flags & P3D_FLAG_SKIP_CROPPED) t.skip = cropped;
             }
         }
-        float sigma;
-        f32x16 rgb;
         // P3D_FLAG_SKIP_CROPPED (grid mode): a cropped point's density is -1000 whatever the network says
         // (eg3d_metrics3d.py:155-159), so it is not decoded: whole wavefronts are skipped, single lanes fetch nothing
-        if (__builtin_amdgcn_ballot_w64(active && !skip) == 0) {
-            if (active && h == 0) p.out_sigma[(size_t)n * p.M + m] = -1000.0f;
-            continue;
-        }
-        p3d_decode_wave<WANT_RGB>(lds, rs, g, p.cfg, px, py, pz, sigma, rgb, !skip);
-        if (skip) sigma = -1000.0f;
-        if (active) {
-            size_t o = (size_t)n * p.M + m;
+        t.any = __builtin_amdgcn_ballot_w64(t.active && !t.skip) != 0;
+    };
+    auto resource = [&](long long n) {
+        const unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
+        const float* base = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 3 * g.plane_bytes, 0x00020000);
+    };
+    auto finish = [&](const Tile& t, float sigma, const f32x16& rgb) {
+        if (t.skip) sigma = -1000.0f;
+        if (t.active) {
+            const size_t o = (size_t)t.n * p.M + t.m;
             if (h == 0) p.out_sigma[o] = sigma;
             if (WANT_RGB) {
                 float* dst = p.out_rgb + o * 32 + 4 * h;
@@ -145,6 +165,75 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
                 for (int q = 0; q < 4; ++q)
                     *(f32x4*)(dst + 8 * q) = (f32x4){rgb[4 * q], rgb[4 * q + 1], rgb[4 * q + 2], rgb[4 * q + 3]};
             }
+        }
+    };
+
+    // grid-stride over tiles of 32 points; a tile never straddles two images
+    long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave;
+    if constexpr (!STAGED) {
+        if (p.band_rows > 0) {  // XCD-banded order: this workgroup's XCD owns band (blockIdx.x & 7) of every slice
+            const int xcd = blockIdx.x & 7;
+            const long long per_xcd = p.ntiles >> 3, tiles_per_band = (long long)p.band_rows * p.tiles_per_row;
+            const long long tiles_per_slice = 8 * tiles_per_band;
+            for (long long q = (long long)(blockIdx.x >> 3) * P3D_WAVES_PER_WG + wave; q < per_xcd; q += (long long)(gridDim.x >> 3) * P3D_WAVES_PER_WG) {
+                const long long slice = q / tiles_per_band, in_band = q - slice * tiles_per_band;
+                Tile t;
+                setup(slice * tiles_per_slice + xcd * tiles_per_band + in_band, t);
+                float sigma = -1000.0f;
+                f32x16 rgb;
+                if (t.any) {
+                    if constexpr (FASTD) p3d_decode_wave_fast<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
+                    else p3d_decode_wave<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
+                }
+                finish(t, sigma, rgb);
+            }
+            return;
+        }
+        for (; tile < p.ntiles; tile += stride) {
+            Tile t;
+            setup(tile, t);
+            float sigma = -1000.0f;
+            f32x16 rgb;
+            if (t.any) {
+                if constexpr (FASTD) p3d_decode_wave_fast<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
+                else p3d_decode_wave<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
+            }
+            finish(t, sigma, rgb);
+        }
+    } else {
+        // software pipeline: the NEXT tile's texel boxes are being loaded (into registers) while this tile is decoded
+        if (tile >= p.ntiles) return;
+        Tile cur, nxt;
+        P3dStage st;
+        setup(tile, cur);
+        bool cur_staged = cur.any && p3d_stage_plan(resource(cur.n), g, p.cfg, cur.px, cur.py, cur.pz, st);
+        for (;;) {
+            P3dBox cb[3] = {st.b[0], st.b[1], st.b[2]};
+            if (cur_staged) p3d_stage_commit(box, st);  // waits for the loads issued one iteration ago
+            const long long next = tile + stride;
+            bool nxt_staged = false;
+            if (next < p.ntiles) {
+                setup(next, nxt);
+                nxt_staged = nxt.any && p3d_stage_plan(resource(nxt.n), g, p.cfg, nxt.px, nxt.py, nxt.pz, st);
+            }
+            float sigma = -1000.0f;
+            f32x16 rgb;
+            if (cur.any) {
+                if (cur_staged) {
+                    const f32x16 X = p3d_gather_features_boxed(box, cb, g, p.cfg, cur.px, cur.py, cur.pz, !cur.skip);
+                    if constexpr (FASTD) p3d_decode_features_fast<WANT_RGB>(lds, p.cfg, X, cur.px, cur.pz, sigma, rgb);
+                    else p3d_decode_features<WANT_RGB>(lds, p.cfg, X, cur.px, cur.pz, sigma, rgb);
+                } else if constexpr (FASTD) {
+                    p3d_decode_wave_fast<WANT_RGB>(lds, resource(cur.n), g, p.cfg, cur.px, cur.py, cur.pz, sigma, rgb, !cur.skip);
+                } else {
+                    p3d_decode_wave<WANT_RGB>(lds, resource(cur.n), g, p.cfg, cur.px, cur.py, cur.pz, sigma, rgb, !cur.skip);
+                }
+            }
+            finish(cur, sigma, rgb);
+            if (next >= p.ntiles) break;
+            tile = next;
+            cur = nxt;
+            cur_staged = nxt_staged;
         }
     }
 }
@@ -1173,12 +1262,14 @@ int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const floa
     p.ntiles = p.tiles_per_img * N;
     p.cfg = make_cfg(opts);
     p.grid_n = 0; p.grid_lo = 0; p.vsize = p.goff0 = p.goff1 = p.goff2 = 0.0f; p.out_cropmask = nullptr; p.mask_limit = 0.0f;
+    p.band_rows = 0; p.tiles_per_row = 0;
     long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    const size_t lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4;
     if (out_rgb)
-        hipLaunchKernelGGL(k_decode_points<true>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_decode_points<true, false, false>), dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_decode_points<false, false, false>), dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, (hipStream_t)stream, p);
     return p3d_check_launch();
 }
 
@@ -1200,7 +1291,32 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     // multiple of the tiles per grid row: with P3D_FLAG_SKIP_CROPPED the masked ends of every row would otherwise always fall
     // on the same waves (measured: 10.7 ms instead of the expected ~7.5 at 512^3 with half of the grid masked)
     if (blocks > 256 * 16 - 1) blocks = 256 * 16 - 1;
-    hipLaunchKernelGGL(k_decode_points<false>, dim3((unsigned)blocks), dim3(P3D_WG), 0, (hipStream_t)stream, p);
+    p.band_rows = 0; p.tiles_per_row = 0;
+    const long long slice_pts = (long long)grid_n * grid_n;
+    if (!(opts->flags & P3D_FLAG_NO_XCD_BANDS) && grid_n % 32 == 0 && lo % slice_pts == 0 && (hi - lo) % slice_pts == 0 && blocks >= 64) {
+        p.band_rows = grid_n / 8;
+        p.tiles_per_row = grid_n / 32;
+        blocks = (blocks / 8) * 8 - ((opts->flags & P3D_FLAG_SKIP_CROPPED) ? 8 : 0);  // a multiple of 8 (XCD = block % 8); see the odd-count note above
+        if (blocks < 8) blocks = 8;
+    }
+    // four variants: exact / tolerance-mode decoder (P3D_FLAG_FAST_COLOR), texel boxes staged through LDS or direct gathers.
+    // Measured at 512^3: the exact decoder is ALU-bound and the direct gathers are L1-service-bound at the SAME
+    // level, so staging pays only together with the cheap decoder; it is therefore on only in the tolerance mode.
+    const bool fastd = (opts->flags & P3D_FLAG_FAST_COLOR) != 0;
+    const bool staged = fastd ? !(opts->flags & P3D_FLAG_NO_STAGING) : (opts->flags & P3D_FLAG_FORCE_STAGING) != 0;
+    if (staged) p.band_rows = 0;  // (the staged loop keeps the plain order)
+    const size_t lds_bytes = (size_t)((fastd ? P3D_LDS_FAST_FLOATS - P3D_LDS_B0P : P3D_LDS_MLP_FLOATS) + 4 +
+                                      (staged ? P3D_WAVES_PER_WG * P3D_BOX_FLOATS_PER_WAVE : 0)) * 4;
+    hipError_t e = hipSuccess;
+#define P3D_LAUNCH_GRID(SV, FV)                                                                                       \
+    do {                                                                                                              \
+        e = p3d_ensure_dynamic_lds(k_decode_points<false, SV, FV>, lds_bytes);                                        \
+        if (e == hipSuccess)                                                                                          \
+            hipLaunchKernelGGL((k_decode_points<false, SV, FV>), dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, (hipStream_t)stream, p); \
+    } while (0)
+    if (staged) { if (fastd) P3D_LAUNCH_GRID(true, true); else P3D_LAUNCH_GRID(true, false); }
+    else { if (fastd) P3D_LAUNCH_GRID(false, true); else P3D_LAUNCH_GRID(false, false); }
+    if (e != hipSuccess) return (int)e;
     return p3d_check_launch();
 }
 

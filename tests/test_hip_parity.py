@@ -426,3 +426,47 @@ def test_fast_color_flag_is_ignored_without_an_importance_pass(hip, oracle):
     b = hip.ops.render(*args, hip.ops.make_opts(inp["ro"], **inp["kw"]))
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,H,W,use_triplane,crop", [(100, 64, 96, 1, None), (64, 256, 256, 0, 0.1), (37, 33, 47, 1, 0.05), (160, 128, 128, 1, None)])
+def test_grid_density_staged_equals_direct_gather(hip, oracle, n, H, W, use_triplane, crop):
+    """The density query can stage each wave's texel boxes through LDS (p3d_stage_plan / _commit / p3d_gather_features_boxed;
+    the default with the tolerance-mode decoder, forced here with the exact one); tiles whose taps do not fit — grids whose
+    rows are not multiples of 32 points, so that tiles straddle rows — fall back to direct gathers.  Either way the results are
+    the direct path's, bit for bit (same values, same arithmetic), and the oracle's on a subset; the XCD-banded tile order
+    changes nothing either; the tolerance-mode decoder stays within 2e-5 (relative to the sigma scale) of the exact one."""
+    from panic3d_amd import volume
+    planes = T.make_planes(300 + n, 1, H, W, scale=3.0, smooth=8)
+    raw = T.make_decoder_params(301 + n, 1.0, 10.0)
+    ro = dict(T.RENDERING_KWARGS, use_triplane=use_triplane)
+    opts = hip.ops.make_opts(ro, force_sigmoid=True)
+    mlp = hip_mlp(hip, raw, 1.0)
+    pl = hip.ops.planes_to_nhwc(dev(planes))
+    bw = 0.7
+    vs, org = bw / (n - 1), -bw / 2
+    lim = None if crop is None else bw / 2 - crop
+    for lo, hi in ((0, n ** 3), (n * n * 3 + 5, n ** 3 - 7)):  # also a slab that starts / ends in the middle of a row
+        kw = dict(crop_limit=lim, skip_cropped=crop is not None)
+        a = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, staged=True, **kw)      # exact decoder, staged boxes
+        b = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, staged=False, xcd_bands=False, **kw)  # direct, plain order
+        c = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, **kw)                   # the default launch
+        f = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, fast=True, **kw)        # tolerance decoder + staging
+        f2 = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, fast=True, staged=False, **kw)
+        if crop is None:
+            a, b, c, f, f2 = (a, None), (b, None), (c, None), (f, None), (f2, None)
+        assert torch.equal(a[0], b[0]) and torch.equal(c[0], b[0]) and torch.equal(f[0], f2[0])
+        if crop is not None:
+            assert torch.equal(a[1], b[1]) and torch.equal(c[1], b[1]) and torch.equal(f[1], b[1])
+        scale = float(b[0][b[0] > -999].abs().max()) if bool((b[0] > -999).any()) else 1.0
+        assert float((f[0] - b[0]).abs().max()) <= 2e-5 * max(scale, 1.0)
+        a = a if crop is not None else a[0]
+    sig = a if crop is None else a[0]
+    idx = torch.arange(lo, hi, 61)
+    pts, _, _ = volume.create_samples(n, (0, 0, 0), bw, idx=idx)
+    osig, _ = oracle.decode(planes, pts.numpy(), oracle.prescale_mlp(*raw), bw, plane_mode=use_triplane, flags=opts.flags, density_only=True)
+    got = sig[0, (idx - lo).cuda(), 0].cpu().numpy()
+    if crop is None:
+        assert np.array_equal(got, osig[0, :, 0])
+    else:
+        cropped = ((pts[0, :, 0].abs() > np.float32(lim)) | (pts[0, :, 2].abs() > np.float32(lim))).numpy()
+        assert np.array_equal(got[~cropped], osig[0, ~cropped, 0]) and np.all(got[cropped] == -1000.0)
