@@ -53,8 +53,6 @@ extern "C" {
                                         of the call's (ray_marcher.py:49-50 takes torch.min/max over the whole batch).  For callers that
                                         batch what the reference renders as N separate calls (generate.py's view loop): the batched
                                         launch then reproduces the per-view results bit for bit, depth included. */
-#define P3D_FLAG_NO_XCD_BANDS 4096 /* p3d_grid_density_f32: plain tile order instead of one band of the grid's middle axis per XCD
-                                      (measurement / tests; results are identical) */
 #define P3D_FLAG_NO_STAGING 2048 /* p3d_grid_density_f32 with P3D_FLAG_FAST_COLOR: gather every tap straight from the planes instead of
                                     staging each wave's texel boxes through LDS (measurement / tests; same bits) */
 #define P3D_FLAG_FORCE_STAGING 8192 /* p3d_grid_density_f32 without P3D_FLAG_FAST_COLOR: stage the texel boxes through LDS although it

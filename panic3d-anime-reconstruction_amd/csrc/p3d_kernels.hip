@@ -74,11 +74,6 @@ struct DecodeParams {
     int grid_n;
     long long grid_lo;
     float vsize, goff0, goff1, goff2;
-    // grid mode, XCD-banded tile order (0: plain order): the grid's middle axis is cut into 8 bands, one per XCD (workgroup b runs
-    // on XCD b % 8), so that an XCD keeps re-reading ITS eighth of the plane that both fast axes index — 1 MB instead of the whole
-    // 8.4 MB plane per slice of the slow axis, which no 4 MB L2 holds (measured: DESIGN.md §4.3)
-    int band_rows;      // rows of one band inside one slice of the slowest axis (grid_n / 8), 0 = off
-    int tiles_per_row;  // grid_n / 32
     P3dDecodeCfg cfg;
 };
 
@@ -171,24 +166,6 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
     // grid-stride over tiles of 32 points; a tile never straddles two images
     long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave;
     if constexpr (!STAGED) {
-        if (p.band_rows > 0) {  // XCD-banded order: this workgroup's XCD owns band (blockIdx.x & 7) of every slice
-            const int xcd = blockIdx.x & 7;
-            const long long per_xcd = p.ntiles >> 3, tiles_per_band = (long long)p.band_rows * p.tiles_per_row;
-            const long long tiles_per_slice = 8 * tiles_per_band;
-            for (long long q = (long long)(blockIdx.x >> 3) * P3D_WAVES_PER_WG + wave; q < per_xcd; q += (long long)(gridDim.x >> 3) * P3D_WAVES_PER_WG) {
-                const long long slice = q / tiles_per_band, in_band = q - slice * tiles_per_band;
-                Tile t;
-                setup(slice * tiles_per_slice + xcd * tiles_per_band + in_band, t);
-                float sigma = -1000.0f;
-                f32x16 rgb;
-                if (t.any) {
-                    if constexpr (FASTD) p3d_decode_wave_fast<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
-                    else p3d_decode_wave<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
-                }
-                finish(t, sigma, rgb);
-            }
-            return;
-        }
         for (; tile < p.ntiles; tile += stride) {
             Tile t;
             setup(tile, t);
@@ -1262,7 +1239,6 @@ int p3d_triplane_decode_f32(const float* planes, int N, int H, int W, const floa
     p.ntiles = p.tiles_per_img * N;
     p.cfg = make_cfg(opts);
     p.grid_n = 0; p.grid_lo = 0; p.vsize = p.goff0 = p.goff1 = p.goff2 = 0.0f; p.out_cropmask = nullptr; p.mask_limit = 0.0f;
-    p.band_rows = 0; p.tiles_per_row = 0;
     long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
     const size_t lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4;
@@ -1291,20 +1267,11 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     // multiple of the tiles per grid row: with P3D_FLAG_SKIP_CROPPED the masked ends of every row would otherwise always fall
     // on the same waves (measured: 10.7 ms instead of the expected ~7.5 at 512^3 with half of the grid masked)
     if (blocks > 256 * 16 - 1) blocks = 256 * 16 - 1;
-    p.band_rows = 0; p.tiles_per_row = 0;
-    const long long slice_pts = (long long)grid_n * grid_n;
-    if (!(opts->flags & P3D_FLAG_NO_XCD_BANDS) && grid_n % 32 == 0 && lo % slice_pts == 0 && (hi - lo) % slice_pts == 0 && blocks >= 64) {
-        p.band_rows = grid_n / 8;
-        p.tiles_per_row = grid_n / 32;
-        blocks = (blocks / 8) * 8 - ((opts->flags & P3D_FLAG_SKIP_CROPPED) ? 8 : 0);  // a multiple of 8 (XCD = block % 8); see the odd-count note above
-        if (blocks < 8) blocks = 8;
-    }
     // four variants: exact / tolerance-mode decoder (P3D_FLAG_FAST_COLOR), texel boxes staged through LDS or direct gathers.
     // Measured at 512^3: the exact decoder is ALU-bound and the direct gathers are L1-service-bound at the SAME
     // level, so staging pays only together with the cheap decoder; it is therefore on only in the tolerance mode.
     const bool fastd = (opts->flags & P3D_FLAG_FAST_COLOR) != 0;
     const bool staged = fastd ? !(opts->flags & P3D_FLAG_NO_STAGING) : (opts->flags & P3D_FLAG_FORCE_STAGING) != 0;
-    if (staged) p.band_rows = 0;  // (the staged loop keeps the plain order)
     const size_t lds_bytes = (size_t)((fastd ? P3D_LDS_FAST_FLOATS - P3D_LDS_B0P : P3D_LDS_MLP_FLOATS) + 4 +
                                       (staged ? P3D_WAVES_PER_WG * P3D_BOX_FLOATS_PER_WAVE : 0)) * 4;
     hipError_t e = hipSuccess;

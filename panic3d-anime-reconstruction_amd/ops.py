@@ -135,15 +135,13 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     return sigma, rgb
 
 
-def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None, skip_cropped=False, staged=None, xcd_bands=True, fast=False):
+def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None, skip_cropped=False, staged=None, fast=False):
     """Density-only decode of flat indices [lo, hi) of the reference's grid_n^3 sample grid (create_samples), the points
     generated inside the kernel.  planes_nhwc [1,3,H,W,32] -> sigma [1, hi-lo, 1]; with crop_limit also the bool mask
     [1, hi-lo, 1] of triplane_crop_mask (|x| or |z| beyond the limit) evaluated on the same generated points.
     skip_cropped: do not decode masked points (sigma = -1000 there): exact for the densities, which are overwritten anyway."""
     if skip_cropped and crop_limit is not None:
         opts = _with_flag(opts, _lib.P3D_FLAG_SKIP_CROPPED)
-    if not xcd_bands:  # plain tile order (tests and measurements)
-        opts = _with_flag(opts, _lib.P3D_FLAG_NO_XCD_BANDS)
     if fast:  # tolerance-mode decoder (f16 two-term MFMA + hardware transcendentals): sigma to ~1e-6 of the exact contract
         opts = _with_flag(opts, _lib.P3D_FLAG_FAST_COLOR)
     if staged is not None:  # default: texel boxes staged through LDS with the tolerance-mode decoder, direct gathers with the exact one

@@ -38,7 +38,7 @@ def sigma2density(sigma):  # eg3d_metrics3d.py:65-69
 
 
 def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None, cull_clouds=None, lo=0, hi=None,
-                 planes=None, skip_cropped=False, **synthesis_kwargs):
+                 planes=None, skip_cropped=False, fast=False, **synthesis_kwargs):
     """sigma / density for flat grid indices [lo, hi) of the resolution^3 grid, on the device: dict(sigmas, densities)
     of shape [1, hi-lo, 1].  `planes` (NCHW [1,3,32,H,W]) skips the backbone.  skip_cropped: the points triplane_crop masks
     (about half of the grid at the released crop of 0.1) are not decoded — identical densities, their `sigmas` read -1000."""
@@ -55,7 +55,7 @@ def density_grid(G, ws, cond, resolution=256, max_batch=None, triplane_crop=None
     vs = rk["box_warp"] / (resolution - 1)
     lim = None if triplane_crop is None else rk["box_warp"] / 2 - triplane_crop
     res = ops.grid_density(nhwc, resolution, lo, hi, vs, (origin[2], origin[1], origin[0]), mlp, opts, crop_limit=lim,
-                           skip_cropped=skip_cropped)
+                           skip_cropped=skip_cropped, fast=fast)
     sig, cropmask = res if lim is not None else (res, None)
     # activation + triplane_crop_mask (renderer.py:138-149, on the sample points, applied to the DENSITIES) + cull_clouds_mask
     # (applied to the densities, sic) in one pass over the grid

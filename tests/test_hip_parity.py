@@ -433,8 +433,7 @@ def test_grid_density_staged_equals_direct_gather(hip, oracle, n, H, W, use_trip
     """The density query can stage each wave's texel boxes through LDS (p3d_stage_plan / _commit / p3d_gather_features_boxed;
     the default with the tolerance-mode decoder, forced here with the exact one); tiles whose taps do not fit — grids whose
     rows are not multiples of 32 points, so that tiles straddle rows — fall back to direct gathers.  Either way the results are
-    the direct path's, bit for bit (same values, same arithmetic), and the oracle's on a subset; the XCD-banded tile order
-    changes nothing either; the tolerance-mode decoder stays within 2e-5 (relative to the sigma scale) of the exact one."""
+    the direct path's, bit for bit (same values, same arithmetic), and the oracle's on a subset; the tolerance-mode decoder stays within 2e-5 (relative to the sigma scale) of the exact one."""
     from panic3d_amd import volume
     planes = T.make_planes(300 + n, 1, H, W, scale=3.0, smooth=8)
     raw = T.make_decoder_params(301 + n, 1.0, 10.0)
@@ -448,7 +447,7 @@ def test_grid_density_staged_equals_direct_gather(hip, oracle, n, H, W, use_trip
     for lo, hi in ((0, n ** 3), (n * n * 3 + 5, n ** 3 - 7)):  # also a slab that starts / ends in the middle of a row
         kw = dict(crop_limit=lim, skip_cropped=crop is not None)
         a = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, staged=True, **kw)      # exact decoder, staged boxes
-        b = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, staged=False, xcd_bands=False, **kw)  # direct, plain order
+        b = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, staged=False, **kw)  # direct gathers
         c = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, **kw)                   # the default launch
         f = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, fast=True, **kw)        # tolerance decoder + staging
         f2 = hip.ops.grid_density(pl, n, lo, hi, vs, (org, org, org), mlp, opts, fast=True, staged=False, **kw)

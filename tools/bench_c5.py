@@ -12,6 +12,7 @@ import numpy as np, torch, torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, default=512)
 ap.add_argument("--crop", type=float, default=None, help="triplane_crop (generate.py uses 0.1): masked points are not decoded")
+ap.add_argument("--fast", action="store_true", help="tolerance-mode density decoder + LDS-staged texel boxes (opt-in)")
 ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered sigma grid (must not depend on the world size)")
 a = ap.parse_args()
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -38,9 +39,9 @@ LAST = {}
 
 def run():
     if a.crop is None:
-        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts), None
+        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts, fast=a.fast), None
     else:
-        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts, crop_limit=0.35 - a.crop, skip_cropped=True)
+        sig, msk = ops.grid_density(nhwc, N, lo * N * N, hi * N * N, vs, (org, org, org), mlp, opts, crop_limit=0.35 - a.crop, skip_cropped=True, fast=a.fast)
     full = sharding.gather_frames(sig.reshape(hi - lo, N * N), counts, 0)
     fmsk = None if msk is None else sharding.gather_frames(msk.view(torch.uint8).reshape(hi - lo, N * N), counts, 0)
     if rank != 0:
@@ -65,7 +66,7 @@ for _ in range(K):
 t1 = sync()
 if rank == 0:
     dt = (t1 - t0) / K
-    res = {"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "triplane_crop": a.crop, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
+    res = {"config": "c5", "grid": N, "points": N ** 3, "n_gpus": world, "triplane_crop": a.crop, "tolerance_mode": a.fast, "seconds": dt, "Gpoints_per_s": N ** 3 / dt / 1e9,
            "verts": int(out[0].shape[0]), "faces": int(out[1].shape[0])}
     if a.check:
         import hashlib

@@ -10,8 +10,8 @@ mlp = ops.prescale_mlp(*(torch.from_numpy(x).to(dev) for x in raw), 1 / np.sqrt(
 opts = ops.make_opts(dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=48, use_triplane=1), force_sigmoid=True)
 nhwc = ops.planes_to_nhwc(torch.from_numpy(planes_np).to(dev))
 vs, org = 0.7 / (N - 1), -0.35
-for staged, bands, fast in ((False, True, False), (True, False, False), (False, True, True), (True, False, True)):
-    f = lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts, staged=staged, xcd_bands=bands, fast=fast)
+for staged, fast in ((False, False), (True, False), (False, True), (True, True)):
+    f = lambda: ops.grid_density(nhwc, N, 0, N ** 3, vs, (org, org, org), mlp, opts, staged=staged, fast=fast)
     for _ in range(2): s = f()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(5): s = f()
