@@ -217,6 +217,24 @@ int p3d_bias_act_f32(const float* x, const float* b, int64_t outer, int C, int64
 int p3d_sigma2density_f32(const float* sigma, const unsigned char* cropmask, int64_t M, float cull_thresh, float* out_density,
                           void* stream);
 
+/* ---- front-view paste --------------------------------------------------------------------------------- */
+
+/* paste_front (training/triplane.py:607-691, mode 'default', front_weight_erosion = 0, force_image = None — what
+ * _scripts/eval/generate.py:55-66 uses) in ONE launch: the four masks (bilinear / nearest F.interpolate to the illustration's
+ * size, kornia.filters.sobel restated, thresholds), sample_orthofront's grid_sample of the illustration (:555-564) and the final
+ * torch.lerp.  Render-resolution inputs [N][.][r][r]: weights (image_weights), xyz (image_xyz), occ (image_weights of the
+ * front-occlusion pass, :565-578), rays_o / rays_d (x['force_rays']); front [N or 1][3][S][S] (cond['image_ortho_front'], in [0,1];
+ * front_shared != 0: one illustration for all N views), image [N][3][S][S] (the super-resolved image).  Outputs at [N][.][S][S]:
+ * out_image [3] (= torch.lerp(image, paste, mask)), out_paste [3], out_mask, out_mask_weights, out_mask_edges, out_mask_occ,
+ * out_mask_dxyz [1].  out_image may alias image. */
+typedef struct {
+    const float *weights, *xyz, *occ, *rays_o, *rays_d, *front, *image;
+    float *out_image, *out_paste, *out_mask, *out_mask_weights, *out_mask_edges, *out_mask_occ, *out_mask_dxyz;
+    int32_t N, r, S, front_shared, normalize_images;
+    float thresh_weight, thresh_edges, thresh_occ, thresh_dxyz, box_warp;
+} p3d_paste_args;
+int p3d_paste_front_f32(const p3d_paste_args* args, void* stream);
+
 /* ---- iso-surface of the density grid on the device ---------------------------------------------------- */
 
 /* Replaces skimage.measure.marching_cubes(vol, level, spacing=(1,1,1), gradient_direction='descent', method='lewiner') as

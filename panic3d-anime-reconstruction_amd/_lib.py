@@ -27,6 +27,14 @@ class Dumps(C.Structure):
                 ("sigma_sorted", C.c_void_p), ("depth_unclamped", C.c_void_p), ("tminmax", C.c_void_p)]
 
 
+class PasteArgs(C.Structure):
+    """p3d_paste_args"""
+    _fields_ = [(n, C.c_void_p) for n in ("weights", "xyz", "occ", "rays_o", "rays_d", "front", "image", "out_image", "out_paste",
+                                          "out_mask", "out_mask_weights", "out_mask_edges", "out_mask_occ", "out_mask_dxyz")] + \
+               [(n, C.c_int32) for n in ("N", "r", "S", "front_shared", "normalize_images")] + \
+               [(n, C.c_float) for n in ("thresh_weight", "thresh_edges", "thresh_occ", "thresh_dxyz", "box_warp")]
+
+
 # symbol -> (restype, argtypes); every function include/panic3d_hip.h declares
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -54,6 +62,7 @@ SIGNATURES = {
     "p3d_mc_workspace_bytes": (_Z, [_I]),
     "p3d_mc_count_f32": (_I, [_P, _I, _I, _F, _P, _Z, _P, _P]),
     "p3d_mc_emit_f32": (_I, [_P, _I, _I, _F, _P, _Z, _L, _L, _P, _P, _P, _P, _P]),
+    "p3d_paste_front_f32": (_I, [C.POINTER(PasteArgs), _P]),
     "p3d_build_info": (C.c_char_p, []),
     "p3d_abi_version": (_I, []),
 }

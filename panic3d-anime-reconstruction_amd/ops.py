@@ -310,6 +310,32 @@ def composite(colors, densities, depths, white_back=True):
     return rgb, depth, w
 
 
+def paste_front(weights, xyz, occ, rays_o, rays_d, front, image, thresh_weight, thresh_edges, thresh_occ, thresh_dxyz, box_warp,
+                normalize_images):
+    """paste_front's masks + illustration sampling + lerp in one launch (p3d_paste_front_f32; training/triplane.py:607-691).
+    weights / occ [N,1,r,r], xyz / rays_o / rays_d [N,3,r,r], front [N or 1,3,S,S], image [N,3,S,S] ->
+    dict(image, paste, mask, mask_weights, mask_edges, mask_occ, mask_dxyz) at S x S."""
+    weights, xyz, occ = _chk(weights, "weights"), _chk(xyz, "xyz"), _chk(occ, "occ")
+    rays_o, rays_d, front, image = _chk(rays_o, "rays_o"), _chk(rays_d, "rays_d"), _chk(front, "front"), _chk(image, "image")
+    N, _, r, r2 = xyz.shape
+    S = image.shape[-1]
+    if (r != r2 or tuple(weights.shape) != (N, 1, r, r) or tuple(occ.shape) != (N, 1, r, r) or tuple(rays_o.shape) != (N, 3, r, r)
+            or tuple(rays_d.shape) != (N, 3, r, r) or tuple(image.shape) != (N, 3, S, S) or front.shape[0] not in (1, N)
+            or tuple(front.shape[1:]) != (3, S, S)):
+        raise RuntimeError("paste_front: weights/occ [N,1,r,r], xyz/rays [N,3,r,r], front [N|1,3,S,S], image [N,3,S,S]")
+    dev = image.device
+    new = lambda c: torch.empty((N, c, S, S), dtype=torch.float32, device=dev)
+    out = dict(image=new(3), paste=new(3), mask=new(1), mask_weights=new(1), mask_edges=new(1), mask_occ=new(1), mask_dxyz=new(1))
+    a = _lib.PasteArgs(_p(weights).value, _p(xyz).value, _p(occ).value, _p(rays_o).value, _p(rays_d).value, _p(front).value,
+                       _p(image).value, *[_p(out[k]).value for k in ("image", "paste", "mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz")],
+                       N, r, S, int(front.shape[0] == 1 and N > 1), int(bool(normalize_images)),
+                       np.float32(thresh_weight), np.float32(thresh_edges), np.float32(thresh_occ), np.float32(thresh_dxyz), np.float32(box_warp))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().p3d_paste_front_f32(C.byref(a), _stream())
+    _lib.check(rc, "p3d_paste_front_f32")
+    return out
+
+
 def depth_minmax(depths):
     """torch.min(depths), torch.max(depths) of ray_marcher.py:50 as one op -> float32 tensor [2] on the device."""
     depths = _chk(depths, "depths")

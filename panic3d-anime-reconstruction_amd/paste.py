@@ -1,12 +1,16 @@
 """`paste_front` — the front-view paste post-process of TriPlaneGenerator.f (training/triplane.py:553-691): where the
 rendered surface is visible from the orthographic front view, the super-resolved colour is replaced by the input
-illustration sampled at the rendered xyz.  Host glue on device tensors (bilinear resizes, Sobel, grid_sample, lerp) plus
-ONE extra pass through the fused renderer for the front-occlusion test (rays from the rendered surface points towards
-the front plane, triplane.py:565-578).
+illustration sampled at the rendered xyz.  Two launches: ONE extra pass through the fused renderer for the front-occlusion
+test (rays from the rendered surface points towards the front plane, triplane.py:565-578), then ONE fused kernel
+(`ops.paste_front` -> p3d_paste_front_f32, csrc/p3d_paste.hip) for the four masks, the sampling of the illustration and the
+lerp — the reference runs three bilinear resizes, a Sobel, a nearest resize, a grid_sample and a lerp over 512^2 x N pixels.
 
-kornia is not a dependency: `sobel_magnitude` restates kornia 0.6.5 `kornia.filters.sobel(x, normalized=True, eps=1e-6)`
-(3x3 Sobel kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + eps)).  `front_weight_erosion >= 1`
-(kornia.morphology.erosion; not used by _scripts/eval/generate.py:55-66) is not mirrored.
+kornia is not a dependency: the kernel restates kornia 0.6.5 `kornia.filters.sobel(x, normalized=True, eps=1e-6)` (3x3
+Sobel kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + eps)) — "parity unpinned": kornia cannot be installed here
+(profiles/r02_notes.txt; tests/golden/make_golden_mesh.py generates the pin where it can).  `front_weight_erosion >= 1`
+(kornia.morphology.erosion; not used by _scripts/eval/generate.py:55-66) is not mirrored.  `sobel_magnitude`,
+`sample_orthofront` and `xyz_discrepancy` below are the torch formulation of the same steps, kept as the kernel's reference
+in tests/ (`paste_front_torch`).
 """
 import torch
 import torch.nn.functional as F
@@ -60,6 +64,23 @@ def xyz_discrepancy(xyz, rays):
 
 def paste_front(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02, thresh_occ=0.05, offset_occ=0.01,
                 thresh_dxyz=0.01, front_weight_erosion=0, grad_sample=False, force_image=None, **kwargs):
+    """training/triplane.py:607-691 on the fused kernel; same arguments and return keys."""
+    from . import ops
+    if front_weight_erosion >= 1 or force_image is not None:
+        raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
+    with torch.no_grad():
+        occ = front_occlusion(G, x, out, offset=offset_occ)
+        res = ops.paste_front(out["image_weights"], out["image_xyz"], occ, x["force_rays"]["ray_origins"], x["force_rays"]["ray_directions"],
+                              x["cond"]["image_ortho_front"], out["image"], thresh_weight, thresh_edges, thresh_occ, thresh_dxyz,
+                              G.rendering_kwargs["box_warp"], x["normalize_images"])
+    return {"image": res["image"], "paste": res["paste"], "mask": res["mask"], "mask_weights": res["mask_weights"],
+            "mask_edges": res["mask_edges"], "mask_occ": res["mask_occ"], "mask_dxyz": res["mask_dxyz"],
+            "mask_frontweight": torch.ones_like(res["mask_dxyz"]), "frontweight": None}
+
+
+def paste_front_torch(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02, thresh_occ=0.05, offset_occ=0.01,
+                      thresh_dxyz=0.01, front_weight_erosion=0, grad_sample=False, force_image=None, **kwargs):
+    """The same post-process as a composition of torch ops (the reference's own formulation): the comparator of the fused kernel."""
     if front_weight_erosion >= 1 or force_image is not None:
         raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
     view_xyz = out["image_xyz"]

@@ -212,6 +212,43 @@ def test_paste_front_vs_reference(hip):
     assert np.abs(sub(out["image"]) - g["paste_image_sub4"]).mean() < 5e-3
 
 
+def test_paste_front_fused_kernel_vs_torch_formulation(hip):
+    """p3d_paste_front_f32 (one launch) against the same post-process written as the reference writes it — torch resizes,
+    Sobel on shifted slices, grid_sample, lerp (paste.paste_front_torch): masks identical except for pixels whose value sits
+    on a threshold (< 0.1 %), paste / image to fp32 round-off.  Perspective and orthographic view, one and three views."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    from panic3d_amd import paste
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    gen = torch.Generator().manual_seed(21)
+    front = torch.rand(1, 3, 512, 512, generator=gen).cuda()
+    pp = {"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5, "offset_occ": 0.01, "thresh_dxyz": 0.05}
+    for res, el, az, fv in ((16, [0.0], [0.0], [-1.0]), (32, [5.0], [30.0], [30.0])):
+        R, S = res * res, 12
+        draws = [(torch.rand(1, R, S, 1, generator=gen).cuda(), torch.rand(R, S, generator=gen).cuda()) for _ in range(2)]
+        x = dict(elevations=torch.tensor(el).cuda(), azimuths=torch.tensor(az).cuda(), fovs=torch.tensor(fv).cuda(), seeds=[3],
+                 cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=res,
+                 noise_mode="const", paste_params=pp)
+        with torch.no_grad():
+            G._inject_draws = [tuple(d) for d in draws]
+            out = G.f(x)
+            ret = {k: out[k] for k in ("image_raw", "image_depth", "image_weights", "triplane", "image_xyz", "normalize_images")}
+            ret["image"] = out["image_prepaste"]
+            G._inject_draws = [tuple(draws[1])]  # the occlusion pass of the comparator consumes the same draws
+            ref = paste.paste_front_torch(G, x, ret, **pp)
+        fused = out["paste"]
+        assert 0.005 < float(ref["mask"].mean()) < 0.995
+        for k in ("mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz"):
+            assert fused[k].shape == ref[k].shape
+            assert float(((fused[k] - ref[k]).abs() > 1e-4).float().mean()) < 1e-3, k
+        same = (fused["mask"] - ref["mask"]).abs() <= 1e-4
+        # the illustration is white noise (gradient ~1 per texel) sampled at coordinates near 512, whose fp32 spacing is 6e-5
+        assert float((fused["paste"] - ref["paste"]).abs().max()) < 2e-4 and float((fused["paste"] - ref["paste"]).abs().mean()) < 1e-5
+        assert float(((fused["image"] - ref["image"]).abs() * same).max()) < 2e-4
+    G._inject_draws = None
+
+
 def test_density_grid(hip):
     """volume.density_grid == get_eg3d_volume's loop (sample_mixed per chunk + sigma2density + crop/cull on densities)."""
     from panic3d_amd.generator import TriPlaneGenerator
