@@ -127,9 +127,11 @@ P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t
     off[3] = (vx1 && vy1) ? base + row + 128u : P3D_OOB_OFFSET;
 }
 
-// The lane's 64 B of one tap as four 16-B loads.  (Rotating the 16-B slot by the quad index — which removes the L1 slot
-// conflicts a micro-benchmark shows, tools/ubench/l1_gather.hip — was measured in the kernel and does not pay: the gathers
-// are not what the kernel waits on; profiles/r02_notes.txt.)
+// The lane's 64 B of one tap as four 16-B loads.  (Rotating the 16-B slot by the quad index removes the L1 slot conflicts
+// and makes this very access pattern 1.75x faster in a micro-benchmark that keeps 32 waves per CU gathering
+// (tools/ubench/l1_gather_real.hip: 53.8 -> 30.8 clk per instruction); in the kernel — 8 waves per CU, <= 16 loads in flight
+// each — it was measured twice and changes nothing: the kernel waits on the LATENCY of its gathers, not on the L1's
+// throughput; profiles/r02_notes.txt.)
 template <typename RSRC>
 P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
     f32x16 v;

@@ -560,7 +560,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             }
             if (early) {
                 while (!done) {
-                    if (st.Td < 1e-60) { done = true; break; }
+                    // exact mode: below 1e-60 every later weight alpha * (float)Td is exactly 0.  Tolerance mode: the transmittance
+                    // bounds everything the rest of the ray can still add (sum of the remaining weights <= Td): stop at 2e-6,
+                    // i.e. <= 4e-6 on a colour, <= 6e-6 on depth / weight sum — early ray termination, inside the 2e-5 budget
+                    if (st.Td < (FAST ? 2e-6 : 1e-60)) { done = true; break; }
                     const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
                     const float t = take_c ? ta : tb;
                     bool known = is_cropped(t);
