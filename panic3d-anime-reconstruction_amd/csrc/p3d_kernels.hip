@@ -401,6 +401,9 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
     float* wcA = tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
     float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;  // [Sf] sorted fine depths
     uint32_t* mkA = (uint32_t*)(wl + (size_t)(p.lds_rows - ((Sc + 31) >> 5)) * 32);  // [ceil(Sc/32)] known-masked bits of the coarse samples
+    const int nmw = (S + 31) >> 5;                         // words of a bit row over the merged list
+    uint32_t* knA = mkA - (size_t)2 * nmw * 32;            // [ceil(S/32)] merged sample q: sigma = -1000 known without a decode
+    uint32_t* slA = knA + (size_t)nmw * 32;                // [ceil(S/32)] merged sample q comes from the coarse list
     const bool dump = DUMP && active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
@@ -526,6 +529,9 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
     // masked) while the previous sample's sigma is <= 602: the interval's softplus argument is then <= -200, rho = alpha = w = 0
     // and Td * (double)(1.0f + 1e-10f) = Td, i.e. the marcher update is exactly the identity (include/p3d_numerics.h); only
     // prev_t / prev_sigma move.  A dead ray (Td < 1e-60: every later weight is exactly 0) drops all its remaining samples.
+    // The merge itself runs ONCE, ahead of the walk, as a uniform loop that leaves two bit rows per lane in LDS (merged sample q
+    // is coarse / is known); the walk then jumps over a whole run of known samples with a count-trailing-ones — consuming them
+    // one at a time was a chain of two LDS round trips per sample and a quarter of the kernel (profiles/r02_notes.txt).
     // What is left — the samples that can matter — is decoded one per wave-step until every lane has finished, so a tile of
     // rays that miss the subject runs ~Sf/2 steps instead of Sc + Sf.  A consumed sample's colour is fetched after all if one
     // of its interval weights turns out non-zero (sigma of a neighbour >= ~794): results are bit-identical by construction.
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
         tmin = __builtin_fminf(tcmin, tb);
         tmax = __builtin_fmaxf(tcmax, (Sf > 0) ? tfA[(Sf - 1) * 32 + j] : -__builtin_inff());
         bool prev_skipped = false, first = true, done = false;
-        int m = 0;  // samples of this lane consumed so far (dump index)
+        int m = 0;  // samples of this lane consumed so far (position in the merged list)
         auto is_cropped = [&](float t) {
             const float px = ox + t * dx, pz = oz + t * dz;
             return f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
@@ -552,42 +558,72 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             fi += take_c ? 0 : 1;
             if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
             else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
-            done = (ci >= Sc) && (fi >= Sf);
         };
-        for (int it = 0;; ++it) {
-            if constexpr (!EARLY) {
-                if (it >= S) break;  // every lane takes exactly one sample per step: the plain uniform loop
-            }
-            if (early) {
-                while (!done) {
-                    // exact mode: below 1e-60 every later weight alpha * (float)Td is exactly 0.  Tolerance mode: the transmittance
-                    // bounds everything the rest of the ray can still add (sum of the remaining weights <= Td): stop at 2e-6,
-                    // i.e. <= 4e-6 on a colour, <= 6e-6 on depth / weight sum — early ray termination, inside the 2e-5 budget
-                    if (st.Td < (FAST ? 2e-6 : 1e-60)) { done = true; break; }
-                    const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
-                    const float t = take_c ? ta : tb;
-                    bool known = is_cropped(t);
-                    if (!known && take_c && Sf > 0) known = (mkA[(ci >> 5) * 32 + j] >> (ci & 31)) & 1u;  // Sf == 0: no coarse pass ran
-                    if (!(known && (first || st.prev_sigma <= 602.0f))) break;
-                    advance(take_c);
-                    st.prev_t = t; st.prev_sigma = P3D_SIGMA_MASKED;
-                    prev_skipped = true; first = false;
-                    ++m;
+        if constexpr (EARLY) {
+            // the merge, once: bit q of slA = merged sample q is the head of the coarse list, bit q of knA = its sigma is known
+            uint32_t kw = 0u, sw = 0u;
+            for (int q = 0; q < S; ++q) {
+                const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+                bool known = is_cropped(take_c ? ta : tb);
+                if (take_c && Sf > 0) known = known || ((mkA[(ci >> 5) * 32 + j] >> (ci & 31)) & 1u);  // Sf == 0: no coarse pass ran
+                kw |= known ? (1u << (q & 31)) : 0u;
+                sw |= take_c ? (1u << (q & 31)) : 0u;
+                advance(take_c);
+                if ((q & 31) == 31 || q == S - 1) {
+                    knA[(q >> 5) * 32 + j] = kw; slA[(q >> 5) * 32 + j] = sw;
+                    kw = 0u; sw = 0u;
                 }
             }
-            if constexpr (EARLY) {
+            ci = 0;  // from here on: coarse samples among the first m merged ones (the fine index is m - ci)
+        }
+        for (int it = 0;; ++it) {
+            bool take_c, known = false;  // known: sigma = -1000 without a decode (reached here only behind a sigma > 602)
+            float t;
+            if constexpr (!EARLY) {
+                if (it >= S) break;  // every lane takes exactly one sample per step: the plain uniform loop
+                take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+                t = take_c ? ta : tb;
+                advance(take_c);
+            } else {
+                // exact mode: below 1e-60 every later weight alpha * (float)Td is exactly 0.  Tolerance mode: the transmittance
+                // bounds everything the rest of the ray can still add (sum of the remaining weights <= Td): stop at 2e-6,
+                // i.e. <= 4e-6 on a colour, <= 6e-6 on depth / weight sum — early ray termination, inside the 2e-5 budget
+                if (!done && st.Td < (FAST ? 2e-6 : 1e-60)) done = true;
+                if (!done && (first || st.prev_sigma <= 602.0f)) {
+                    // jump over the run of known samples that starts at m (one iteration per 32-bit word the run touches)
+                    bool any = false, last_c = false;
+                    while (m < S) {
+                        const int sh = m & 31, left = (32 - sh < S - m) ? 32 - sh : S - m;
+                        const uint32_t kw = knA[(m >> 5) * 32 + j] >> sh, sw = slA[(m >> 5) * 32 + j] >> sh;
+                        int run = (~kw != 0u) ? __builtin_ctz(~kw) : 32;
+                        run = run < left ? run : left;
+                        if (run > 0) {
+                            const uint32_t inrun = run >= 32 ? 0xffffffffu : ((1u << run) - 1u);
+                            ci += __builtin_popcount(sw & inrun);
+                            last_c = (sw >> (run - 1)) & 1u;
+                            any = true;
+                            m += run;
+                        }
+                        if (run < left) break;  // stopped in front of a sample that has to be decoded
+                    }
+                    if (any) {
+                        st.prev_t = last_c ? tcA[(ci - 1) * 32 + j] : tfA[(m - ci - 1) * 32 + j];
+                        st.prev_sigma = P3D_SIGMA_MASKED;
+                        prev_skipped = true; first = false;
+                    }
+                    done = m >= S;
+                }
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+                const int mm = done ? S - 1 : m;  // finished lanes: any valid address
+                const uint32_t kb = knA[(mm >> 5) * 32 + j] >> (mm & 31), sb = slA[(mm >> 5) * 32 + j] >> (mm & 31);
+                take_c = (sb & 1u) != 0u;
+                known = !done && (kb & 1u) != 0u;
+                const int cq = ci < Sc ? ci : Sc - 1, fq = (m - ci < Sf) ? m - ci : (Sf > 0 ? Sf - 1 : 0);
+                t = (take_c || Sf == 0) ? tcA[cq * 32 + j] : tfA[fq * 32 + j];
+                if (!done) { ++m; ci += take_c ? 1 : 0; }
             }
             const bool have = EARLY ? !done : true;
-            const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
-            const float t = take_c ? ta : tb;
             const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
-            bool known = false;  // sigma = -1000 known without a decode (reached here only behind a sigma > 602)
-            if (early && have) {
-                known = is_cropped(t);
-                if (!known && take_c && Sf > 0) known = (mkA[(ci >> 5) * 32 + j] >> (ci & 31)) & 1u;  // Sf == 0: no coarse pass ran
-            }
-            if (have) advance(take_c);
             float sigma = P3D_SIGMA_MASKED;
             f32x16 rgb;
 #pragma unroll
@@ -640,7 +676,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
                 prev_rgb = rgb;
                 prev_skipped = skipped;
                 first = false;
-                ++m;
+                if constexpr (!EARLY) ++m;
             }
         }
     }
@@ -1332,7 +1368,8 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     p.ntiles = p.tiles_per_img * N;
     // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
     const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
-    p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0) + ((Sc + 31) >> 5);  // + the known-masked bits of the coarse samples
+    // + two bit rows over the merged list (is-coarse / known-masked) + the known-masked bits of the coarse samples
+    p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0) + 2 * ((Sc + Sf + 31) >> 5) + ((Sc + 31) >> 5);
     int nwaves = P3D_RENDER_WAVES;
     // small ray counts (e.g. the pipeline's 128^2 rays = 512 tiles): shrink the workgroup so that every CU gets work
     while (nwaves > 1 && p.ntiles / nwaves < 2 * 256) nwaves >>= 1;
