@@ -556,8 +556,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
         auto advance = [&](bool take_c) {  // pop the head of the coarse or of the fine list
             ci += take_c ? 1 : 0;
             fi += take_c ? 0 : 1;
-            if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + j];
-            else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + j];
+            // (one LDS read at a selected address and two selects: `if (take_c) ta = ...; else tb = ...;` is turned into a store
+            // through a selected POINTER, which parks ta / tb in scratch memory — 1.5-3 k clocks per merged sample)
+            const int cq = ci < Sc ? ci : Sc - 1, fq = fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0);
+            const float nv = (take_c ? tcA : tfA)[(take_c ? cq : fq) * 32 + j];
+            ta = take_c ? nv : ta;
+            tb = take_c ? tb : nv;
         };
         if constexpr (EARLY) {
             // the merge, once: bit q of slA = merged sample q is the head of the coarse list, bit q of knA = its sigma is known
@@ -896,8 +900,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             const float t = take_c ? ta : tb;
             ci += take_c ? 1 : 0;
             fi += take_c ? 0 : 1;
-            if (take_c) ta = tcA[(ci < Sc ? ci : Sc - 1) * 32 + jr];
-            else tb = tfA[(fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0)) * 32 + jr];
+            const int cq = ci < Sc ? ci : Sc - 1, fq = fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0);
+            const float nv = (take_c ? tcA : tfA)[(take_c ? cq : fq) * 32 + jr];  // (selects, not a store through a selected pointer)
+            ta = take_c ? nv : ta;
+            tb = take_c ? tb : nv;
             tmin = __builtin_fminf(tmin, t);
             tmax = __builtin_fmaxf(tmax, t);
             return t;
