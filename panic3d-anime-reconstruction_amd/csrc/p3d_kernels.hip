@@ -325,6 +325,42 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
     return bb + ((ui - cb) / den) * (ba - bb);
 }
 
+// B independent draws at once: the same arithmetic as p3d_inverse_cdf, with the B LDS reads of every search step in flight
+// together (one draw is a chain of 8 dependent LDS round trips; 48 of them back to back were ~9 % of k_render).
+template <int B>
+P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, int j, const float (&ui)[B], float (&out)[B], int (&k_out)[B]) {
+    const int n = Ns + 1;
+    int pos[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) pos[q] = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        if (step <= n) {  // wave-uniform
+            float c[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) c[q] = cdfA[((pos[q] + step <= n) ? pos[q] + step - 1 : 0) * 32 + j];
+#pragma unroll
+            for (int q = 0; q < B; ++q) pos[q] = ((pos[q] + step <= n) && (c[q] <= ui[q])) ? pos[q] + step : pos[q];
+        }
+    }
+    float cb[B], ca[B], t0[B], t1[B], t2[B], t3[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+        const int k = pos[q], below = k - 1 > 0 ? k - 1 : 0, above = k < Ns ? k : Ns;
+        k_out[q] = k;
+        cb[q] = cdfA[below * 32 + j]; ca[q] = cdfA[above * 32 + j];
+        t0[q] = tcA[below * 32 + j]; t1[q] = tcA[(below + 1) * 32 + j];
+        t2[q] = tcA[above * 32 + j]; t3[q] = tcA[(above + 1) * 32 + j];
+    }
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+        float den = ca[q] - cb[q];
+        if (den < 1e-5f) den = 1.0f;
+        const float bb = 0.5f * (t0[q] + t1[q]), ba = 0.5f * (t2[q] + t3[q]);
+        out[q] = bb + ((ui[q] - cb[q]) / den) * (ba - bb);
+    }
+}
+
 // NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
 // DUMP: per-stage dumps (parity tests; disables the early-outs so that every dumped density is a real decode).
 //
@@ -413,15 +449,24 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
         float prev = -__builtin_inff();
-        for (int i = 0; i < Sc; ++i) {
-            float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
-            float t = lin + jit[i] * p.depth_delta;
-            tcA[i * 32 + j] = t;
-            unsorted |= (t < prev);
-            prev = t;
-            tcmin = __builtin_fminf(tcmin, t);
-            tcmax = __builtin_fmaxf(tcmax, t);
-            if constexpr (DUMP) if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
+        for (int i0 = 0; i0 < Sc; i0 += 8) {  // eight loads of the jitter row in flight (one at a time exposed a global-load latency per sample)
+            float jv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) jv[q] = jit[i0 + q < Sc ? i0 + q : Sc - 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q;
+                if (i < Sc) {  // wave-uniform
+                    float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
+                    float t = lin + jv[q] * p.depth_delta;
+                    tcA[i * 32 + j] = t;
+                    unsorted |= (t < prev);
+                    prev = t;
+                    tcmin = __builtin_fminf(tcmin, t);
+                    tcmax = __builtin_fmaxf(tcmax, t);
+                    if constexpr (DUMP) if (dump && p.dumps.depths_coarse) p.dumps.depths_coarse[ray * Sc + i] = t;
+                }
+            }
         }
     }
     float tmin = __builtin_inff(), tmax = -__builtin_inff();
@@ -482,19 +527,30 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             }
         }
         const float* uu = p.u + ray * Sf;
+        constexpr int DB = 8;  // draws in flight
         if constexpr (NF > 0) {
             float tf[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                tf[i] = __builtin_inff();
-                if (i < Sf) {  // wave-uniform
-                    int k;
-                    float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
-                    tf[i] = v;
-                    if constexpr (DUMP) {
-                        if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
-                        if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? uu[i] : 0.0f;  // every load of the row issued before the first search
+#pragma unroll
+            for (int i0 = 0; i0 < NF; i0 += DB) {
+                if (i0 < Sf) {  // wave-uniform
+                    float ub[DB], vb[DB];
+                    int kb[DB];
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) ub[q] = tf[i0 + q];
+                    p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, j, ub, vb, kb);
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) {
+                        tf[i0 + q] = (i0 + q < Sf) ? vb[q] : __builtin_inff();
+                        if constexpr (DUMP) {
+                            if (dump && i0 + q < Sf && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i0 + q] = vb[q];
+                            if (dump && i0 + q < Sf && p.dumps.inds) p.dumps.inds[ray * Sf + i0 + q] = kb[q];
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) tf[i0 + q] = __builtin_inff();
                 }
             }
             p3d_sort_network<NF>(tf);
@@ -502,13 +558,21 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             for (int i = 0; i < NF; ++i)
                 if (i < Sf) tfA[i * 32 + j] = tf[i];  // over the cdf rows: every search is done
         } else {
-            for (int i = 0; i < Sf; ++i) {
-                int k;
-                float v = p3d_inverse_cdf(wcA, tcA, Ns, j, uu[i], k);
-                tfA[i * 32 + j] = v;
-                if constexpr (DUMP) {
-                    if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i] = v;
-                    if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i] = k;
+            for (int i0 = 0; i0 < Sf; i0 += DB) {
+                float ub[DB], vb[DB];
+                int kb[DB];
+#pragma unroll
+                for (int q = 0; q < DB; ++q) ub[q] = uu[i0 + q < Sf ? i0 + q : Sf - 1];
+                p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, j, ub, vb, kb);
+#pragma unroll
+                for (int q = 0; q < DB; ++q) {
+                    if (i0 + q < Sf) {
+                        tfA[(i0 + q) * 32 + j] = vb[q];
+                        if constexpr (DUMP) {
+                            if (dump && p.dumps.depths_fine) p.dumps.depths_fine[ray * Sf + i0 + q] = vb[q];
+                            if (dump && p.dumps.inds) p.dumps.inds[ray * Sf + i0 + q] = kb[q];
+                        }
+                    }
                 }
             }
             p3d_lds_insertion_sort(tfA, Sf, j);
