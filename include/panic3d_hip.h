@@ -192,6 +192,20 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
                              const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two-term f16 operands: every MFMA operand is carried as hi + lo (hi = f16(v) RNE, lo = f16(v - hi)) and a product is
+ * a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, accumulated in fp32 — fp32-class results (what is dropped is ~2^-22 relative, the size of
+ * the fp32 kernel's own accumulation-order noise; measured in tests/test_hip_synthesis.py) on the f16 matrix cores: 3 MFMAs of
+ * 32 cycles per 16 channels instead of 8 of 64.  w_f16x2: 2 x [O][ks*ks][I] f16, the hi parts followed by the lo parts, made
+ * once per layer by p3d_conv_weights_to_f16x2 (16-byte aligned, O*I*ks*ks*2 bytes a multiple of 16; the weights are stored
+ * scaled by 2^6, the kernel scales s*x by 2^4 and the accumulators back by 2^-10, because the matrix cores flush f16
+ * subnormals).  Domain: |s*x| < 8188, |w| < 2047 (beyond that the operand saturates; it does not become inf).  Same arguments
+ * and semantics as p3d_modconv2d_f32 otherwise; I % 16 == 0. */
+int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream);
+int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
+                               const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
+                               const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by
  * `down`.  x [NC][H][W] -> y [NC][(H*up+pady0+pady1-fh)/down+1][(W*up+padx0+padx1-fw)/down+1]. */

@@ -40,6 +40,7 @@ struct ConvParams {
     const float* x;       // [N][I][H][W]
     const float* w;       // [O][I][ks][ks]
     const void* wh;       // f16 copy [O][ks*ks][I] (f16-operand kernels) or null
+    int wsplit;           // wh holds hi parts followed by lo parts (two-term operands)
     const float* styles;  // [N][I]
     const float* dcoef;   // [N][O] or null
     const float* noise;   // [OH*OW] (shared) or [N][OH*OW] or null; already multiplied by noise_strength
@@ -372,12 +373,25 @@ DEV ConvStagePlanH conv_plan_h(const ConvParams& p, int tid, int gy0, int gx0, i
     return s;
 }
 
-template <int NT>
-struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[(NT * 128 + 255) / 256]; };
+// SPLIT (two-term operands, p3d_modconv2d_f16x2mma_f32): every operand is carried as hi + lo, hi = f16(v) (RNE), lo = f16(v - hi),
+// and a product is a_hi*b_hi + a_lo*b_hi + a_hi*b_lo with fp32 accumulation: the dropped a_lo*b_lo term and the rounding of lo are
+// ~2^-22 relative, i.e. fp32-class results at 3 f16 MFMAs (96 cycles per 16 channels) instead of 8 f32 ones (512 cycles).
+// The weight tensor then holds the hi parts followed by the lo parts (k_weights_to_f16 with split = 1); LDS keeps the lo images
+// behind the hi ones, and the weights single-buffered (hi + lo of a chunk are 36 KB for 3x3: two workgroups per CU still fit).
+// The matrix cores flush f16 subnormals, so the operands are scaled by a power of two before they are split — the weights by
+// 2^6 (lo parts of |w| >= 2^-8 stay normal), the modulated activations s*x by 2^4 (|s*x| >= 2^-6; more headroom at the top:
+// hi + lo saturate, they do not overflow, at |s*x| = 2 * 65504 / 16 = 8188) — and the accumulators are scaled back by 2^-10
+// when they are stored; all exact.  A value below those thresholds loses its lo part (absolute error <= 2^-11 |v|, i.e.
+// below 8e-6 / 2e-6): rare and small next to the 2^-22 relative rounding of the ordinary terms.
+#define HX_SPLIT_SCALE_X 16.0f
+#define HX_SPLIT_SCALE_W 64.0f
+#define HX_SPLIT_UNSCALE (1.0f / 1024.0f)
+template <int NT, bool SPLIT = false>
+struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[(NT * 128 + 255) / 256]; i32x4 wl[SPLIT ? (NT * 128 + 255) / 256 : 1]; };
 
-template <int NT>
+template <int NT, bool SPLIT = false>
 DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float* xn, const float* sn, int ic0, int ic_end,
-                      ConvStageRegsH<NT>& r) {
+                      ConvStageRegsH<NT, SPLIT>& r) {
     const int HW = p.H * p.W;
     // channels left in this split-K slice; a slice beyond the last channel (I not a multiple of the slice width) has none:
     // every load is then out of range -> zeros -> the workgroup stores a zero partial sum
@@ -396,31 +410,54 @@ DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float
     }
 #pragma unroll
     for (int u = 0; u < (NT * 128 + 255) / 256; ++u) r.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, pl.woff[u], 0, 0);
+    if constexpr (SPLIT) {  // the lo parts: a second tensor of the same shape right behind the hi parts
+        auto rl = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + ((size_t)p.O * NT * p.I + ic0) * 2), 0,
+                                                    left ? (p.O * NT * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
+#pragma unroll
+        for (int u = 0; u < (NT * 128 + 255) / 256; ++u) r.wl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl, pl.woff[u], 0, 0);
+    }
 }
 
-template <int NT>
-DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT>& r) {
+template <int NT, bool SPLIT>
+DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (pl.xdst[u] < 0) continue;
-        f16x8 v;
+        f16x8 v, l;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (_Float16)(r.s[u][i >> 2][i & 3] * r.x[u][i]);  // RNE
+        for (int i = 0; i < 8; ++i) {
+            float m = r.s[u][i >> 2][i & 3] * r.x[u][i];
+            if constexpr (SPLIT) m = __builtin_fminf(__builtin_fmaxf(m * HX_SPLIT_SCALE_X, -65504.0f), 65504.0f);
+            v[i] = (_Float16)m;  // RNE
+            if constexpr (SPLIT) l[i] = (_Float16)(m - (float)v[i]);
+        }
         *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
+        if constexpr (SPLIT) *reinterpret_cast<f16x8*>(xs + HX_BYTES + pl.xdst[u]) = l;
     }
+}
+template <int NT, bool SPLIT>
+DEV void conv_lstore_hw(char* ws, int tid, const ConvStageRegsH<NT, SPLIT>& r) {
 #pragma unroll
     for (int u = 0; u < (NT * 128 + 255) / 256; ++u) {
         const int q = tid + u * 256;
-        if (q < NT * 128) *reinterpret_cast<i32x4*>(ws + q * 16) = r.w[u];
+        if (q < NT * 128) {
+            *reinterpret_cast<i32x4*>(ws + q * 16) = r.w[u];
+            if constexpr (SPLIT) *reinterpret_cast<i32x4*>(ws + NT * 128 * 16 + q * 16) = r.wl[u];
+        }
     }
 }
+template <int NT, bool SPLIT = false>
+DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
+    conv_lstore_hx<NT, SPLIT>(xs, pl, r);
+    conv_lstore_hw<NT, SPLIT>(ws, tid, r);
+}
 
-template <int MODE>
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
     using T = ConvTaps<MODE>;
     constexpr int NT = T::N, NB = CONV_TH / 4, WBYTES = NT * 128 * 16;
-    __shared__ __attribute__((aligned(16))) char xs[2][HX_BYTES];
-    __shared__ __attribute__((aligned(16))) char ws[2][WBYTES];
+    __shared__ __attribute__((aligned(16))) char xs[2][SPLIT ? 2 * HX_BYTES : HX_BYTES];
+    __shared__ __attribute__((aligned(16))) char ws[SPLIT ? 1 : 2][SPLIT ? 2 * WBYTES : WBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
     const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
@@ -442,27 +479,41 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
     const int wlane = (half * 64 + wc * 32 + j) * 16;
 
     const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
-    ConvStageRegsH<NT> rg;
-    conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
-    conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    ConvStageRegsH<NT, SPLIT> rg;
+    conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore_h<NT, SPLIT>(xs[0], ws[0], tid, pl, rg);
     __syncthreads();
     int buf = 0;
     for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
         const bool more = ic0 + 16 < ic_end;
-        if (more) conv_gload_h<NT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        if (more) conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
-        const char* wb = ws[buf] + wlane;
+        const char* wb = ws[SPLIT ? 0 : buf] + wlane;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f16x8 av = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16);
+            f16x8 al;
+            if constexpr (SPLIT) al = *reinterpret_cast<const f16x8*>(wb + WBYTES + t * 128 * 16);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const f16x8 bv = *reinterpret_cast<const f16x8*>(xb + ((T::dy[t] + 2 * b) * HX_PITCH + T::dx[t]) * 16);
+                const int off = ((T::dy[t] + 2 * b) * HX_PITCH + T::dx[t]) * 16;
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(xb + off);
+                if constexpr (SPLIT) {
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(xb + HX_BYTES + off);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bv, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl, acc[b], 0, 0, 0);
+                }
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[b], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // the stores (and their vmcnt waits) stay behind the MFMAs
-        if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        if constexpr (SPLIT) {  // single-buffered weights: everybody has to be done with them first
+            if (more) conv_lstore_hx<NT, SPLIT>(xs[buf ^ 1], pl, rg);
+            __syncthreads();
+            if (more) conv_lstore_hw<NT, SPLIT>(ws[0], tid, rg);
+        } else {
+            if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -476,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
             const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (ch >= p.O) continue;
             float v = acc[t][r];
+            if constexpr (SPLIT) v *= HX_SPLIT_UNSCALE;
             if (p.epilogue) {
                 if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
                 if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)gy * p.OW + gx];
@@ -488,10 +540,11 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
 }
 
 // the fused four-phase transposed convolution (see k_modconv_up) on f16 operands
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
     constexpr int NT = 9, WBYTES = NT * 128 * 16;
-    __shared__ __attribute__((aligned(16))) char xs[2][HX_BYTES];
-    __shared__ __attribute__((aligned(16))) char ws[2][WBYTES];
+    __shared__ __attribute__((aligned(16))) char xs[2][SPLIT ? 2 * HX_BYTES : HX_BYTES];
+    __shared__ __attribute__((aligned(16))) char ws[SPLIT ? 1 : 2][SPLIT ? 2 * WBYTES : WBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1, half = lane >> 5, j = lane & 31;
     const int tiles_x = (p.GW + CONV_TW - 1) / CONV_TW;
@@ -515,38 +568,44 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
     const int wlane = (half * 64 + wc * 32 + j) * 16;
 
     const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
-    ConvStageRegsH<NT> rg;
-    conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
-    conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    ConvStageRegsH<NT, SPLIT> rg;
+    conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_lstore_h<NT, SPLIT>(xs[0], ws[0], tid, pl, rg);
     __syncthreads();
     int buf = 0;
+    // (phase, tap, patch offset) of the nine products of the four output phases
+    const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
     for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
         const bool more = ic0 + 16 < ic_end;
-        if (more) conv_gload_h<NT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        if (more) conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
-        const char* wb = ws[buf] + wlane;
-        f16x8 a[9];
+        const char* wb = ws[SPLIT ? 0 : buf] + wlane;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16);
+        for (int pass = 0; pass < (SPLIT ? 3 : 1); ++pass) {  // SPLIT: a_lo*b_hi, a_hi*b_lo, a_hi*b_hi
+            const int aoff = (SPLIT && pass == 0) ? WBYTES : 0, boff = (SPLIT && pass == 1) ? HX_BYTES : 0;
+            f16x8 a[9];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const char* xp = xb + (2 * t * HX_PITCH) * 16;
-            const f16x8 b00 = *reinterpret_cast<const f16x8*>(xp);
-            const f16x8 b01 = *reinterpret_cast<const f16x8*>(xp - 16);
-            const f16x8 b10 = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
-            const f16x8 b11 = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b00, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b00, acc[1][t], 0, 0, 0);
-            acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b00, acc[2][t], 0, 0, 0);
-            acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[4], b00, acc[3][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b01, acc[0][t], 0, 0, 0);
-            acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[5], b01, acc[2][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[6], b10, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[7], b10, acc[1][t], 0, 0, 0);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[8], b11, acc[0][t], 0, 0, 0);
+            for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const f16x8*>(wb + aoff + t * 128 * 16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char* xp = xb + boff + (2 * t * HX_PITCH) * 16;
+                f16x8 bq[4];
+                bq[0] = *reinterpret_cast<const f16x8*>(xp);
+                bq[1] = *reinterpret_cast<const f16x8*>(xp - 16);
+                bq[2] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
+                bq[3] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TP[q]], bq[BO[q]], acc[PH[q]][t], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        if constexpr (SPLIT) {
+            if (more) conv_lstore_hx<NT, SPLIT>(xs[buf ^ 1], pl, rg);
+            __syncthreads();
+            if (more) conv_lstore_hw<NT, SPLIT>(ws[0], tid, rg);
+        } else {
+            if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -562,18 +621,22 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
+                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = SPLIT ? acc[ph][t][r] * HX_SPLIT_UNSCALE : acc[ph][t][r];
             }
         }
     }
 }
 
-// w [O][I][kk] f32 -> wh [O][kk][I] f16 (RNE), once per layer
-__global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int kk, _Float16* __restrict__ wh) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)O * I * kk) return;
+// w [O][I][kk] f32 -> wh [O][kk][I] f16 (RNE), once per layer; split: followed by the lo parts f16(w - hi) in the same layout
+__global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int kk, _Float16* __restrict__ wh, int split) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)O * I * kk;
+    if (idx >= total) return;
     const int i = (int)(idx % I), t = (int)((idx / I) % kk), o = (int)(idx / ((long long)I * kk));
-    wh[idx] = (_Float16)w[((long long)o * I + i) * kk + t];
+    float v = w[((long long)o * I + i) * kk + t];
+    if (split) v = fminf(fmaxf(v * HX_SPLIT_SCALE_W, -65504.0f), 65504.0f);
+    const _Float16 hi = (_Float16)v;
+    wh[idx] = hi;
+    if (split) wh[total + idx] = (_Float16)(v - (float)hi);
 }
 
 // sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
@@ -816,7 +879,8 @@ static inline int chk() {
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-    if (p.wh) hipLaunchKernelGGL((k_modconv_h<MODE>), grid, dim3(256), 0, st, p);
+    if (p.wh && p.wsplit) hipLaunchKernelGGL((k_modconv_h<MODE, true>), grid, dim3(256), 0, st, p);
+    else if (p.wh) hipLaunchKernelGGL((k_modconv_h<MODE, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
 }
 
@@ -841,7 +905,7 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     return b + 256;
 }
 
-static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int O, int ks,
+static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int wsplit, int O, int ks,
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -864,7 +928,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     }
     const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
     ConvParams p;
-    p.x = x; p.w = w; p.wh = wh; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
+    p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
@@ -877,7 +941,8 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (p.wh) hipLaunchKernelGGL(k_modconv_up_h, grid, dim3(256), 0, st, p);
+        if (p.wh && p.wsplit) hipLaunchKernelGGL(k_modconv_up_h<true>, grid, dim3(256), 0, st, p);
+        else if (p.wh) hipLaunchKernelGGL(k_modconv_up_h<false>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
     if (ksplit > 1) {
@@ -903,7 +968,7 @@ int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w
                       int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias, int up,
                       int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                       size_t workspace_bytes, void* stream) {
-    return modconv_impl(x, N, I, H, W, w, nullptr, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act,
+    return modconv_impl(x, N, I, H, W, w, nullptr, 0, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act,
                         alpha, gain, clamp, fir, y, workspace, workspace_bytes, stream);
 }
 
@@ -916,13 +981,19 @@ int p3d_demod_coefs_f32(const float* w2, const float* styles, const int32_t* tab
     return chk();
 }
 
-int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream) {
+static int weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, int split, void* stream) {
     if (!w || !w_f16 || O <= 0 || I <= 0) return P3D_E_ARG;
     if (ks != 1 && ks != 3) return P3D_E_RANGE;
     const long long total = (long long)O * I * ks * ks;
     hipLaunchKernelGGL(k_weights_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, O, I, ks * ks,
-                       (_Float16*)w_f16);
+                       (_Float16*)w_f16, split);
     return chk();
+}
+int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream) {
+    return weights_to_f16(w, O, I, ks, w_f16, 0, stream);
+}
+int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream) {
+    return weights_to_f16(w, O, I, ks, w_f16x2, 1, stream);
 }
 
 int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
@@ -931,8 +1002,18 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
                              size_t workspace_bytes, void* stream) {
     if (!w_f16) return P3D_E_ARG;
     if (I % 16 != 0 || ((uintptr_t)w_f16 & 15)) return P3D_E_RANGE;  // a K chunk is 16 channels; 16-byte weight pieces
-    return modconv_impl(x, N, I, H, W, w, w_f16, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act, alpha,
+    return modconv_impl(x, N, I, H, W, w, w_f16, 0, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act, alpha,
                         gain, clamp, fir, y, workspace, workspace_bytes, stream);
+}
+
+int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
+                               const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
+                               const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!w_f16x2) return P3D_E_ARG;
+    if (I % 16 != 0 || ((uintptr_t)w_f16x2 & 15) || ((size_t)O * I * ks * ks * 2) % 16 != 0) return P3D_E_RANGE;
+    return modconv_impl(x, N, I, H, W, w, w_f16x2, 1, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act,
+                        alpha, gain, clamp, fir, y, workspace, workspace_bytes, stream);
 }
 
 int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,

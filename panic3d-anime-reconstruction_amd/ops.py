@@ -488,13 +488,17 @@ def upsample2d_add(x, f, add=None):
     return y
 
 
-def conv_weights_to_f16(weight):
-    """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer)."""
+def conv_weights_to_f16(weight, split=False):
+    """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer); split: the
+    [2,O,k*k,I] hi / lo pair of the two-term variant (hi = f16(w), lo = f16(w - hi))."""
     weight = _chk(weight, "weight")
     O, I, kh, kw = weight.shape
-    wh = torch.empty((O, kh * kw, I), dtype=torch.float16, device=weight.device)
+    wh = torch.empty((2, O, kh * kw, I) if split else (O, kh * kw, I), dtype=torch.float16, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(_lib.lib().p3d_conv_weights_to_f16(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16")
+        if split:
+            _lib.check(_lib.lib().p3d_conv_weights_to_f16x2(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16x2")
+        else:
+            _lib.check(_lib.lib().p3d_conv_weights_to_f16(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16")
     return wh
 
 
@@ -512,7 +516,8 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
     noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
     weight_f16 (from conv_weights_to_f16): run the matrix cores on f16 operands (fp32 accumulate, fp32 in/out) — what the
-    reference's fp16 super-resolution blocks do on the GPU, with less rounding; needs I % 16 == 0."""
+    reference's fp16 super-resolution blocks do on the GPU, with less rounding; needs I % 16 == 0.  A [2,O,k*k,I] tensor
+    (conv_weights_to_f16(split=True)) selects the two-term variant: fp32-class results on the f16 matrix cores."""
     x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
     N, I, H, W = x.shape
     O, I2, kh, kw = weight.shape
@@ -546,12 +551,14 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         if weight_f16 is not None:
-            if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape) != (O, kh * kw, I) or not weight_f16.is_contiguous():
-                raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] float16 tensor of conv_weights_to_f16")
-            rc = L.p3d_modconv2d_f16mma_f32(_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
-                                            _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y),
-                                            _p(ws), wsb, _stream())
-            _lib.check(rc, "p3d_modconv2d_f16mma_f32")
+            split = weight_f16.ndim == 4
+            if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape)[-3:] != (O, kh * kw, I) or not weight_f16.is_contiguous() \
+                    or (split and weight_f16.shape[0] != 2):
+                raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] / [2,O,k*k,I] float16 tensor of conv_weights_to_f16")
+            fn, name = (L.p3d_modconv2d_f16x2mma_f32, "p3d_modconv2d_f16x2mma_f32") if split else (L.p3d_modconv2d_f16mma_f32, "p3d_modconv2d_f16mma_f32")
+            rc = fn(_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
+                    _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
+            _lib.check(rc, name)
         else:
             rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(dcoef), _p(noise), nps,
                                      _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())

@@ -8,6 +8,8 @@ trainers/train_eclustrousC.py:253,553).  All convolution-shaped work runs in lib
 ToRGBLayer is ONE fused call (modulation, conv on the matrix cores, demodulation, noise, bias, lrelu, gain, clamp);
 the tiny fully-connected layers (w -> styles, mapping) stay on torch matmul.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -108,14 +110,25 @@ class MappingNetwork(torch.nn.Module):
         return x
 
 
+# How the 3x3 convolutions feed the matrix cores when a layer does not say (`layer.mma_f16`): "f32" = v_mfma_f32_32x32x2_f32,
+# "x2" = two-term f16 operands on v_mfma_f32_32x32x16_f16 (fp32-class results: tests/test_hip_synthesis.py measures its error
+# against float64 next to the f32 kernel's; ~1.8x faster).  The environment variable is for A/B runs.
+DEFAULT_CONV_MMA = os.environ.get("P3D_CONV_MMA", "f32")
+
+
 def _f16_operand(layer):
-    """The cached [O,k*k,I] f16 copy of layer.weight when the layer is switched to f16 MFMA operands (`layer.mma_f16`,
-    see TriPlaneGenerator.set_sr_mma_f16), else None.  A plain attribute, not a buffer: the state_dict stays the reference's."""
-    if not getattr(layer, "mma_f16", False) or layer.in_channels % 16 != 0:
+    """The cached f16 operand copy of layer.weight when the layer runs on f16 MFMA operands, else None.  `layer.mma_f16`:
+    False = fp32 operands, True = one f16 term ([O,k*k,I]; TriPlaneGenerator.set_sr_mma_f16), "x2" = two-term operands
+    ([2,O,k*k,I]); unset = DEFAULT_CONV_MMA for the plain 3x3 layers.  A plain attribute, not a buffer: the state_dict stays
+    the reference's."""
+    mode = getattr(layer, "mma_f16", None)  # None | False | True | "x2"
+    if mode is None:
+        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and getattr(layer, "up", 0) == 1 and layer.weight.shape[-1] == 3) else False
+    if not mode or layer.in_channels % 16 != 0:
         return None
-    key = (layer.weight.data_ptr(), layer.weight._version)
+    key = (layer.weight.data_ptr(), layer.weight._version, mode)
     if getattr(layer, "_wh_key", None) != key:
-        layer._wh, layer._wh_key = ops.conv_weights_to_f16(layer.weight.detach()), key
+        layer._wh, layer._wh_key = ops.conv_weights_to_f16(layer.weight.detach(), split=(mode == "x2")), key
     return layer._wh
 
 

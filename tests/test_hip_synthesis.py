@@ -343,6 +343,39 @@ def test_modconv_f16_operands_vs_fp32(hip, I, O, H, up, ks, N):
         assert (y16 - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("I,O,H,up,ks,N", [(32, 64, 24, 1, 3, 2), (64, 40, 20, 2, 3, 1), (48, 3, 33, 1, 1, 2), (256, 128, 64, 2, 3, 1),
+                                           (128, 128, 96, 1, 3, 1), (512, 512, 16, 1, 3, 1)])
+def test_modconv_f16x2_operands_are_fp32_class(hip, I, O, H, up, ks, N):
+    """The two-term f16-operand convolution (hi + lo operands, fp32 accumulate) measured against a float64 evaluation of the same
+    layer, next to the exact-fp32 HIP convolution: its error has to be of the size of the fp32 kernel's own rounding /
+    summation-order error, three orders of magnitude below the one-term f16 variant."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(I + O)
+    x = torch.randn(N, I, H, H, generator=g).cuda(); w = torch.randn(O, I, ks, ks, generator=g).cuda()
+    s = (torch.randn(N, I, generator=g) * 0.5 + 1).cuda(); b = torch.randn(O, generator=g).cuda()
+    f = ops.setup_filter([1, 3, 3, 1]).cuda()
+    kw = dict(up=up, padding=ks // 2, resample_filter=f, demodulate=ks == 3, bias=b, act="lrelu" if ks == 3 else "linear")
+    w2 = ops.conv_weights_to_f16(w, split=True)
+    wsc = w.reshape(O, I, ks * ks).permute(0, 2, 1) * 64.0  # stored scaled by 2^6 (the matrix cores flush f16 subnormals)
+    hi = wsc.half()
+    assert w2.shape == (2, O, ks * ks, I) and torch.equal(w2[0], hi)
+    assert torch.equal(w2[1], (wsc - hi.float()).half())
+    ref = torch_modconv_ref(x.double().cpu(), w.double().cpu(), s.double().cpu(), None, up, ks == 3, b.double().cpu(), f.double().cpu())
+    ref = (F.leaky_relu(ref, 0.2) * np.sqrt(2) if ks == 3 else ref).cuda()
+    y32 = ops.modulated_conv2d(x, w, s, **kw).double()
+    yx2 = ops.modulated_conv2d(x, w, s, weight_f16=w2, **kw).double()
+    y16 = ops.modulated_conv2d(x, w, s, weight_f16=ops.conv_weights_to_f16(w), **kw).double()
+    e32, ex2, e16 = ((y - ref).abs().mean().item() for y in (y32, yx2, y16))
+    m32, mx2 = ((y - ref).abs().max().item() for y in (y32, yx2))
+    scale = ref.abs().mean().item()
+    print(f"I={I} O={O} H={H} up={up} ks={ks}: mean |err| fp32 {e32:.3e}  f16x2 {ex2:.3e}  f16 {e16:.3e} | max fp32 {m32:.3e}  f16x2 {mx2:.3e} | mean |y| {scale:.3f}")
+    assert e32 < 1e-6 * scale, (e32, scale)          # the fp32 kernel itself
+    # operands carry 22 significant bits (fp32: 24): the mean error stays at the fp32 kernel's (summation dominates), single
+    # outputs can be off by a few times more
+    assert ex2 < 3 * e32 and mx2 < 8 * m32, (ex2, e32, mx2, m32)
+    assert ex2 < 1e-2 * e16, (ex2, e16)
+
+
 def test_sr_f16_operands_image_quality(hip):
     """TriPlaneGenerator with set_sr_mma_f16: the 512^2 image stays within f16-operand rounding of the fp32 image
     (PSNR > 50 dB on [-1,1] images; the reference's own fp16 blocks round activations as well)."""

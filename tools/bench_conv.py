@@ -8,10 +8,11 @@ from panic3d_amd import ops
 dev = "cuda"
 f = ops.setup_filter([1, 3, 3, 1]).to(dev)
 F16 = "--f16" in sys.argv  # f16 MFMA operands (fp32 accumulate)
+X2 = "--f16x2" in sys.argv  # two-term f16 operands (fp32-class results)
 def run(I, O, H, up, ks, N=1):
     x = torch.randn(N, I, H, H, device=dev); w = torch.randn(O, I, ks, ks, device=dev); s = torch.randn(N, I, device=dev)
     b = torch.randn(O, device=dev)
-    wh = ops.conv_weights_to_f16(w) if F16 and I % 16 == 0 else None
+    wh = ops.conv_weights_to_f16(w, split=X2) if (F16 or X2) and I % 16 == 0 else None
     fn = lambda: ops.modulated_conv2d(x, w, s, up=up, padding=ks // 2, resample_filter=f, demodulate=ks == 3, bias=b, act="lrelu" if ks == 3 else "linear", weight_f16=wh)
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.perf_counter()

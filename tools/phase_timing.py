@@ -18,13 +18,13 @@ for scene in ("canonical", "surface"):
         for early in (True, False):
             opts = ops.make_opts(ro, early_out=early, fast_color=fast, **T.BENCH_KW)
             for _ in range(2): ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
-            buf = (ctypes.c_ulonglong * 16)(); L.p3d_phase_read(buf, 1)
+            buf = (ctypes.c_ulonglong * 17)(); L.p3d_phase_read(buf, 1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res); e1.record(); torch.cuda.synchronize()
             L.p3d_phase_read(buf, 1)
             b = list(buf); ms = e0.elapsed_time(e1)
-            tot = b[6]
+            tot = b[16]
             print(f"{scene} fast={fast} early={early}: {ms:.2f} ms | wave lifetime ticks {tot/ max(b[7],1):.0f} per wave ({b[7]} waves) | "
                   f"coarse: gather {b[0]/tot:.3f} mlp {b[1]/tot:.3f} ({b[4]} steps, {b[0]/max(b[4],1):.0f}+{b[1]/max(b[4],1):.0f} ticks/step) | "
                   f"final: gather {b[2]/tot:.3f} mlp {b[3]/tot:.3f} ({b[5]} steps, {b[2]/max(b[5],1):.0f}+{b[3]/max(b[5],1):.0f} ticks/step) | other {1-(b[0]+b[1]+b[2]+b[3])/tot:.3f}"
-                  f" || sections: weights->LDS+sync {b[8]/tot:.3f} stratified {b[9]/tot:.3f} coarse loop {b[10]/tot:.3f} cdf {b[11]/tot:.3f} draws+sort {b[12]/tot:.3f} final loop {b[13]/tot:.3f} [skip-walk {b[14]/tot:.3f} march+composite {b[15]/tot:.3f}]")
+                  f" || sections: weights->LDS+sync {b[8]/tot:.3f} stratified {b[9]/tot:.3f} coarse loop {b[10]/tot:.3f} cdf {b[11]/tot:.3f} draws+sort {b[12]/tot:.3f} final loop {b[13]/tot:.3f} [merge pre-pass {b[6]/tot:.3f} select/skip {b[14]/tot:.3f} march+composite {b[15]/tot:.3f}]")
