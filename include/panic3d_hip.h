@@ -201,6 +201,9 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
  * subnormals).  Domain: |s*x| < 8188, |w| < 2047 (beyond that the operand saturates; it does not become inf).  Same arguments
  * and semantics as p3d_modconv2d_f32 otherwise; I % 16 == 0. */
 int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream);
+/* 1 if any two-term convolution since the last reset met a modulated activation outside its domain (|s*x| > 8188, or NaN) and
+ * saturated it, else 0 (-1: the device could not be read).  Synchronises the device: a debugging / validation call. */
+int p3d_conv_f16x2_saturated(int reset);
 int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
                                const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
                                const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,

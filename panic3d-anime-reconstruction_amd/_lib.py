@@ -56,6 +56,7 @@ SIGNATURES = {
     "p3d_conv_weights_to_f16": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
+    "p3d_conv_f16x2_saturated": (_I, [_I]),
     "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_upsample2d_add_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),

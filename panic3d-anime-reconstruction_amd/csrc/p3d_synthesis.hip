@@ -386,8 +386,10 @@ DEV ConvStagePlanH conv_plan_h(const ConvParams& p, int tid, int gy0, int gx0, i
 #define HX_SPLIT_SCALE_X 16.0f
 #define HX_SPLIT_SCALE_W 64.0f
 #define HX_SPLIT_UNSCALE (1.0f / 1024.0f)
+// set (never cleared by a kernel) when a two-term operand left the representable range: p3d_conv_f16x2_saturated()
+__device__ unsigned int g_f16x2_saturated = 0u;
 template <int NT, bool SPLIT = false>
-struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[(NT * 128 + 255) / 256]; i32x4 wl[SPLIT ? (NT * 128 + 255) / 256 : 1]; };
+struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[NT ? (NT * 128 + 255) / 256 : 1]; i32x4 wl[SPLIT ? (NT * 128 + 255) / 256 : 1]; };  // NT = 0: activations only
 
 template <int NT, bool SPLIT = false>
 DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float* xn, const float* sn, int ic0, int ic_end,
@@ -418,18 +420,26 @@ DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float
     }
 }
 
-template <int NT, bool SPLIT>
-DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
+template <int NT, bool SPLIT, typename REGS>
+DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const REGS& r) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (pl.xdst[u] < 0) continue;
         f16x8 v, l;
+        bool sat = false;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float m = r.s[u][i >> 2][i & 3] * r.x[u][i];
-            if constexpr (SPLIT) m = __builtin_fminf(__builtin_fmaxf(m * HX_SPLIT_SCALE_X, -65504.0f), 65504.0f);
+            if constexpr (SPLIT) {
+                m *= HX_SPLIT_SCALE_X;
+                sat = sat || !(__builtin_fabsf(m) <= 2.0f * 65504.0f);  // beyond hi + lo (or NaN)
+                m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+            }
             v[i] = (_Float16)m;  // RNE
             if constexpr (SPLIT) l[i] = (_Float16)(m - (float)v[i]);
+        }
+        if constexpr (SPLIT) {
+            if (sat) atomicOr(&g_f16x2_saturated, 1u);
         }
         *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
         if constexpr (SPLIT) *reinterpret_cast<f16x8*>(xs + HX_BYTES + pl.xdst[u]) = l;
@@ -450,6 +460,26 @@ template <int NT, bool SPLIT = false>
 DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
     conv_lstore_hx<NT, SPLIT>(xs, pl, r);
     conv_lstore_hw<NT, SPLIT>(ws, tid, r);
+}
+// the weight pieces of one chunk (hi and lo) straight from L2 into LDS (buffer_load_dwordx4 ... lds: wave-uniform LDS base +
+// lane * 16, which is exactly the [piece] order of the image) — no staging registers; out-of-range pieces arrive as zeros
+template <int NT>
+DEV void conv_glds_w2(const ConvParams& p, const ConvStagePlanH& pl, char* ws, int tid, int ic0, int ic_end) {
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + (size_t)ic0 * 2), 0,
+                                                left ? (p.O * NT * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
+    auto rl = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + ((size_t)p.O * NT * p.I + ic0) * 2), 0,
+                                                left ? (p.O * NT * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int u = 0; u < (NT * 128 + 255) / 256; ++u) {
+        const int q = tid + u * 256;
+        if (q < NT * 128) {
+            char* dst = ws + ((tid & ~63) + u * 256) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, pl.woff[u], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr)(dst + NT * 128 * 16), 16, pl.woff[u], 0, 0, 0);
+        }
+    }
 }
 
 template <int MODE, bool SPLIT>
@@ -479,14 +509,22 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
     const int wlane = (half * 64 + wc * 32 + j) * 16;
 
     const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
-    ConvStageRegsH<NT, SPLIT> rg;
-    conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic_beg, ic_end, rg);
-    conv_lstore_h<NT, SPLIT>(xs[0], ws[0], tid, pl, rg);
+    // SPLIT: only the activations go through registers (the fp32 -> hi / lo conversion); the weights are copied L2 -> LDS
+    ConvStageRegsH<SPLIT ? 0 : NT, false> rg;
+    if constexpr (SPLIT) {
+        conv_gload_h<0, false>(p, pl, xn, sn, ic_beg, ic_end, rg);
+        conv_glds_w2<NT>(p, pl, ws[0], tid, ic_beg, ic_end);
+        conv_lstore_hx<0, true>(xs[0], pl, rg);
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the LDS-direct loads have landed
+    } else {
+        conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+        conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    }
     __syncthreads();
     int buf = 0;
     for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
         const bool more = ic0 + 16 < ic_end;
-        if (more) conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        if (more) conv_gload_h<SPLIT ? 0 : NT, false>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
         const char* wb = ws[SPLIT ? 0 : buf] + wlane;
 #pragma unroll
@@ -508,9 +546,10 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);  // the stores (and their vmcnt waits) stay behind the MFMAs
         if constexpr (SPLIT) {  // single-buffered weights: everybody has to be done with them first
-            if (more) conv_lstore_hx<NT, SPLIT>(xs[buf ^ 1], pl, rg);
+            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg);
             __syncthreads();
-            if (more) conv_lstore_hw<NT, SPLIT>(ws[0], tid, rg);
+            if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end);
+            __builtin_amdgcn_s_waitcnt(0);
         } else {
             if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
         }
@@ -568,41 +607,51 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
     const int wlane = (half * 64 + wc * 32 + j) * 16;
 
     const ConvStagePlanH pl = conv_plan_h<NT>(p, tid, gy0, gx0, o0);
-    ConvStageRegsH<NT, SPLIT> rg;
-    conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic_beg, ic_end, rg);
-    conv_lstore_h<NT, SPLIT>(xs[0], ws[0], tid, pl, rg);
+    // SPLIT: only the activations go through registers (x: the fp32 -> hi / lo conversion); the weights are copied L2 -> LDS
+    ConvStageRegsH<SPLIT ? 0 : NT, false> rg;
+    if constexpr (SPLIT) {
+        conv_gload_h<0, false>(p, pl, xn, sn, ic_beg, ic_end, rg);
+        conv_glds_w2<NT>(p, pl, ws[0], tid, ic_beg, ic_end);
+        conv_lstore_hx<0, true>(xs[0], pl, rg);
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the LDS-direct loads have landed
+    } else {
+        conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
+        conv_lstore_h<NT>(xs[0], ws[0], tid, pl, rg);
+    }
     __syncthreads();
     int buf = 0;
     // (phase, tap, patch offset) of the nine products of the four output phases
     const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
     for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
         const bool more = ic0 + 16 < ic_end;
-        if (more) conv_gload_h<NT, SPLIT>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        if (more) conv_gload_h<SPLIT ? 0 : NT, false>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
         const char* wb = ws[SPLIT ? 0 : buf] + wlane;
 #pragma unroll
         for (int pass = 0; pass < (SPLIT ? 3 : 1); ++pass) {  // SPLIT: a_lo*b_hi, a_hi*b_lo, a_hi*b_hi
             const int aoff = (SPLIT && pass == 0) ? WBYTES : 0, boff = (SPLIT && pass == 1) ? HX_BYTES : 0;
-            f16x8 a[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a[t] = *reinterpret_cast<const f16x8*>(wb + aoff + t * 128 * 16);
+            f16x8 bq[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const char* xp = xb + boff + (2 * t * HX_PITCH) * 16;
-                f16x8 bq[4];
-                bq[0] = *reinterpret_cast<const f16x8*>(xp);
-                bq[1] = *reinterpret_cast<const f16x8*>(xp - 16);
-                bq[2] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
-                bq[3] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
+                bq[t][0] = *reinterpret_cast<const f16x8*>(xp);
+                bq[t][1] = *reinterpret_cast<const f16x8*>(xp - 16);
+                bq[t][2] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
+                bq[t][3] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
+            }
 #pragma unroll
-                for (int q = 0; q < 9; ++q) acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TP[q]], bq[BO[q]], acc[PH[q]][t], 0, 0, 0);
+            for (int q = 0; q < 9; ++q) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(wb + aoff + TP[q] * 128 * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[t][BO[q]], acc[PH[q]][t], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SPLIT) {
-            if (more) conv_lstore_hx<NT, SPLIT>(xs[buf ^ 1], pl, rg);
-            __syncthreads();
-            if (more) conv_lstore_hw<NT, SPLIT>(ws[0], tid, rg);
+            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg);
+            __syncthreads();  // everybody is done with the (single-buffered) weights
+            if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end);
+            __builtin_amdgcn_s_waitcnt(0);
         } else {
             if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
         }
@@ -994,6 +1043,15 @@ int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, v
 }
 int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream) {
     return weights_to_f16(w, O, I, ks, w_f16x2, 1, stream);
+}
+int p3d_conv_f16x2_saturated(int reset) {
+    unsigned int v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16x2_saturated), sizeof(v)) != hipSuccess) return -1;  // (synchronises the device)
+    if (reset && v) {
+        const unsigned int z = 0u;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16x2_saturated), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return v ? 1 : 0;
 }
 
 int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,

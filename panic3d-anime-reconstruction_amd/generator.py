@@ -286,6 +286,21 @@ class TriPlaneGenerator(torch.nn.Module):
     def set_force_sigmoid(self, state):
         return self.decoder.set_force_sigmoid(state)
 
+    def set_conv_mma(self, mode):
+        """How the 3x3 convolutions of the backbone and of the super-resolution feed the matrix cores: "f32" (fp32 operands,
+        v_mfma_f32_32x32x2_f32), "x2" (two-term f16 operands: fp32-class results, ~2x faster; domain |s*x| < 8188, checked by
+        ops.conv_f16x2_saturated()), "f16" (one f16 term: the precision of the reference's fp16 blocks) or None (the
+        package default, stylegan2.DEFAULT_CONV_MMA)."""
+        val = {"f32": False, "x2": "x2", "f16": True, None: None}[mode]
+        for m in list(self.backbone.modules()) + list(self.superresolution.modules()):
+            if isinstance(m, stylegan2.SynthesisLayer):
+                if val is None:
+                    if hasattr(m, "mma_f16"):
+                        del m.mma_f16
+                else:
+                    m.mma_f16 = val
+        return mode
+
     def set_sr_mma_f16(self, state=True):
         """Opt-in: run the super-resolution convolutions on f16 MFMA operands (fp32 accumulate, fp32 activations in HBM).
         The reference runs these blocks in fp16 on the GPU (sr_num_fp16_res = 4, superresolution.py:277-280); the default here

@@ -502,6 +502,15 @@ def conv_weights_to_f16(weight, split=False):
     return wh
 
 
+def conv_f16x2_saturated(reset=True):
+    """True if a two-term f16 convolution met a modulated activation outside its domain (|s*x| > 8188) since the last reset.
+    Synchronises the device."""
+    rc = _lib.lib().p3d_conv_f16x2_saturated(int(bool(reset)))
+    if rc < 0:
+        raise RuntimeError("p3d_conv_f16x2_saturated: device not readable")
+    return bool(rc)
+
+
 def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
     """Demodulation coefficients of L layers in one launch (p3d_demod_coefs_f32); see stylegan2.StylePlan."""
     with torch.cuda.device(out.device):

@@ -113,7 +113,7 @@ class MappingNetwork(torch.nn.Module):
 # How the 3x3 convolutions feed the matrix cores when a layer does not say (`layer.mma_f16`): "f32" = v_mfma_f32_32x32x2_f32,
 # "x2" = two-term f16 operands on v_mfma_f32_32x32x16_f16 (fp32-class results: tests/test_hip_synthesis.py measures its error
 # against float64 next to the f32 kernel's; ~1.8x faster).  The environment variable is for A/B runs.
-DEFAULT_CONV_MMA = os.environ.get("P3D_CONV_MMA", "f32")
+DEFAULT_CONV_MMA = os.environ.get("P3D_CONV_MMA", "x2")
 
 
 def _f16_operand(layer):
@@ -123,7 +123,7 @@ def _f16_operand(layer):
     the reference's."""
     mode = getattr(layer, "mma_f16", None)  # None | False | True | "x2"
     if mode is None:
-        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and getattr(layer, "up", 0) == 1 and layer.weight.shape[-1] == 3) else False
+        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and layer.weight.shape[-1] == 3) else False
     if not mode or layer.in_channels % 16 != 0:
         return None
     key = (layer.weight.data_ptr(), layer.weight._version, mode)

@@ -376,6 +376,51 @@ def test_modconv_f16x2_operands_are_fp32_class(hip, I, O, H, up, ks, N):
     assert ex2 < 1e-2 * e16, (ex2, e16)
 
 
+def test_modconv_f16x2_saturation_is_reported(hip):
+    """Outside its domain (|s*x| > 8188) the two-term convolution saturates the operand — finite, wrong — and says so."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 32, 16, 16, generator=g).cuda(); w = torch.randn(64, 32, 3, 3, generator=g).cuda()
+    s = torch.ones(1, 32).cuda()
+    w2 = ops.conv_weights_to_f16(w, split=True)
+    ops.conv_f16x2_saturated(reset=True)
+    y = ops.modulated_conv2d(x * 100, w, s, padding=1, weight_f16=w2)
+    assert not ops.conv_f16x2_saturated() and torch.isfinite(y).all()
+    y32 = ops.modulated_conv2d(x * 100, w, s, padding=1)
+    assert (y - y32).abs().max() < 1e-5 * y32.abs().max()
+    x[0, 3, 5, 5] = 9000.0
+    y = ops.modulated_conv2d(x, w, s, padding=1, weight_f16=w2)
+    assert torch.isfinite(y).all()
+    assert ops.conv_f16x2_saturated(reset=True) and not ops.conv_f16x2_saturated()
+
+
+def test_generator_conv_mma_modes_agree(hip):
+    """TriPlaneGenerator.set_conv_mma: the two-term f16 convolutions reproduce the fp32-operand image to fp32-class accuracy
+    through the whole backbone + renderer + super-resolution stack (PSNR > 100 dB on [-1,1] images), the one-term ones do not."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**TRI_KW), g, "sd_")
+    G.set_force_sigmoid(True)
+    x = dict(elevations=torch.tensor([0.0]).cuda(), azimuths=torch.tensor([20.0]).cuda(), fovs=torch.tensor([30.0]).cuda(),
+             seeds=[3], cond={}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+    out = {}
+    with torch.no_grad():
+        for mode in ("f32", "x2", "f16"):
+            G.set_conv_mma(mode)
+            G._inject_draws = (dev(g["jitter"])[:1], dev(g["u"])[:256])
+            out[mode] = G.f(dict(x))
+    G._inject_draws = None
+    G.set_conv_mma(None)
+    assert not hip.ops.conv_f16x2_saturated()
+    used = [m for m in list(G.backbone.modules()) + list(G.superresolution.modules()) if getattr(m, "_wh", None) is not None]
+    assert len(used) >= 6
+    psnr = lambda a, b: 10 * np.log10(4.0 / max(float(((a - b).double() ** 2).mean()), 1e-30))
+    p_x2, p_16 = psnr(out["x2"]["image"], out["f32"]["image"]), psnr(out["f16"]["image"], out["f32"]["image"])
+    print(f"PSNR vs fp32 operands: two-term {p_x2:.1f} dB, one-term {p_16:.1f} dB; planes max |diff| "
+          f"{(out['x2']['triplane'] - out['f32']['triplane']).abs().max().item():.2e}")
+    assert p_x2 > 100 and p_16 < p_x2 - 30
+
+
 def test_sr_f16_operands_image_quality(hip):
     """TriPlaneGenerator with set_sr_mma_f16: the 512^2 image stays within f16-operand rounding of the fp32 image
     (PSNR > 50 dB on [-1,1] images; the reference's own fp16 blocks round activations as well)."""
