@@ -578,6 +578,210 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The two-term convolution on a WIDE tile (3x3, maps of 32 columns and more): 64 output channels x 8 rows x 32 columns per
+// workgroup, a wave = 64 channels x 2 rows x 32 columns = 2 x 2 MFMA tiles.  Measured on the 8 x 16 tile above (256 -> 256
+// channels at 256^2): 0.39 ms, of which 0.10 ms weight staging, 0.09 ms activation staging and 0.20 ms the MFMA loop itself —
+// one ds_read_b128 per MFMA is the LDS's limit, not the matrix cores'.  Here a tap costs 8 (+2) reads for 12 MFMAs, the
+// weights of a chunk are staged once for twice the MFMAs, and both halves of the (single-buffered) weight image are re-loaded
+// UNDER MFMAs:   phase 1 = a_hi x (b_hi, b_lo)   | barrier | a_hi(next) -> LDS under phase 2 = a_lo x b_hi | barrier |
+//                a_lo(next) -> LDS under the next chunk's phase 1.
+//   LDS B: [hi | lo][buffer][k half][10 rows][34 px][8 ch] f16 = 2 x 2 x 10 880 B;  LDS A: [hi | lo][tap][k half][64 o][8 ch] = 36 864 B
+//   -> 80 384 B per workgroup, two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+#define WX_TW 32
+#define WX_ROW (WX_TW + 2)                         // patch columns = LDS row pitch (px)
+#define WX_HALF ((CONV_TH + 2) * WX_ROW * 16)      // bytes of one k half
+#define WX_BYTES (2 * WX_HALF)                     // one (hi or lo) patch image: 10 880
+#define WX_ITEMS (2 * (CONV_TH + 2) * WX_ROW)      // (k half, pixel) items per chunk: 680
+#define WX_ROUNDS ((WX_ITEMS + 255) / 256)         // 3
+
+struct ConvStagePlanW {
+    int xoff[WX_ROUNDS], xdst[WX_ROUNDS], soff[WX_ROUNDS];
+    int woff[5];
+};
+DEV ConvStagePlanW conv_plan_w(const ConvParams& p, int tid, int gy0, int gx0, int o0) {
+    ConvStagePlanW s;
+#pragma unroll
+    for (int u = 0; u < WX_ROUNDS; ++u) {
+        const int it = tid + u * 256;
+        const int h = it / ((CONV_TH + 2) * WX_ROW), px = it - h * ((CONV_TH + 2) * WX_ROW);
+        const int r = px / WX_ROW, c = px - r * WX_ROW;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        const bool item = it < WX_ITEMS;
+        const bool ok = item && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        s.xoff[u] = ok ? ((8 * h * p.H + iy) * p.W + ix) * 4 : CONV_OOB;
+        s.soff[u] = ok ? 32 * h : CONV_OOB;
+        s.xdst[u] = item ? h * WX_HALF + (r * WX_ROW + c) * 16 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = tid + u * 256;  // piece = (tap, k half, o): 16 bytes = 8 channels
+        const int t = q >> 7, h = (q >> 6) & 1, o = q & 63;
+        const bool ok = q < 9 * 128 && o0 + o < p.O;
+        s.woff[u] = ok ? (((o0 + o) * 9 + t) * p.I + 8 * h) * 2 : CONV_OOB;
+    }
+    return s;
+}
+struct ConvStageRegsW { float x[WX_ROUNDS][8]; f32x4 s[WX_ROUNDS][2]; };
+DEV void conv_gload_w(const ConvParams& p, const ConvStagePlanW& pl, const float* xn, const float* sn, int ic0, int ic_end, ConvStageRegsW& r) {
+    const int HW = p.H * p.W;
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xn + (size_t)ic0 * HW), 0, left * HW * 4, CONV_RSRC_FLAGS);
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sn + ic0), 0, left * 4, CONV_RSRC_FLAGS);
+#pragma unroll
+    for (int u = 0; u < WX_ROUNDS; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            r.x[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, pl.xoff[u], i * HW * 4, 0));
+        r.s[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pl.soff[u], 0, 0));
+        r.s[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pl.soff[u], 16, 0));
+    }
+}
+// hi image at xs, lo image at xs + 2 * WX_BYTES (the two buffers of one kind are adjacent)
+DEV void conv_lstore_w(char* xs, const ConvStagePlanW& pl, const ConvStageRegsW& r) {
+#pragma unroll
+    for (int u = 0; u < WX_ROUNDS; ++u) {
+        if (pl.xdst[u] < 0) continue;
+        f16x8 v, l;
+        bool sat = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float m = r.s[u][i >> 2][i & 3] * r.x[u][i] * HX_SPLIT_SCALE_X;
+            sat = sat || !(__builtin_fabsf(m) <= 2.0f * 65504.0f);
+            m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+            v[i] = (_Float16)m;
+            l[i] = (_Float16)(m - (float)v[i]);
+        }
+        *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
+        *reinterpret_cast<f16x8*>(xs + 2 * WX_BYTES + pl.xdst[u]) = l;
+        if (sat) atomicOr(&g_f16x2_saturated, 1u);
+    }
+}
+// one half (hi: which = 0, lo: which = 1) of a chunk's weight image, L2 -> LDS
+DEV void conv_glds_wh(const ConvParams& p, const ConvStagePlanW& pl, char* ws, int tid, int ic0, int ic_end, int which) {
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + ((size_t)which * p.O * 9 * p.I + ic0) * 2), 0,
+                                                left ? (p.O * 9 * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = tid + u * 256;
+        if (q < 9 * 128)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(ws + which * (9 * 128 * 16) + ((tid & ~63) + u * 256) * 16), 16, pl.woff[u], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
+    using T = ConvTaps<0>;
+    constexpr int WBYTES = 9 * 128 * 16;
+    __shared__ __attribute__((aligned(16))) char xs[2 /*hi, lo*/][2 /*buffer*/][WX_BYTES];
+    __shared__ __attribute__((aligned(16))) char ws[2 * WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * WX_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
+    const float* sn = p.styles + (size_t)n * p.I;
+
+    f32x16 acc[2][2];  // [channel tile][column half]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const int prow = 2 * wave + (j >> 4), pcol = j & 15;
+    const int xlane = half * WX_HALF + ((prow + 1) * WX_ROW + pcol + 1) * 16;  // column half b adds 16 px
+    const int wlane = (half * 64 + j) * 16;                                     // channel tile a adds 32 o
+
+    const ConvStagePlanW pl = conv_plan_w(p, tid, gy0, gx0, o0);
+    ConvStageRegsW rg;
+    conv_gload_w(p, pl, xn, sn, ic_beg, ic_end, rg);
+    conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 0);
+    conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 1);
+    conv_lstore_w(xs[0][0], pl, rg);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    int buf = 0;
+    for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
+        const bool more = ic0 + 16 < ic_end;
+        if (more) conv_gload_w(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        const char* xh = xs[0][buf] + xlane;
+        const char* xl = xs[1][buf] + xlane;
+        const char* wb = ws + wlane;
+        // phase 1: a_hi x (b_lo, b_hi)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = (T::dy[t] * WX_ROW + T::dx[t]) * 16;
+            f16x8 ah[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16 + a * 32 * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * 16 * 16);
+                bl[b] = *reinterpret_cast<const f16x8*>(xl + off + b * 16 * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) conv_lstore_w(xs[0][buf ^ 1], pl, rg);   // (waits for this chunk's a_lo too: it was requested before phase 1)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                                    // a_hi is free, a_lo has landed everywhere
+        if (more) conv_glds_wh(p, pl, ws, tid, ic0 + 16, ic_end, 0);
+        // phase 2: a_lo x b_hi
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int off = (T::dy[t] * WX_ROW + T::dx[t]) * 16;
+            f16x8 al[2], bh[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) al[a] = *reinterpret_cast<const f16x8*>(wb + WBYTES + t * 128 * 16 + a * 32 * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * 16 * 16);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                                    // a_lo and this patch buffer are free, a_hi(next) has landed
+        if (more) conv_glds_wh(p, pl, ws, tid, ic0 + 16, ic_end, 1);
+        buf ^= 1;
+    }
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+    const int gy = gy0 + prow;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int gx = gx0 + 16 * b + pcol;
+        if (gy >= p.GH || gx >= p.GW) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = o0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ch >= p.O) continue;
+                float v = acc[a][b][r] * HX_SPLIT_UNSCALE;
+                if (p.epilogue) {
+                    if (p.dcoef) v = v * p.dcoef[(size_t)n * p.O + ch];
+                    if (p.noise) v = v + p.noise[(p.noise_per_sample ? (size_t)n * p.OH * p.OW : 0) + (size_t)gy * p.OW + gx];
+                    if (p.bias) v = v + p.bias[ch];
+                    v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+                }
+                yout[(((size_t)n * p.O + ch) * p.OH + gy) * p.OW + gx] = v;
+            }
+    }
+}
+
 // the fused four-phase transposed convolution (see k_modconv_up) on f16 operands
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
@@ -928,14 +1132,19 @@ static inline int chk() {
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+    if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
+        dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+        hipLaunchKernelGGL(k_modconv_w2, gw, dim3(256), 0, st, p);
+        return;
+    }
     if (p.wh && p.wsplit) hipLaunchKernelGGL((k_modconv_h<MODE, true>), grid, dim3(256), 0, st, p);
     else if (p.wh) hipLaunchKernelGGL((k_modconv_h<MODE, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
 }
 
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
-static int choose_ksplit(int N, int I, int O, int GH, int GW) {
-    long long wgs = (long long)((GW + CONV_TW - 1) / CONV_TW) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
+static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) {
+    long long wgs = (long long)((GW + tw - 1) / tw) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
     // down to ONE 8-channel chunk per workgroup: at batch 1 the 4^2..16^2 layers are a weight stream (9.4 MB for 512 -> 512 x 3x3)
     // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/r02_notes.txt
@@ -950,6 +1159,10 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     size_t out_elems = (up == 2) ? (size_t)N * O * (2 * H + 1) * (2 * W + 1) : (size_t)N * O * H * W;
     if (up == 2) b += out_elems * 4;  // transposed-conv intermediate
     int ks = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
+    if (up == 1 && W >= WX_TW) {  // the wide tile of the two-term kernel may split deeper
+        const int kw = choose_ksplit(N, I, O, H, W, WX_TW);
+        ks = kw > ks ? kw : ks;
+    }
     if (ks > 1) b += (size_t)ks * out_elems * 4;  // split-K partial sums
     return b + 256;
 }
@@ -975,7 +1188,8 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
-    const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
+    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w2
+    const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W, wide ? WX_TW : CONV_TW);
     ConvParams p;
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
