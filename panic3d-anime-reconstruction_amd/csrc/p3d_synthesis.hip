@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The two-term convolution on a WIDE tile (3x3, maps of 32 columns and more): 64 output channels x 8 rows x 32 columns per
-// workgroup, a wave = 64 channels x 2 rows x 32 columns = 2 x 2 MFMA tiles.  Measured on the 8 x 16 tile above (256 -> 256
+// workgroup, a wave = 64 channels x 2 rows x 32 columns = 2 x 2 MFMA tiles (a B tile = one row).  Measured on the 8 x 16 tile above (256 -> 256
 // channels at 256^2): 0.39 ms, of which 0.10 ms weight staging, 0.09 ms activation staging and 0.20 ms the MFMA loop itself —
 // one ds_read_b128 per MFMA is the LDS's limit, not the matrix cores'.  Here a tap costs 8 (+2) reads for 12 MFMAs, the
 // weights of a chunk are staged once for twice the MFMAs, and both halves of the (single-buffered) weight image are re-loaded
@@ -687,15 +687,17 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
     const float* xn = p.x + (size_t)n * p.I * p.H * p.W;
     const float* sn = p.styles + (size_t)n * p.I;
 
-    f32x16 acc[2][2];  // [channel tile][column half]
+    f32x16 acc[2][2];  // [channel tile][row of the wave's row pair]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const int prow = 2 * wave + (j >> 4), pcol = j & 15;
-    const int xlane = half * WX_HALF + ((prow + 1) * WX_ROW + pcol + 1) * 16;  // column half b adds 16 px
+    // a B tile is ONE row of 32 columns (lane j = column j): ds_read_b128 serves lanes {0-3, 12-15, 20-27} together, and with
+    // 2 rows x 16 columns per tile the 34-pixel row pitch put lanes 20-27 on the slots of lanes 12-13 (35 % conflict cycles)
+    const int prow = 2 * wave, pcol = j;
+    const int xlane = half * WX_HALF + ((prow + 1) * WX_ROW + pcol + 1) * 16;  // row b adds one row pitch
     const int wlane = (half * 64 + j) * 16;                                     // channel tile a adds 32 o
 
     const ConvStagePlanW pl = conv_plan_w(p, tid, gy0, gx0, o0);
@@ -722,8 +724,8 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
             for (int a = 0; a < 2; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16 + a * 32 * 16);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * 16 * 16);
-                bl[b] = *reinterpret_cast<const f16x8*>(xl + off + b * 16 * 16);
+                bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * WX_ROW * 16);
+                bl[b] = *reinterpret_cast<const f16x8*>(xl + off + b * WX_ROW * 16);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) al[a] = *reinterpret_cast<const f16x8*>(wb + WBYTES + t * 128 * 16 + a * 32 * 16);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * 16 * 16);
+            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * WX_ROW * 16);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -759,10 +761,10 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
         buf ^= 1;
     }
     float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
-    const int gy = gy0 + prow;
+    const int gx = gx0 + pcol;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int gx = gx0 + 16 * b + pcol;
+        const int gy = gy0 + prow + b;
         if (gy >= p.GH || gx >= p.GW) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)

@@ -13,7 +13,7 @@ import csv,glob,collections,os
 acc=collections.defaultdict(list)
 for fn in glob.glob(os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/pmc_conv_*/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "k_modconv_h" in r["Kernel_Name"]:
+        if "k_modconv_h" in r["Kernel_Name"] or "k_modconv_w2" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(acc.items()): print(k, sum(v)/len(v), len(v))
 PY
