@@ -13,8 +13,9 @@ Workload (config.workload): BASELINE config c3 with synthetic assets — one 512
 A step = ImportanceRenderer.forward end to end on the HIP path: NCHW->NHWC plane transpose, the two random draws
 (torch.rand on device, renderer.py:324,371), the fused render kernel, the global depth clamp.  Inputs (planes, rays,
 decoder) are resident in HBM before the timed region.  Multi-GPU: every rank renders its own views of the sweep (no
-data-path collective); the K frames of all ranks go to rank 0 with ONE gather at the end of the sweep, inside the timed
-region (its time is also reported separately, with every rank's own ms/step).
+data-path collective); the K frames of all ranks go to rank 0 inside the timed region — by default in eight slices that leave
+on the collective's stream while the next frames render (`--gather end`: ONE gather after the K steps); the exposed part of the
+transfer is reported separately, with every rank's own ms/step.
 
 Prints ONE JSON line (rank 0).
 `roofline` prices the fused kernel against the HBM roofline with ALGORITHMIC bytes ((Sc+Sf)*1536 + 172 B per
@@ -167,6 +168,8 @@ def load_pmc(scene, src_sha):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gather", choices=["streamed", "end"], default="streamed",
+                    help="multi-GPU: send finished slices of the sweep to rank 0 while rendering goes on (default) or gather once after the K steps")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", choices=("canonical", "surface"), default="canonical")
@@ -236,19 +239,36 @@ def main():
 
     for _ in range(a.warmup):
         ws = step()
+    streamed = launched and a.gather == "streamed"
+    chunk = max(1, a.steps // 8)  # frames per message: eight slices per sweep, sent while the next ones render
     if launched:  # warm the collective too (communicator + buffer registration happen on first use)
-        sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
+        if streamed:
+            g0 = sharding.FrameGather(frames, a.steps, dst=0)
+            g0.push(0, min(chunk, a.steps))
+            g0.finish()
+            del g0
+        else:
+            sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
     torch.cuda.synchronize()
     if launched:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # the path's only collective: the sweep's final RGBA frames go to rank 0, inside the timed region — streamed (default):
+    # finished slices leave on the collective's stream while the next frames render; `--gather end`: ONE gather after the K steps
+    fg = sharding.FrameGather(frames, a.steps, dst=0) if streamed else None
+    sent = 0
     for i in range(a.steps):
         ws = step(i)
-    torch.cuda.synchronize()
-    t_render = time.perf_counter() - t0  # this rank's K steps, before the collective
-    if launched:  # the path's only collective: ONE gather of the sweep's final RGBA frames to rank 0 (inside the timed region)
-        gathered = sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
+        if streamed and (i + 1) % chunk == 0:
+            fg.push(sent, i + 1)
+            sent = i + 1
+    if streamed and sent < a.steps:
+        fg.push(sent, a.steps)
+    torch.cuda.current_stream().synchronize()  # the render stream only: streamed transfers may still be in flight
+    t_render = time.perf_counter() - t0  # this rank's K steps
+    if launched:
+        gathered = fg.finish() if streamed else sharding.gather_frames(frames, counts=[a.steps] * world, dst=0, force=True)
         if rank == 0:
             assert gathered.shape == (world * a.steps, res, res, 4)
     torch.cuda.synchronize()
@@ -331,7 +351,8 @@ def main():
                                       "(an EMPTY volume under cull 0.5)" if a.scene == "canonical" else
                                       "round-1 surface scene: smooth-blob planes, strong sigma row (~55 % of rays hit a surface)")
                                    + ", crop=0.1 cull=0.5 white_back, step = transpose + rand draws + fused render + depth clamp"
-                                   + ("; after the K steps ONE gather of all ranks' RGBA frames to rank 0, inside the timed region" if launched else "")
+                                   + (("; all ranks' RGBA frames go to rank 0 inside the timed region, " +
+                                       ("in eight slices sent while the next frames render" if streamed else "in ONE gather after the K steps")) if launched else "")
                                    + ("; final pass in tolerance mode (P3D_FLAG_FAST_COLOR)" if fast else "; exact-contract final pass"),
                        "scene": a.scene, "rays_per_step_per_gpu": R, "samples_per_ray": Sc + Sf, "parallelism": f"views x{world}"},
             "roofline": roof,

@@ -172,6 +172,51 @@ def test_view_sharding_more_ranks_than_views(tmp_path):
     _run_gather_worker(tmp_path, 3, 2, 29543)
 
 
+_STREAM_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+import panic3d_amd
+from panic3d_amd import sharding
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+K, res = 7, 4
+frames = torch.zeros((K, res, res, 4))
+g = sharding.FrameGather(frames, K, dst=0)
+chunk = 3
+for i in range(K):  # "render" frame i, hand finished slices over while the loop goes on
+    frames[i] = 100.0 * rank + i
+    if (i + 1) % chunk == 0:
+        g.push(i + 1 - chunk, i + 1)
+if K % chunk:
+    g.push(K - K % chunk, K)
+out = g.finish()
+if rank == 0:
+    assert out.shape == (world * K, res, res, 4)
+    for r in range(world):
+        for i in range(K):
+            assert torch.all(out[r * K + i] == 100.0 * r + i), (r, i)
+    print("GATHER_OK")
+else:
+    assert out is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_streamed_frame_gather_gloo_world3(tmp_path):
+    """sharding.FrameGather (bench.py's collective: slices of the sweep sent while the next ones render) at world size 3:
+    rank order, slice order and the ragged last slice."""
+    script = tmp_path / "worker.py"
+    script.write_text(_STREAM_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GATHER_OK" in r.stdout
+
+
 def test_stylegan2_state_dict_matches_reference_names(P):
     """Drop-in requirement (eg3dc_v0.py:49 copy_params_and_buffers(require_all=True)): identical parameter / buffer names
     and shapes as the reference's Generator — checked against the state_dict the reference itself produced."""
