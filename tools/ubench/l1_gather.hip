@@ -90,26 +90,29 @@ __global__ __launch_bounds__(1024) void k(const float* tab, unsigned win, float*
     out[gid] = acc;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+static int g_threads = 1024;  // threads per block = per CU (argv[1]): 16 waves by default, 8 = k_render's occupancy
 template <int MODE>
 void run(const char* name, const float* tab, unsigned win) {
     float* d; long long* c;
     const int nb = 256, iters = 400;
     (void)hipMalloc(&d, (size_t)nb * 1024 * 4); (void)hipMalloc(&c, nb * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<nb, 1024>>>(tab, win, d, c, 4);
+    k<MODE><<<nb, g_threads>>>(tab, win, d, c, 4);
     hipEventRecord(e0);
-    k<MODE><<<nb, 1024>>>(tab, win, d, c, iters);
+    k<MODE><<<nb, g_threads>>>(tab, win, d, c, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long hc[256]; (void)hipMemcpy(hc, c, nb * 8, hipMemcpyDeviceToHost);
     double mx = 0; for (int i = 0; i < nb; ++i) mx = hc[i] > mx ? hc[i] : mx;
-    const double reqs_per_cu = 1024.0 * iters * 16;  // lane requests issued by one CU's block
+    const double reqs_per_cu = (double)g_threads * iters * 16;  // lane requests issued by one CU's block
     const double bytes = (MODE == 7 ? 4.0 : 16.0);
     printf("mode %d win %6u  %-44s %.3f ms  %8.0f kcyc  %.2f lane-req/clk/CU  %.1f B/clk/CU  (%.2f TB/s chip at wall time)\n", MODE, win, name, ms,
            mx / 1e3, reqs_per_cu / mx, reqs_per_cu * bytes / mx, 256.0 * reqs_per_cu * bytes / ms / 1e9);
     (void)hipFree(d); (void)hipFree(c);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_threads = atoi(argv[1]);
+    printf("threads per CU: %d\n", g_threads);
     const unsigned wins[2] = {8192, 131072};
     float* tab; (void)hipMalloc(&tab, (size_t)256 * 131072); (void)hipMemset(tab, 0, (size_t)256 * 131072);
     for (unsigned w : wins) {
