@@ -191,7 +191,12 @@ P3D_DEV void p3d_pin16(f32x16& v) {
 // each) are in flight while the oldest one is folded into its plane's bilinear sum, in the contract's order (nw, ne, sw, se;
 // plane 0 + plane 1, + plane 2, x 1/3).  The depth bounds the live tap registers (the compiler would otherwise hoist all 48
 // loads = 192 VGPRs).  load(k) returns this lane's 16 channels of tap k.
-template <typename LOAD>
+template <int CTRL>  // quad_perm: lane i of every quad reads lane (CTRL >> 2i) & 3 of the same quad
+P3D_DEV uint32_t p3d_quad_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+P3D_DEV float p3d_quad_f(float v) { return __builtin_bit_cast(float, p3d_quad_u<CTRL>(__builtin_bit_cast(uint32_t, v))); }
+// QUAD: the registers of a tap are [ray of the quad][4 channels] (p3d_load16_quad), so register c takes the weight of ray c >> 2.
+template <bool QUAD = false, typename LOAD>
 P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
     f32x16 tap[P3D_GATHER_DEPTH];
 #pragma unroll
@@ -201,12 +206,18 @@ P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
     for (int k = 0; k < 12; ++k) {
         __builtin_amdgcn_sched_barrier(0);
         const f32x16 v = tap[k % P3D_GATHER_DEPTH];
+        float w4[4];
+        if constexpr (QUAD) {
+            w4[0] = p3d_quad_f<0x00>(wg[k]); w4[1] = p3d_quad_f<0x55>(wg[k]); w4[2] = p3d_quad_f<0xaa>(wg[k]); w4[3] = p3d_quad_f<0xff>(wg[k]);
+        } else {
+            w4[0] = w4[1] = w4[2] = w4[3] = wg[k];
+        }
         if ((k & 3) == 0) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) f[c] = wg[k] * v[c];
+            for (int c = 0; c < 16; ++c) f[c] = w4[c >> 2] * v[c];
         } else {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) f[c] = p3d_fma(wg[k], v[c], f[c]);
+            for (int c = 0; c < 16; ++c) f[c] = p3d_fma(w4[c >> 2], v[c], f[c]);
         }
         if (k == 3) X = f;
         if (k == 7) {
@@ -227,9 +238,72 @@ P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
     return X;
 }
 
+// ---- quad-cooperative gathers ----------------------------------------------------------------------------------------------
+// The vector L1 charges a gather instruction by the distinct texels it touches (profiles/r02_notes.txt: "every ray its own
+// texel" 63 clk, "a quad shares a texel" 16 clk per instruction), so the four lanes of a quad (4 consecutive samples, same
+// channel half) fetch the half-texel of ONE of their samples per instruction — lane i piece i, 64 contiguous bytes — instead
+// of four pieces of four different texels: instruction r serves sample r of the quad.  A lane then holds 4 channels of each of
+// the quad's 4 samples; the bilinear fold is per channel, so it runs on that layout unchanged (the weight of sample r comes
+// from lane r by DPP) — every (sample, channel) value is produced by the same multiply / fma chain as before, on another lane:
+// bit-identical — and ONE 4 x 4 transpose inside the quad per sample (not per tap) restores "lane = sample".
+
+// tap registers [4 r + d] = channels 4 i + d (of this lane's half) of sample r of the quad; off = THIS lane's tap offset
+template <typename RSRC>
+P3D_DEV f32x16 p3d_load16_quad(RSRC rs, uint32_t off) {
+    const uint32_t piece = ((uint32_t)__lane_id() & 3u) * 16u;
+    const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(p3d_quad_u<0x00>(off) + piece), 0, 0);
+    const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(p3d_quad_u<0x55>(off) + piece), 0, 0);
+    const i32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(p3d_quad_u<0xaa>(off) + piece), 0, 0);
+    const i32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(p3d_quad_u<0xff>(off) + piece), 0, 0);
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b), fc = __builtin_bit_cast(f32x4, c),
+                fd = __builtin_bit_cast(f32x4, d);
+    f32x16 v;
+    v.s0 = fa.x; v.s1 = fa.y; v.s2 = fa.z; v.s3 = fa.w;
+    v.s4 = fb.x; v.s5 = fb.y; v.s6 = fb.z; v.s7 = fb.w;
+    v.s8 = fc.x; v.s9 = fc.y; v.sa = fc.z; v.sb = fc.w;
+    v.sc = fd.x; v.sd = fd.y; v.se = fd.z; v.sf = fd.w;
+    return v;
+}
+
+// in: [4 r + d] = channels 4 i + d of sample r (lane i of the quad); out: [4 p + d] = channels 4 p + d of this lane's sample.
+// rotate the rows by the lane index (selects), move row q from lane (i - q) & 3 (one DPP each), rotate back.
+P3D_DEV f32x16 p3d_quad_transpose(const f32x16& in) {
+    const uint32_t i = (uint32_t)__lane_id() & 3u;
+    const bool i0 = (i & 1u) != 0u, i1 = (i & 2u) != 0u;
+    f32x16 y, r, out;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {  // y[q] = in[(i + q) & 3]
+        float b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = i0 ? in[4 * ((q + 1) & 3) + d] : in[4 * q + d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[4 * q + d] = i1 ? b[(q + 2) & 3] : b[q];
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {  // r[q] (lane i) = y[q] of lane (i - q) & 3  =  channels piece (i - q) & 3 of sample i
+        r[d] = y[d];
+        r[4 + d] = p3d_quad_f<0x93>(y[4 + d]);   // lanes 0..3 read 3, 0, 1, 2
+        r[8 + d] = p3d_quad_f<0x4e>(y[8 + d]);   // 2, 3, 0, 1
+        r[12 + d] = p3d_quad_f<0x39>(y[12 + d]); // 1, 2, 3, 0
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {  // out[p] = r[(i - p) & 3]
+        float b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = i0 ? r[4 * ((q + 3) & 3) + d] : r[4 * q + d];   // b[q] = r[(q - i0) & 3]
+        float c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = i1 ? b[(q + 2) & 3] : b[q];                     // c[q] = r[(q - i) & 3]
+        // out[p] = r[(i - p) & 3] = c[(2 i - p) & 3]: for even i c[(-p) & 3], for odd i c[(2 - p) & 3]
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) out[4 * pz + d] = i0 ? c[(2 - pz) & 3] : c[(4 - pz) & 3];
+    }
+    return out;
+}
+
 // This lane's 16 interpolated feature channels (16h .. 16h+15) of the sample at (px,py,pz): the three bilinear plane samples
 // and their mean (renderer.py:68-81, triplane.py:530), gathered straight from the planes (per-lane L1 gathers).
-template <typename RSRC>
+template <bool QUADG = false, typename RSRC>
 P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px, float py, float pz,
                                    bool live) {
     const int h = __lane_id() >> 5;
@@ -242,7 +316,8 @@ P3D_DEV f32x16 p3d_gather_features(RSRC rs, const P3dPlaneGeom& g, const P3dDeco
     p3d_tap_offsets(g, 0u, chan_off, qx, qy, of, wg, live);
     p3d_tap_offsets(g, g.plane_bytes, chan_off, qx, qz, of + 4, wg + 4, live);
     p3d_tap_offsets(g, 2u * g.plane_bytes, chan_off, g2x, g2y, of + 8, wg + 8, live);
-    return p3d_fold_taps(wg, [&](int k) { return p3d_load16(rs, of[k]); });
+    if constexpr (QUADG) return p3d_quad_transpose(p3d_fold_taps<true>(wg, [&](int k) { return p3d_load16_quad(rs, of[k]); }));
+    else return p3d_fold_taps(wg, [&](int k) { return p3d_load16(rs, of[k]); });
 }
 
 // ---- LDS-staged gather for the regular-grid query (north_star's "LDS-staged plane tiles") -------------------------------
@@ -411,10 +486,10 @@ template <bool WANT_RGB>
 P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
                                  f32x16& rgb);
 
-template <bool WANT_RGB, typename RSRC>
+template <bool WANT_RGB, bool QUADG = false, typename RSRC>
 P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                              float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
-    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
+    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);
     p3d_decode_features<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
 }
 
@@ -526,10 +601,10 @@ template <bool WANT_RGB>
 P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
                                       f32x16& rgb);
 
-template <bool WANT_RGB = true, typename RSRC>
+template <bool WANT_RGB = true, bool QUADG = false, typename RSRC>
 P3D_DEV void p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                                   float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
-    const f32x16 X = p3d_gather_features(rs, g, cfg, px, py, pz, live);
+    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);
     p3d_decode_features_fast<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
 }
 

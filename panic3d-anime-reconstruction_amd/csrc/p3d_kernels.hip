@@ -22,6 +22,14 @@
 
 #define P3D_WAVES_PER_WG 4
 #define P3D_RENDER_WAVES 4  // k_render workgroup (two workgroups per CU -> two waves per SIMD)
+// Quad-cooperative gathers (p3d_decode.hpp) are used where the decoder is the cheap one — the tolerance-mode final pass of k_render
+// (512^2 x (48+48): canonical 2.22 -> 2.12 ms, surface 2.93 -> 2.65, every sample decoded 4.95 -> 4.10) and the tolerance-mode
+// point / grid query (512^3 direct 12.4 -> 10.2 ms) — and not with the exact decoders, which are bound by VALU / f32-MFMA issue
+// and lose to the extra ~110 VALU instructions per sample (k_render exact 5.57 -> 6.23 ms, grid 12.7 -> 15.6), nor in the
+// density-only coarse pass of the tolerance kernel (2.17 vs 2.12 ms).
+#ifndef P3D_QUAD_COARSE
+#define P3D_QUAD_COARSE 0
+#endif
 #ifndef P3D_RENDER_OCC
 #define P3D_RENDER_OCC 2    // waves per SIMD the register allocation of k_render is held to (launch_bounds) and the host packs for
 #endif
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
             float sigma = -1000.0f;
             f32x16 rgb;
             if (t.any) {
-                if constexpr (FASTD) p3d_decode_wave_fast<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
+                if constexpr (FASTD) p3d_decode_wave_fast<WANT_RGB, true>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
                 else p3d_decode_wave<WANT_RGB>(lds, resource(t.n), g, p.cfg, t.px, t.py, t.pz, sigma, rgb, !t.skip);
             }
             finish(t, sigma, rgb);
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             }
             if (!skip) {
                 f32x16 dummy;
-                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                p3d_decode_wave<false, FAST && (P3D_QUAD_COARSE != 0)>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
             }
             if (early) {  // a lane whose gathers were suppressed (dead ray) decoded garbage: its sample is NOT known to be masked
                 mword |= (cropped || (live && sigma == P3D_SIGMA_MASKED)) ? (1u << (i & 31)) : 0u;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             const bool live = have && !known;
             bool skipped = true;
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
-                if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                if constexpr (FAST) p3d_decode_wave_fast<true, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
                 skipped = !live;  // per lane: a lane whose gathers were suppressed has no colour
@@ -718,14 +726,14 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
                 if (__builtin_amdgcn_ballot_w64(marching && prev_skipped && w != 0.0f) != 0) {
                     float s2;
                     f32x16 c2;
-                    if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                    if constexpr (FAST) p3d_decode_wave_fast<true, true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
                     else p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
                     if (prev_skipped) prev_rgb = c2;
                     prev_skipped = false;
                 }
                 if (__builtin_amdgcn_ballot_w64(marching && skipped && w != 0.0f) != 0) {
                     float s2;
-                    if constexpr (FAST) p3d_decode_wave_fast(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                    if constexpr (FAST) p3d_decode_wave_fast<true, true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
                     else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
                     skipped = false;
                 }
