@@ -464,7 +464,7 @@ DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, co
 // the weight pieces of one chunk (hi and lo) straight from L2 into LDS (buffer_load_dwordx4 ... lds: wave-uniform LDS base +
 // lane * 16, which is exactly the [piece] order of the image) — no staging registers; out-of-range pieces arrive as zeros
 template <int NT>
-DEV void conv_glds_w2(const ConvParams& p, const ConvStagePlanH& pl, char* ws, int tid, int ic0, int ic_end) {
+DEV void conv_glds_w2(const ConvParams& p, const ConvStagePlanH& pl, char* ws, int tid, int ic0, int ic_end, int which = 2 /* 0 hi, 1 lo, 2 both */) {
     const int left = ic_end > ic0 ? ic_end - ic0 : 0;
     auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wh + (size_t)ic0 * 2), 0,
                                                 left ? (p.O * NT * p.I - ic0) * 2 : 0, CONV_RSRC_FLAGS);
@@ -476,8 +476,8 @@ DEV void conv_glds_w2(const ConvParams& p, const ConvStagePlanH& pl, char* ws, i
         const int q = tid + u * 256;
         if (q < NT * 128) {
             char* dst = ws + ((tid & ~63) + u * 256) * 16;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, pl.woff[u], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr)(dst + NT * 128 * 16), 16, pl.woff[u], 0, 0, 0);
+            if (which != 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, pl.woff[u], 0, 0, 0);
+            if (which != 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr)(dst + NT * 128 * 16), 16, pl.woff[u], 0, 0, 0);
         }
     }
 }
@@ -833,9 +833,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
         if (more) conv_gload_h<SPLIT ? 0 : NT, false>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
         const char* wb = ws[SPLIT ? 0 : buf] + wlane;
-#pragma unroll
-        for (int pass = 0; pass < (SPLIT ? 3 : 1); ++pass) {  // SPLIT: a_lo*b_hi, a_hi*b_lo, a_hi*b_hi
-            const int aoff = (SPLIT && pass == 0) ? WBYTES : 0, boff = (SPLIT && pass == 1) ? HX_BYTES : 0;
+        auto run_pass = [&](int aoff, int boff) {
             f16x8 bq[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -851,17 +849,27 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[t][BO[q]], acc[PH[q]][t], 0, 0, 0);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        };
         if constexpr (SPLIT) {
+            // as in k_modconv_w2: the two halves of the single-buffered weight image are re-loaded under MFMAs
+            run_pass(0, HX_BYTES);   // a_hi x b_lo
+            run_pass(0, 0);          // a_hi x b_hi
+            __builtin_amdgcn_sched_barrier(0);
             if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg);
-            __syncthreads();  // everybody is done with the (single-buffered) weights
-            if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end);
             __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();         // a_hi is free, a_lo (requested before this chunk's first pass) has landed everywhere
+            if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end, 0);
+            run_pass(WBYTES, 0);     // a_lo x b_hi
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();         // a_lo and this patch buffer are free, a_hi(next) has landed
+            if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end, 1);
         } else {
+            run_pass(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if (more) conv_lstore_h<NT>(xs[buf ^ 1], ws[buf ^ 1], tid, pl, rg);
+            __syncthreads();
         }
-        __syncthreads();
         buf ^= 1;
     }
     float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
