@@ -17,7 +17,8 @@ w0, b0, w1, b1 = torch.randn(64, 32, generator=g), torch.randn(64, generator=g) 
 w1[0] *= 30.0; b1[0] = -45.0
 mlp = ops.prescale_mlp(*(t.to(dev) for t in (w0, b0, w1, b1)), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
 ro = dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=Sc, depth_resolution_importance=Sf, white_back=True, use_triplane=1)
-opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+EXACT = "--exact" in sys.argv  # exact-contract final pass (default: the renderer's default, tolerance mode)
+opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True, fast_color=not EXACT)
 labels = torch.stack([cameras.camera_label(0.0, 30.0 * i, 1.0, 30.0) for i in range(N)]).to(dev)
 o, d = cameras.rays_from_label(labels, res)
 R = res * res
@@ -49,6 +50,6 @@ with torch.no_grad():
     for _ in range(K):
         ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
     t3 = sync()
-print(json.dumps({"config": "c2", "batch": N, "rays_per_image": R, "samples": [Sc, Sf], "ms_backbone_plus_render": (t1 - t0) / K * 1e3,
+print(json.dumps({"config": "c2", "final_pass": "exact" if EXACT else "tolerance", "batch": N, "rays_per_image": R, "samples": [Sc, Sf], "ms_backbone_plus_render": (t1 - t0) / K * 1e3,
                   "ms_render_only": (t3 - t2) / K * 1e3, "rays_per_s_render_only": N * R / ((t3 - t2) / K),
                   "rays_per_s_incl_backbone": N * R / ((t1 - t0) / K), "wsum_mean": float(out[2].mean())}))

@@ -15,6 +15,7 @@ import numpy as np, torch, torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=120)
 ap.add_argument("--res", type=int, default=512)
+ap.add_argument("--exact", action="store_true", help="exact-contract final pass (default: the renderer's default, tolerance mode)")
 ap.add_argument("--batch", type=int, default=1, help="views per launch (planes shared by the batch: P3D_FLAG_SHARED_PLANES)")
 ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered [views,4,res,res] tensor: every view draws from "
                 "its own seeded generator (the reference seeds each view: _train/eg3dc/util/eg3dc_v0.py:72), so the hash must be the "
@@ -36,7 +37,7 @@ w0, b0, w1, b1 = torch.randn(64, 32, generator=g), torch.randn(64, generator=g) 
 w1[0] *= 30.0; b1[0] = -45.0
 mlp = ops.prescale_mlp(*(t.to(dev) for t in (w0, b0, w1, b1)), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
 ro = dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=48, depth_resolution_importance=48, white_back=True, use_triplane=1)
-opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True, fast_color=not a.exact)
 res, R = a.res, a.res * a.res
 azims = np.linspace(0, 360, a.views + 1)[:-1]
 labels = torch.stack([cameras.camera_label(0.0, float(az), 1.0, 30.0) for az in azims]).to(dev)  # host camera maths, once
@@ -79,7 +80,7 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
 if rank == 0:
     assert frames.shape == (a.views, 4, res, res)
-    out = {"config": "c4", "views": a.views, "res": res, "batch": a.batch, "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
+    out = {"config": "c4", "views": a.views, "res": res, "batch": a.batch, "final_pass": "exact" if a.exact else "tolerance", "n_gpus": world, "seconds": dt, "views_per_s": a.views / dt,
            "rays_per_s": a.views * R / dt, "alpha_mean": float(frames[:, 3].mean())}
     if a.check:
         import hashlib
