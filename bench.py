@@ -347,7 +347,11 @@ def main():
         out = {
             "metric": "rendered rays/sec at 512^2 img x 96 samples/ray", "value": rays / dt, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # every stored value, the coarse pass, the importance resampling and all accumulation are f32 (transmittance f64); in the
+            # default launch the final-pass MLP feeds the f16 matrix cores with two-term (hi + lo, ~22-bit) operands
+            "dtype": "f32" if not fast else "f32 (final-pass MLP operands as two-term f16, f32 accumulate; --exact: f32 throughout)",
+            "data": "synthetic",
             "config": {"workload": f"c3 [{a.scene} scene]: {res}x{res} rays/view, {Sc}+{Sf} samples/ray, one view per GPU per step, "
                                    + ("SURVEY 8(d) inputs: randn planes seed 0 [1,3,32,256,256], OSGDecoder under torch.manual_seed(0) "
                                       "(an EMPTY volume under cull 0.5)" if a.scene == "canonical" else
