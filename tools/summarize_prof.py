@@ -68,7 +68,9 @@ def main():
                 b["gpu_active_clocks"] = clk
                 if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
                     b["tcp_lookups_per_clk_per_cu"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (clk * N_CU)
-                    b["tcp_lookups_peak_measured"] = 1.6
+                    # what tools/ubench/l1_gather sustains at this kernel's occupancy (8 waves per CU): per-lane gathers of the
+                    # kernel's layout 1.0 lane-requests per clk per CU, a quad on one texel 4.1, lane-random 16-byte pieces 2.7
+                    b["tcp_lookups_ubench_per_clk_per_cu"] = {"per_lane_layout": 1.0, "quad_on_one_texel": 4.1, "random_pieces": 2.7}
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
                     b["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (clk * N_SIMD)
                 if "SQ_INSTS_VALU" in c:
