@@ -482,20 +482,25 @@ P3D_DEV float p3d_apply_masks(const P3dDecodeCfg& cfg, float px, float pz, float
 }
 
 // The decoder on already gathered features X (this lane's 16 channels), then the masks.
-template <bool WANT_RGB>
-P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
-                                 f32x16& rgb);
+// LAZY: colour on demand.  A sample's colour enters the result only through the two interval weights next to it, and a masked
+// sample (sigma = -1000 after crop / cull) has exactly-zero weights unless a neighbour's sigma is >= ~794 — which the marcher
+// checks on the exact weights and answers with a colour decode after all (k_render's `skipped` guards).  So when NO live lane
+// of the wave has an unmasked sigma, layer 2 and the 16 sigmoids are skipped: the function returns false and rgb is not
+// written.  (Wave-uniform decision: in an empty or culled region every final-pass step takes this exit.)
+template <bool WANT_RGB, bool LAZY = false>
+P3D_DEV bool p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                 f32x16& rgb, bool live = true);
 
-template <bool WANT_RGB, bool QUADG = false, typename RSRC>
-P3D_DEV void p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
+template <bool WANT_RGB, bool QUADG = false, bool LAZY = false, typename RSRC>
+P3D_DEV bool p3d_decode_wave(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                              float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
     const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);
-    p3d_decode_features<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
+    return p3d_decode_features<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);
 }
 
-template <bool WANT_RGB>
-P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
-                                 f32x16& rgb) {
+template <bool WANT_RGB, bool LAZY>
+P3D_DEV bool p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                 f32x16& rgb, bool live) {
     const int lane = __lane_id();
     const int h = lane >> 5;
 
@@ -539,7 +544,11 @@ P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) sa = p3d_fma(w[e], acc1[4 * s4 + e], sa);
     }
-    float sigma = sa + p3d_partner(sa);
+    const float sigma = p3d_apply_masks(cfg, px, pz, sa + p3d_partner(sa));
+    sigma_out = sigma;
+    if constexpr (LAZY) {
+        if (__builtin_amdgcn_ballot_w64(live && sigma != P3D_SIGMA_MASKED) == 0) return false;
+    }
 
     if (WANT_RGB) {  // ---- layer 2 rows 1..32 on the matrix cores + sigmoid (triplane.py:539-542)
         const f32x4* b1p = (const f32x4*)(lds + P3D_LDS_B1P + h * 16);
@@ -565,7 +574,7 @@ P3D_DEV void p3d_decode_features(const float* lds, const P3dDecodeCfg& cfg, cons
             rgb[r] = fs ? sg : sg * 1.002f - 0.001f;
         }
     }
-    sigma_out = p3d_apply_masks(cfg, px, pz, sigma);
+    return WANT_RGB;
 }
 
 // ---- tolerance-mode decode (P3D_FLAG_FAST_COLOR, final pass only) -----------------------------------------------------
@@ -597,20 +606,20 @@ P3D_DEV float p3d_sigmoid_hw(float x) {
 // Same interface and lane layout as p3d_decode_wave<true>; lds must also hold the f16 images (p3d_load_mlp_f16_to_lds).
 // Domain: |interpolated feature| and hidden activations below the f16 range (65504); results agree with the exact decode to
 // ~1e-6 (sigma, relative to the magnitude of the sum's terms) / ~3e-7 (colours).
-template <bool WANT_RGB>
-P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
-                                      f32x16& rgb);
+template <bool WANT_RGB, bool LAZY = false>
+P3D_DEV bool p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                      f32x16& rgb, bool live = true);
 
-template <bool WANT_RGB = true, bool QUADG = false, typename RSRC>
-P3D_DEV void p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
+template <bool WANT_RGB = true, bool QUADG = false, bool LAZY = false, typename RSRC>
+P3D_DEV bool p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                                   float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
     const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);
-    p3d_decode_features_fast<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);
+    return p3d_decode_features_fast<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);
 }
 
-template <bool WANT_RGB>
-P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
-                                      f32x16& rgb) {
+template <bool WANT_RGB, bool LAZY>
+P3D_DEV bool p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
+                                      f32x16& rgb, bool live) {
     const int lane = __lane_id();
     const int h = lane >> 5;
     float xs[16];
@@ -655,6 +664,21 @@ P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg,
         for (int e = 0; e < 4; ++e) sa = p3d_fma(w[e], hs[4 * s4 + e], sa);
     }
     float sigma = sa + p3d_partner(sa);
+    // ---- masks (hardware transcendentals here too)
+    if (cfg.flags & P3D_FLAG_CROP) {
+        if (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit) sigma = P3D_SIGMA_MASKED;
+    }
+    if (cfg.flags & (P3D_FLAG_CULL | P3D_FLAG_BINARIZE)) {
+        float a = 1.0f - __builtin_amdgcn_exp2f(-p3d_softplus_hw(sigma - 1.0f) * P3D_LOG2E);
+        if (cfg.flags & P3D_FLAG_BINARIZE)
+            sigma = (a < cfg.cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
+        else if (a < cfg.cull_thresh)
+            sigma = P3D_SIGMA_MASKED;
+    }
+    sigma_out = sigma;
+    if constexpr (LAZY) {
+        if (__builtin_amdgcn_ballot_w64(live && sigma != P3D_SIGMA_MASKED) == 0) return false;
+    }
     // ---- layer 2 rows 1..32: K = 64 as four chunks (t, pp): lane (j,h) supplies neurons 32t + rowof(8pp + i) + 4h
     if constexpr (WANT_RGB) {
         const f32x4* b1p = (const f32x4*)(lds + P3D_LDS_B1P + h * 16);
@@ -677,16 +701,5 @@ P3D_DEV void p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg,
             rgb[r] = fs ? sg : sg * 1.002f - 0.001f;
         }
     }
-    // ---- masks (hardware transcendentals here too)
-    if (cfg.flags & P3D_FLAG_CROP) {
-        if (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit) sigma = P3D_SIGMA_MASKED;
-    }
-    if (cfg.flags & (P3D_FLAG_CULL | P3D_FLAG_BINARIZE)) {
-        float a = 1.0f - __builtin_amdgcn_exp2f(-p3d_softplus_hw(sigma - 1.0f) * P3D_LOG2E);
-        if (cfg.flags & P3D_FLAG_BINARIZE)
-            sigma = (a < cfg.cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
-        else if (a < cfg.cull_thresh)
-            sigma = P3D_SIGMA_MASKED;
-    }
-    sigma_out = sigma;
+    return WANT_RGB;
 }

@@ -707,10 +707,11 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             const bool live = have && !known;
             bool skipped = true;
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
-                if constexpr (FAST) p3d_decode_wave_fast<true, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
-                else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                bool have_rgb;  // EARLY: colour on demand (p3d_decode.hpp, LAZY): a step whose live samples are all masked has none
+                if constexpr (FAST) have_rgb = p3d_decode_wave_fast<true, true, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                else have_rgb = p3d_decode_wave<true, false, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
-                skipped = !live;  // per lane: a lane whose gathers were suppressed has no colour
+                skipped = !live || !have_rgb;  // per lane: a lane whose gathers were suppressed has no colour
                 if (known) sigma = P3D_SIGMA_MASKED;
             }
             if constexpr (DUMP) {

@@ -29,12 +29,12 @@ def patch(path, pairs):
     open(path, "w").write(s)
 
 DECODE = [
-    ('template <bool WANT_RGB, bool QUADG = false, typename RSRC>\nP3D_DEV void p3d_decode_wave(const float* lds, RSRC rs,',
-     '__device__ unsigned long long g_phase[17];\n#define P3D_T() __builtin_amdgcn_s_memtime()\nP3D_DEV unsigned long long* p3d_phase_slots() {\n    __shared__ unsigned long long slots[8][16];\n    return slots[(threadIdx.x >> 6) & 7];\n}\ntemplate <bool WANT_RGB, bool QUADG = false, typename RSRC>\nP3D_DEV void p3d_decode_wave(const float* lds, RSRC rs,'),
-    ('    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_decode_features<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);\n',
-     '    const unsigned long long t0 = P3D_T();\n    f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_pin16(X);\n    const unsigned long long t1 = P3D_T();\n    p3d_decode_features<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);\n    asm volatile("" : "+v"(sigma_out));\n    const unsigned long long t2 = P3D_T();\n    if (__lane_id() == 0) { unsigned long long* sl = p3d_phase_slots(); sl[WANT_RGB ? 2 : 0] += t1 - t0; sl[WANT_RGB ? 3 : 1] += t2 - t1; sl[WANT_RGB ? 5 : 4] += 1ull; }\n'),
-    ('    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_decode_features_fast<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);\n',
-     '    const unsigned long long t0 = P3D_T();\n    f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_pin16(X);\n    const unsigned long long t1 = P3D_T();\n    p3d_decode_features_fast<WANT_RGB>(lds, cfg, X, px, pz, sigma_out, rgb);\n    asm volatile("" : "+v"(sigma_out));\n    const unsigned long long t2 = P3D_T();\n    if (__lane_id() == 0) { unsigned long long* sl = p3d_phase_slots(); sl[2] += t1 - t0; sl[3] += t2 - t1; sl[5] += 1ull; }\n'),
+    ('template <bool WANT_RGB, bool QUADG = false, bool LAZY = false, typename RSRC>\nP3D_DEV bool p3d_decode_wave(const float* lds, RSRC rs,',
+     '__device__ unsigned long long g_phase[17];\n#define P3D_T() __builtin_amdgcn_s_memtime()\nP3D_DEV unsigned long long* p3d_phase_slots() {\n    __shared__ unsigned long long slots[8][16];\n    return slots[(threadIdx.x >> 6) & 7];\n}\ntemplate <bool WANT_RGB, bool QUADG = false, bool LAZY = false, typename RSRC>\nP3D_DEV bool p3d_decode_wave(const float* lds, RSRC rs,'),
+    ('    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    return p3d_decode_features<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);\n',
+     '    const unsigned long long t0 = P3D_T();\n    f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_pin16(X);\n    const unsigned long long t1 = P3D_T();\n    const bool have_ = p3d_decode_features<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);\n    asm volatile("" : "+v"(sigma_out));\n    const unsigned long long t2 = P3D_T();\n    if (__lane_id() == 0) { unsigned long long* sl = p3d_phase_slots(); sl[WANT_RGB ? 2 : 0] += t1 - t0; sl[WANT_RGB ? 3 : 1] += t2 - t1; sl[WANT_RGB ? 5 : 4] += 1ull; }\n    return have_;\n'),
+    ('    const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    return p3d_decode_features_fast<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);\n',
+     '    const unsigned long long t0 = P3D_T();\n    f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);\n    p3d_pin16(X);\n    const unsigned long long t1 = P3D_T();\n    const bool have_ = p3d_decode_features_fast<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);\n    asm volatile("" : "+v"(sigma_out));\n    const unsigned long long t2 = P3D_T();\n    if (__lane_id() == 0) { unsigned long long* sl = p3d_phase_slots(); sl[2] += t1 - t0; sl[3] += t2 - t1; sl[5] += 1ull; }\n    return have_;\n'),
 ]
 KERNELS = [
     ('    extern __shared__ __attribute__((aligned(16))) float lds[];\n    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);\n    if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);',
