@@ -266,37 +266,47 @@ P3D_DEV f32x16 p3d_load16_quad(RSRC rs, uint32_t off) {
 }
 
 // in: [4 r + d] = channels 4 i + d of sample r (lane i of the quad); out: [4 p + d] = channels 4 p + d of this lane's sample.
-// rotate the rows by the lane index (selects), move row q from lane (i - q) & 3 (one DPP each), rotate back.
+// rotate the rows by the lane index, move row q from lane (i - q) & 3 (one DPP each), rotate back.  The lane-dependent
+// selects are written as bit-field inserts under per-lane masks ((m & a) | (~m & b) = one v_bfi / v_bitop3 each): as `?:` on
+// lane predicates the optimiser re-derived them into compare-and-select chains on the lane index — 700 instructions per
+// sample instead of 76 (seen in the ISA of the first version).
+P3D_DEV uint32_t p3d_bsel(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }  // m ? a : b, m = 0 or ~0
 P3D_DEV f32x16 p3d_quad_transpose(const f32x16& in) {
     const uint32_t i = (uint32_t)__lane_id() & 3u;
-    const bool i0 = (i & 1u) != 0u, i1 = (i & 2u) != 0u;
-    f32x16 y, r, out;
+    uint32_t m0 = 0u - (i & 1u), m1 = 0u - ((i >> 1) & 1u);
+    asm volatile("" : "+v"(m0), "+v"(m1));  // opaque: keep them masks
+    uint32_t x[16], y[16], r[16];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {  // y[q] = in[(i + q) & 3]
-        float b[4];
+    for (int c = 0; c < 16; ++c) {
+        const float f = in[c];  // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this clang)
+        x[c] = __builtin_bit_cast(uint32_t, f);
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = i0 ? in[4 * ((q + 1) & 3) + d] : in[4 * q + d];
+    for (int d = 0; d < 4; ++d) {  // y[q] = x[(i + q) & 3]
+        uint32_t b[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[4 * q + d] = i1 ? b[(q + 2) & 3] : b[q];
+        for (int q = 0; q < 4; ++q) b[q] = p3d_bsel(m0, x[4 * ((q + 1) & 3) + d], x[4 * q + d]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[4 * q + d] = p3d_bsel(m1, b[(q + 2) & 3], b[q]);
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {  // r[q] (lane i) = y[q] of lane (i - q) & 3  =  channels piece (i - q) & 3 of sample i
         r[d] = y[d];
-        r[4 + d] = p3d_quad_f<0x93>(y[4 + d]);   // lanes 0..3 read 3, 0, 1, 2
-        r[8 + d] = p3d_quad_f<0x4e>(y[8 + d]);   // 2, 3, 0, 1
-        r[12 + d] = p3d_quad_f<0x39>(y[12 + d]); // 1, 2, 3, 0
+        r[4 + d] = p3d_quad_u<0x93>(y[4 + d]);   // lanes 0..3 read 3, 0, 1, 2
+        r[8 + d] = p3d_quad_u<0x4e>(y[8 + d]);   // 2, 3, 0, 1
+        r[12 + d] = p3d_quad_u<0x39>(y[12 + d]); // 1, 2, 3, 0
     }
+    f32x16 out;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {  // out[p] = r[(i - p) & 3]
-        float b[4];
+        uint32_t b[4], c[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = i0 ? r[4 * ((q + 3) & 3) + d] : r[4 * q + d];   // b[q] = r[(q - i0) & 3]
-        float c[4];
+        for (int q = 0; q < 4; ++q) b[q] = p3d_bsel(m0, r[4 * ((q + 3) & 3) + d], r[4 * q + d]);   // b[q] = r[(q - i0) & 3]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = i1 ? b[(q + 2) & 3] : b[q];                     // c[q] = r[(q - i) & 3]
+        for (int q = 0; q < 4; ++q) c[q] = p3d_bsel(m1, b[(q + 2) & 3], b[q]);                     // c[q] = r[(q - i) & 3]
         // out[p] = r[(i - p) & 3] = c[(2 i - p) & 3]: for even i c[(-p) & 3], for odd i c[(2 - p) & 3]
 #pragma unroll
-        for (int pz = 0; pz < 4; ++pz) out[4 * pz + d] = i0 ? c[(2 - pz) & 3] : c[(4 - pz) & 3];
+        for (int pz = 0; pz < 4; ++pz) out[4 * pz + d] = __builtin_bit_cast(float, p3d_bsel(m0, c[(2 - pz) & 3], c[(4 - pz) & 3]));
     }
     return out;
 }
