@@ -22,13 +22,15 @@
 
 #define P3D_WAVES_PER_WG 4
 #define P3D_RENDER_WAVES 4  // k_render workgroup (two workgroups per CU -> two waves per SIMD)
-// Quad-cooperative gathers (p3d_decode.hpp) are used where the decoder is the cheap one — the tolerance-mode final pass of k_render
-// (512^2 x (48+48): canonical 2.22 -> 2.12 ms, surface 2.93 -> 2.65, every sample decoded 4.95 -> 4.10) and the tolerance-mode
-// point / grid query (512^3 direct 12.4 -> 10.2 ms) — and not with the exact decoders, which are bound by VALU / f32-MFMA issue
-// and lose to the extra ~110 VALU instructions per sample (k_render exact 5.57 -> 6.23 ms, grid 12.7 -> 15.6), nor in the
-// density-only coarse pass of the tolerance kernel (2.17 vs 2.12 ms).
+// Quad-cooperative gathers (p3d_decode.hpp) in k_render: every decode of both kernels (measured with the 76-instruction transpose,
+// 512^2 x (48+48), canonical / surface ms: tolerance kernel 1.99 / 2.62 -> 1.61 / 2.13 with them in the final AND the coarse pass
+// (final only: 1.78 / 2.22); exact kernel 2.32 / 3.33 -> 1.93 / 3.09 (final only 2.09 / 3.16); every sample decoded 3.39 / 5.16).
+// Not in the exact point / grid query (density-only decoder: 12.75 vs 12.65 ms at 512^3); yes in the tolerance one (10.2 -> 7.7).
 #ifndef P3D_QUAD_COARSE
-#define P3D_QUAD_COARSE 0
+#define P3D_QUAD_COARSE 1
+#endif
+#ifndef P3D_QUAD_EXACT
+#define P3D_QUAD_EXACT 1
 #endif
 #ifndef P3D_RENDER_OCC
 #define P3D_RENDER_OCC 2    // waves per SIMD the register allocation of k_render is held to (launch_bounds) and the host packs for
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             }
             if (!skip) {
                 f32x16 dummy;
-                p3d_decode_wave<false, FAST && (P3D_QUAD_COARSE != 0)>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                p3d_decode_wave<false, (FAST || P3D_QUAD_EXACT != 0) && (P3D_QUAD_COARSE != 0)>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
             }
             if (early) {  // a lane whose gathers were suppressed (dead ray) decoded garbage: its sample is NOT known to be masked
                 mword |= (cropped || (live && sigma == P3D_SIGMA_MASKED)) ? (1u << (i & 31)) : 0u;
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
                 bool have_rgb;  // EARLY: colour on demand (p3d_decode.hpp, LAZY): a step whose live samples are all masked has none
                 if constexpr (FAST) have_rgb = p3d_decode_wave_fast<true, true, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
-                else have_rgb = p3d_decode_wave<true, false, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                else have_rgb = p3d_decode_wave<true, P3D_QUAD_EXACT != 0, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
                 skipped = !live || !have_rgb;  // per lane: a lane whose gathers were suppressed has no colour
                 if (known) sigma = P3D_SIGMA_MASKED;
@@ -1389,7 +1391,9 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     // Measured at 512^3: the exact decoder is ALU-bound and the direct gathers are L1-service-bound at the SAME
     // level, so staging pays only together with the cheap decoder; it is therefore on only in the tolerance mode.
     const bool fastd = (opts->flags & P3D_FLAG_FAST_COLOR) != 0;
-    const bool staged = fastd ? !(opts->flags & P3D_FLAG_NO_STAGING) : (opts->flags & P3D_FLAG_FORCE_STAGING) != 0;
+    // LDS-staged texel boxes only on request: with quad-cooperative gathers the direct tolerance query is faster (512^3: 7.7 ms
+    // direct, 10.0 staged; exact: 12.7 direct, 22.8 staged); P3D_FLAG_NO_STAGING is accepted and has nothing left to switch off
+    const bool staged = (opts->flags & P3D_FLAG_FORCE_STAGING) != 0;
     const size_t lds_bytes = (size_t)((fastd ? P3D_LDS_FAST_FLOATS - P3D_LDS_B0P : P3D_LDS_MLP_FLOATS) + 4 +
                                       (staged ? P3D_WAVES_PER_WG * P3D_BOX_FLOATS_PER_WAVE : 0)) * 4;
     hipError_t e = hipSuccess;

@@ -144,7 +144,7 @@ def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, cr
         opts = _with_flag(opts, _lib.P3D_FLAG_SKIP_CROPPED)
     if fast:  # tolerance-mode decoder (f16 two-term MFMA + hardware transcendentals): sigma to ~1e-6 of the exact contract
         opts = _with_flag(opts, _lib.P3D_FLAG_FAST_COLOR)
-    if staged is not None:  # default: texel boxes staged through LDS with the tolerance-mode decoder, direct gathers with the exact one
+    if staged is not None:  # default: direct (quad-cooperative / per-lane) gathers; staged=True: texel boxes through LDS (same bits)
         opts = _with_flag(opts, (_lib.P3D_FLAG_FORCE_STAGING if staged else _lib.P3D_FLAG_NO_STAGING))
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
     if planes_nhwc.shape[0] != 1:
