@@ -32,6 +32,9 @@
 #ifndef P3D_QUAD_EXACT
 #define P3D_QUAD_EXACT 1
 #endif
+#ifndef P3D_QUAD_PAIR
+#define P3D_QUAD_PAIR 1     // ... and in the small-launch kernel k_render_pair
+#endif
 #ifndef P3D_RENDER_OCC
 #define P3D_RENDER_OCC 2    // waves per SIMD the register allocation of k_render is held to (launch_bounds) and the host packs for
 #endif
@@ -895,7 +898,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             }
             if (!skip) {
                 f32x16 dummy;
-                p3d_decode_wave<false>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                p3d_decode_wave<false, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
                 ndec += 1;
             }
             const float so = partner(sigma);
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
                 skipped = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skipped) {
-                p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                p3d_decode_wave<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 ndec += 1;
                 skipped = !live;
             }
