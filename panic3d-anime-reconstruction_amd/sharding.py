@@ -69,8 +69,8 @@ class FrameGather:
     """The same true gather, streamed: every rank renders `per_rank` frames into its own stack and hands finished slices
     [lo, hi) to `push` while it keeps rendering — the transfers run on the collective's own stream (RCCL over xGMI) under the
     next slices' kernels, and `finish` only waits for what is still in flight.  Rank `dst` ends with [world * per_rank, ...]
-    in rank order (`out`), written in place (no staging copy); every message is exactly the pushed slice; every rank must
-    push the same [lo, hi) sequence.  With 8 ranks at 512^2 x RGBA fp32 this hides 5.9 GB of inbound frames per 200-view sweep
+    in rank order (`out`), written in place (no staging copy); every slice is one asynchronous `gather` (only dst receives);
+    every rank must push the same [lo, hi) sequence.  With 8 ranks at 512^2 x RGBA fp32 this hides 5.9 GB of inbound frames per 200-view sweep
     behind rendering instead of paying them after it."""
 
     def __init__(self, local, per_rank, dst=0):
@@ -89,14 +89,24 @@ class FrameGather:
         """Frames [lo, hi) of every rank's stack are final: start moving them."""
         if not (0 <= lo < hi <= self.per_rank):
             raise ValueError(f"slice [{lo}, {hi}) outside [0, {self.per_rank})")
+        if not self.active or self.world == 1:
+            if self.out is not None:
+                self.out[lo:hi].copy_(self.local[lo:hi])
+            return
+        # one `gather` per slice on the default communicator (RCCL: the root receives, every other rank sends its slice once),
+        # asynchronous: it runs on the collective's stream, this rank's render stream goes on
+        dests = [self.out[r * self.per_rank + lo:r * self.per_rank + hi] for r in range(self.world)] if self.rank == self.dst else None
+        if not getattr(self, "p2p", False):
+            try:
+                self.pending.append(dist.gather(self.local[lo:hi], gather_list=dests, dst=self.dst, async_op=True))
+                return
+            except (NotImplementedError, TypeError, ValueError):  # argument-level refusal (the same on every rank): batched P2P instead
+                self.p2p = True
         if self.rank != self.dst:
             self.pending += dist.batch_isend_irecv([dist.P2POp(dist.isend, self.local[lo:hi], self.dst)])
             return
-        ops_ = [dist.P2POp(dist.irecv, self.out[r * self.per_rank + lo:r * self.per_rank + hi], r)
-                for r in range(self.world) if r != self.dst]
-        if ops_:
-            self.pending += dist.batch_isend_irecv(ops_)
-        self.out[self.dst * self.per_rank + lo:self.dst * self.per_rank + hi].copy_(self.local[lo:hi])
+        self.pending += dist.batch_isend_irecv([dist.P2POp(dist.irecv, dests[r], r) for r in range(self.world) if r != self.dst])
+        dests[self.dst].copy_(self.local[lo:hi])
 
     def finish(self):
         """Wait for the transfers still in flight; returns the gathered stack on dst, None elsewhere."""
