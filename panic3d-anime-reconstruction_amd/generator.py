@@ -7,6 +7,8 @@ modulated-conv kernel.
 Inference only.  Not mirrored: `sample` (broken in the reference, triplane.py:254-271).  The `paste_front`
 post-process (triplane.py:555-691) lives in paste.py.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -281,6 +283,12 @@ class TriPlaneGenerator(torch.nn.Module):
             ret["image_prepaste"] = ret["image"]
             ret["paste"] = paste_front(self, x, ret, **x["paste_params"])
             ret["image"] = ret["paste"]["image"]
+        if os.environ.get("P3D_CHECK_CONV_DOMAIN"):  # validation runs: did a two-term convolution leave its domain? (synchronises)
+            from . import ops
+            if ops.conv_f16x2_saturated(reset=True):
+                import warnings
+                warnings.warn("a two-term f16 convolution met |s*x| > 8188 and saturated it: use set_conv_mma('f32') for this model",
+                              RuntimeWarning)
         return ret
 
     def set_force_sigmoid(self, state):
