@@ -84,6 +84,7 @@ class FrameGather:
         if self.rank == self.dst:
             self.out = torch.empty((self.world * self.per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         self.pending = []
+        self.p2p = False  # set if the backend refuses gather(): batched point-to-point from then on
 
     def push(self, lo, hi):
         """Frames [lo, hi) of every rank's stack are final: start moving them."""
@@ -96,7 +97,7 @@ class FrameGather:
         # one `gather` per slice on the default communicator (RCCL: the root receives, every other rank sends its slice once),
         # asynchronous: it runs on the collective's stream, this rank's render stream goes on
         dests = [self.out[r * self.per_rank + lo:r * self.per_rank + hi] for r in range(self.world)] if self.rank == self.dst else None
-        if not getattr(self, "p2p", False):
+        if not self.p2p:
             try:
                 self.pending.append(dist.gather(self.local[lo:hi], gather_list=dests, dst=self.dst, async_op=True))
                 return
