@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 3
+#define P3D_ABI_VERSION 4
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -132,6 +132,17 @@ int p3d_render_f32(const float* planes_nhwc, int N, int H, int W, const float* r
                    const float* w1, const float* b1, const p3d_opts* opts, float* out_feat, float* out_depth,
                    float* out_wsum, float* out_xyz, void* workspace, size_t workspace_bytes, const p3d_dumps* dumps,
                    void* stream);
+
+/* The same with PER-RAY depth limits: rendering_options['ray_start'] == ['ray_end'] == 'auto' (renderer.py:165-171).  ray_start,
+ * ray_end [N][R]: the box-intersection limits after the reference's patching of the rays that miss the box (the caller
+ * computes them: cameras.ray_limits_box + renderer.py:167-170); the coarse depths are then math_utils.linspace (:101-118:
+ * start + (i / (Sc - 1)) * (end - start), each operation rounded) + jitter * ((end - start) / (Sc - 1)), and
+ * opts->ray_start / ray_end / depth_delta are not read.  Both NULL = p3d_render_f32. */
+int p3d_render_limits_f32(const float* planes_nhwc, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                          int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
+                          const float* w1, const float* b1, const float* ray_start, const float* ray_end, const p3d_opts* opts,
+                          float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
+                          size_t workspace_bytes, const p3d_dumps* dumps, void* stream);
 
 /* sample_stratified (renderer.py:303-326, numeric ray_start/ray_end branch).  jitter, out [NR][S]. */
 int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta, int S, const float* jitter, int64_t NR,

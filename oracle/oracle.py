@@ -74,7 +74,10 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= FLAG_FORCE_SIGMOID
     if ro.get("white_back", False):
         flags |= FLAG_WHITE_BACK
-    rs, re = float(ro["ray_start"]), float(ro["ray_end"])
+    if ro.get("ray_start") == "auto" and ro.get("ray_end") == "auto":  # per-ray limits go to render(ray_limits=...)
+        rs = re = 0.0
+    else:
+        rs, re = float(ro["ray_start"]), float(ro["ray_end"])
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / (Sc - 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
 
@@ -160,9 +163,11 @@ def unify_perm(depths_coarse, depths_fine):
     return perm
 
 
-def render(planes, rays_o, rays_d, jitter, u, mlp, opts, dumps=False):
+def render(planes, rays_o, rays_d, jitter, u, mlp, opts, dumps=False, ray_limits=None):
     """ImportanceRenderer.forward (renderer.py:162-264) with injected randomness.
-    jitter [N,R,Sc] = the torch.rand_like draw of renderer.py:324; u [N*R,Sf] = the torch.rand draw of :371."""
+    jitter [N,R,Sc] = the torch.rand_like draw of renderer.py:324; u [N*R,Sf] = the torch.rand draw of :371.
+    ray_limits: None, or (ray_start, ray_end) per ray [N,R(,1)] = the 'auto' limits of renderer.py:165-171 (after the patching
+    of the rays that miss the box)."""
     planes, pp = _f(planes)
     rays_o, po = _f(rays_o)
     rays_d, pd = _f(rays_d)
@@ -191,10 +196,14 @@ def render(planes, rays_o, rays_d, jitter, u, mlp, opts, dumps=False):
                  sigma_fine=np.empty((NR, Sf), np.float32), perm=np.empty((NR, Sc + Sf), np.int32),
                  depth_unclamped=np.empty((NR,), np.float32), tminmax=np.empty((2,), np.float32))
         dm = Dumps(*[d[k].ctypes.data_as(C.c_void_p) for k, _ in Dumps._fields_])
-    rc = lib().p3d_oracle_render(pp, N, H, W, po, pd, C.c_long(R), pj, pu, p0, q0, p1, q1, C.byref(opts),
-                                 feat.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
-                                 wsum.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p),
-                                 C.byref(dm) if dm is not None else None)
+    prs = pre = None
+    if ray_limits is not None:
+        (rs_, prs), (re_, pre) = _f(ray_limits[0]), _f(ray_limits[1])
+        assert rs_.size == N * R and re_.size == N * R
+    rc = lib().p3d_oracle_render_limits(pp, N, H, W, po, pd, C.c_long(R), pj, pu, p0, q0, p1, q1, prs, pre, C.byref(opts),
+                                        feat.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                                        wsum.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p),
+                                        C.byref(dm) if dm is not None else None)
     if rc != 0:
         raise RuntimeError(f"p3d_oracle_render failed: {rc}")
     return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)

@@ -216,6 +216,20 @@ static void or_stratified(float start, float end, float delta, int S, const floa
     }
 }
 
+/* renderer.py:317-319 (ray_start / ray_end tensors: the 'auto' limits of :165-171): math_utils.linspace (:101-118) is
+ * start + (arange(S) / (S - 1)) * (stop - start) — an fp32 division, a multiplication and an addition, each rounded — and
+ * depth_delta = (ray_end - ray_start) / (S - 1) per ray. */
+static void or_stratified_limits(float start, float end, int S, const float* jitter, float* t) {
+    const float span = end - start;
+    const float delta = span / (float)(S - 1);
+    for (int i = 0; i < S; ++i) {
+        const float step = (float)i / (float)(S - 1);
+        const float prod = step * span;
+        const float lin = start + prod;
+        t[i] = lin + jitter[i] * delta;
+    }
+}
+
 void p3d_oracle_sample_stratified(float start, float end, float delta, int S, const float* jitter, long NR, float* out) {
 #pragma omp parallel for schedule(static)
     for (long r = 0; r < NR; ++r) or_stratified(start, end, delta, S, jitter + r * S, out + r * S);
@@ -379,10 +393,25 @@ typedef struct { /* optional per-stage dumps; any pointer may be NULL */
 
 /* renderer.py:162-264.  planes [N][3][32][H][W]; rays_o/rays_d [N][R][3]; jitter [N][R][Sc]; u [N*R][Sf].
  * Outputs: feat [N][R][32], depth [N][R], wsum [N][R], xyz [N][R][3]. */
+/* ray_start / ray_end: NULL, or per-ray limits [N][R] (renderer.py:165-171 'auto': get_ray_limits_box + the patching of the
+ * rays that miss the box, both done by the caller) — the scalar limits of `o` are then unused. */
+int p3d_oracle_render_limits(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, long R,
+                             const float* jitter, const float* u, const float* w0, const float* b0, const float* w1,
+                             const float* b1, const float* ray_start, const float* ray_end, const p3d_oracle_opts* o,
+                             float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, const p3d_oracle_dumps* dmp);
+
 int p3d_oracle_render(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, long R,
                       const float* jitter, const float* u, const float* w0, const float* b0, const float* w1,
                       const float* b1, const p3d_oracle_opts* o, float* out_feat, float* out_depth, float* out_wsum,
                       float* out_xyz, const p3d_oracle_dumps* dmp) {
+    return p3d_oracle_render_limits(planes, N, H, W, rays_o, rays_d, R, jitter, u, w0, b0, w1, b1, NULL, NULL, o, out_feat,
+                                    out_depth, out_wsum, out_xyz, dmp);
+}
+
+int p3d_oracle_render_limits(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, long R,
+                             const float* jitter, const float* u, const float* w0, const float* b0, const float* w1,
+                             const float* b1, const float* ray_start, const float* ray_end, const p3d_oracle_opts* o,
+                             float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, const p3d_oracle_dumps* dmp) {
     const int Sc = o->Sc, Sf = o->Sf, S = Sc + Sf, K = 35;
     if (Sc < 4 || Sc > 192 || Sf < 0 || Sf > 192) return -1;
     or_mlp m = {w0, b0, w1, b1};
@@ -399,7 +428,8 @@ int p3d_oracle_render(const float* planes, int N, int H, int W, const float* ray
         const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
         float t[384], sg[384], col[384 * 35], wts[384];
         /* coarse pass: renderer.py:174-206 */
-        or_stratified(o->ray_start, o->ray_end, o->depth_delta, Sc, jitter + r * Sc, t);
+        if (ray_start && ray_end) or_stratified_limits(ray_start[r], ray_end[r], Sc, jitter + r * Sc, t);
+        else or_stratified(o->ray_start, o->ray_end, o->depth_delta, Sc, jitter + r * Sc, t);
         for (int i = 0; i < Sc; ++i) {
             float px = ox + t[i] * dx, py = oy + t[i] * dy, pz = oz + t[i] * dz; /* :179 (mul, then add) */
             or_decode_point(planes_n, H, W, px, py, pz, &m, o->coord_scale, o->plane_mode, o->flags, o->crop_limit,

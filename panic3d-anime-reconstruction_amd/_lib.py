@@ -10,7 +10,7 @@ SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D
 
 P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP, P3D_FLAG_NO_STAGING, P3D_FLAG_FORCE_STAGING = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 3  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 4  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -44,6 +44,8 @@ SIGNATURES = {
     "p3d_render_workspace_bytes": (_Z, [_I, _L, _I, _I]),
     "p3d_render_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
                             _Z, C.POINTER(Dumps), _P]),
+    "p3d_render_limits_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
+                                   _Z, C.POINTER(Dumps), _P]),
     "p3d_sample_stratified_f32": (_I, [_F, _F, _F, _I, _P, _L, _P, _P]),
     "p3d_composite_workspace_bytes": (_Z, [_L, _I, _I]),
     "p3d_depth_minmax_f32": (_I, [_P, _L, _P, _P, _Z, _P]),

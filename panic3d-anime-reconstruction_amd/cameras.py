@@ -80,3 +80,37 @@ def ortho_rays_flat(elev, azim, dist, boxwarp, resolution, device=None):
     o = fr["ray_origins"].permute(0, 2, 3, 1).reshape(1, resolution * resolution, 3).contiguous()
     d = fr["ray_directions"].permute(0, 2, 3, 1).reshape(1, resolution * resolution, 3).contiguous()
     return o, d
+
+
+def ray_limits_box(rays_o, rays_d, box_side_length):
+    """math_utils.get_ray_limits_box (volumetric_rendering/math_utils.py:46-98): entry / exit distance of every ray through the
+    axis-aligned box of side `box_side_length` centred at the origin; (-1, -2) for rays that miss it.  The same fp32
+    operations in the same order (1 / d, (bound - o) * invdir, max / min), as tensor ops: rays [..., 3] -> two [..., 1]."""
+    shape = rays_o.shape
+    o, d = rays_o.detach().reshape(-1, 3), rays_d.detach().reshape(-1, 3)
+    lo = torch.full((1,), -1 * (box_side_length / 2), dtype=o.dtype, device=o.device)
+    hi = torch.full((1,), 1 * (box_side_length / 2), dtype=o.dtype, device=o.device)
+    invdir = 1 / d
+    neg = invdir < 0
+    near, far = torch.where(neg, hi, lo), torch.where(neg, lo, hi)  # bounds[sign], bounds[1 - sign] per axis
+    t0, t1 = (near - o) * invdir, (far - o) * invdir
+    tmin, tmax = t0[:, 0], t1[:, 0]
+    valid = ~((tmin > t1[:, 1]) | (t0[:, 1] > tmax))
+    tmin, tmax = torch.max(tmin, t0[:, 1]), torch.min(tmax, t1[:, 1])
+    valid = valid & ~((tmin > t1[:, 2]) | (t0[:, 2] > tmax))
+    tmin, tmax = torch.max(tmin, t0[:, 2]), torch.min(tmax, t1[:, 2])
+    tmin = torch.where(valid, tmin, torch.full_like(tmin, -1))
+    tmax = torch.where(valid, tmax, torch.full_like(tmax, -2))
+    return tmin.reshape(*shape[:-1], 1), tmax.reshape(*shape[:-1], 1)
+
+
+def patch_ray_limits(ray_start, ray_end):
+    """renderer.py:167-170: rays that miss the box take [min, max] of the valid rays' START distances (sic).  No host
+    synchronisation: with no valid ray at all the limits stay as they are, like the reference's `if torch.any(...)`."""
+    valid = ray_end > ray_start
+    big = torch.finfo(ray_start.dtype).max
+    lo = torch.where(valid, ray_start, torch.full_like(ray_start, big)).min()
+    hi = torch.where(valid, ray_start, torch.full_like(ray_start, -big)).max()
+    some = valid.any()
+    fix = (~valid) & some
+    return torch.where(fix, lo, ray_start), torch.where(fix, hi, ray_end)

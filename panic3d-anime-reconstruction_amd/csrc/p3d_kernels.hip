@@ -248,6 +248,7 @@ struct RenderParams {
     int H, W;
     int Sc, Sf;
     float ray_start, ray_end, depth_delta;
+    const float *ray_start_arr, *ray_end_arr;  // per-ray limits [N][R] ('auto', renderer.py:165-171) or null
     int white_back;
     int lds_rows;     // rows (of 32 floats) of per-wave LDS
     int swz;          // XCD swizzle run length (blocks)
@@ -461,6 +462,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
     {
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
+        // per-ray limits (ray_start = ray_end = 'auto'): math_utils.linspace + per-ray depth_delta (renderer.py:317-319)
+        const bool limits = p.ray_start_arr != nullptr;
+        const float rs = limits ? p.ray_start_arr[ray] : 0.0f, span = limits ? p.ray_end_arr[ray] - rs : 0.0f;
+        const float rdelta = span / (float)(Sc - 1);
         float prev = -__builtin_inff();
         for (int i0 = 0; i0 < Sc; i0 += 8) {  // eight loads of the jitter row in flight (one at a time exposed a global-load latency per sample)
             float jv[8];
@@ -472,6 +477,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
                 if (i < Sc) {  // wave-uniform
                     float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
                     float t = lin + jv[q] * p.depth_delta;
+                    if (limits) {  // wave-uniform
+                        const float prod = ((float)i / (float)(Sc - 1)) * span;
+                        t = (rs + prod) + jv[q] * rdelta;
+                    }
                     tcA[i * 32 + j] = t;
                     unsorted |= (t < prev);
                     prev = t;
@@ -868,10 +877,17 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
     {
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
+        const bool limits = p.ray_start_arr != nullptr;  // per-ray limits: as in k_render
+        const float rs = limits ? p.ray_start_arr[ray] : 0.0f, span = limits ? p.ray_end_arr[ray] - rs : 0.0f;
+        const float rdelta = span / (float)(Sc - 1);
         float prev = -__builtin_inff();
         for (int i = 0; i < Sc; ++i) {
             float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
             float t = lin + jit[i] * p.depth_delta;
+            if (limits) {
+                const float prod = ((float)i / (float)(Sc - 1)) * span;
+                t = (rs + prod) + jit[i] * rdelta;
+            }
             tcA[i * 32 + jr] = t;
             unsorted |= (t < prev);
             prev = t;
@@ -1422,6 +1438,16 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
                    const float* w1, const float* b1, const p3d_opts* opts, float* out_feat, float* out_depth,
                    float* out_wsum, float* out_xyz, void* workspace, size_t workspace_bytes, const p3d_dumps* dumps,
                    void* stream) {
+    return p3d_render_limits_f32(planes, N, H, W, rays_o, rays_d, R, ray_tile_w, jitter, u, w0, b0, w1, b1, nullptr, nullptr, opts,
+                                 out_feat, out_depth, out_wsum, out_xyz, workspace, workspace_bytes, dumps, stream);
+}
+
+int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                          int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
+                          const float* w1, const float* b1, const float* ray_start, const float* ray_end, const p3d_opts* opts,
+                          float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
+                          size_t workspace_bytes, const p3d_dumps* dumps, void* stream) {
+    if ((ray_start == nullptr) != (ray_end == nullptr)) return P3D_E_ARG;  // both or neither
     if (!planes || !rays_o || !rays_d || !jitter || !w0 || !b0 || !w1 || !b1 || !opts || !out_feat || !out_depth ||
         !out_wsum || !out_xyz || !workspace || N <= 0 || R <= 0)
         return P3D_E_ARG;
@@ -1440,6 +1466,7 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
     if (dumps) p.dumps = *dumps; else memset(&p.dumps, 0, sizeof(p.dumps));
     p.R = R; p.H = H; p.W = W; p.Sc = Sc; p.Sf = Sf;
     p.ray_start = opts->ray_start; p.ray_end = opts->ray_end; p.depth_delta = opts->depth_delta;
+    p.ray_start_arr = ray_start; p.ray_end_arr = ray_end;
     p.white_back = (opts->flags & P3D_FLAG_WHITE_BACK) ? 1 : 0;
     p.cfg = make_cfg(opts);
     if (ray_tile_w > 0 && R % ray_tile_w == 0 && ray_tile_w % 8 == 0 && (R / ray_tile_w) % 4 == 0) {

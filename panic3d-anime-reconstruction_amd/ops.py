@@ -38,8 +38,9 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
     """rendering_kwargs + ImportanceRenderer.forward arguments (renderer.py:162) -> p3d_opts.
     The double -> binary32 conversions are the ones include/p3d_numerics.h states."""
     ro = rendering_options
-    if ro.get("ray_start") == "auto" or ro.get("ray_end") == "auto":
-        raise NotImplementedError("ray_start/ray_end='auto' (renderer.py:165-171) is not used by PAniC-3D configs")
+    auto = ro.get("ray_start") == "auto" and ro.get("ray_end") == "auto"  # per-ray limits: render(..., ray_limits=...)
+    if not auto and (ro.get("ray_start") == "auto" or ro.get("ray_end") == "auto"):
+        raise ValueError("ray_start and ray_end must both be 'auto' or both be numbers (renderer.py:165)")
     if ro.get("disparity_space_sampling", False):
         raise NotImplementedError("disparity_space_sampling (renderer.py:309-316) is not used by PAniC-3D configs")
     if ro.get("clamp_mode", "softplus") != "softplus":
@@ -71,7 +72,7 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= _lib.P3D_FLAG_NO_PAIR
     if fast_color:  # opt-in tolerance mode of the final pass (include/panic3d_hip.h P3D_FLAG_FAST_COLOR)
         flags |= _lib.P3D_FLAG_FAST_COLOR
-    rs, re = float(ro["ray_start"]), float(ro["ray_end"])
+    rs, re = (0.0, 0.0) if auto else (float(ro["ray_start"]), float(ro["ray_end"]))
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
 
@@ -213,12 +214,15 @@ DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "
              "depth_unclamped", "tminmax")
 
 
-def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False):
+def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False,
+           ray_limits=None):
     """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
     jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
     Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps).
     `stats`: pass a dict to receive the number of decode steps the launch executed (exact early-outs, see k_render).
-    per_view_clamp: clamp each image's depth to its own sample range (N batched views = N calls of the reference)."""
+    per_view_clamp: clamp each image's depth to its own sample range (N batched views = N calls of the reference).
+    ray_limits: (ray_start, ray_end) per ray [N,R(,1)] for rendering_options['ray_start'] == ['ray_end'] == 'auto'
+    (renderer.py:165-171; cameras.ray_limits_box + cameras.patch_ray_limits compute them)."""
     if per_view_clamp:
         opts = _with_flag(opts, _lib.P3D_FLAG_PER_VIEW_CLAMP)
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
@@ -257,11 +261,18 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
                  sigma_sorted=torch.empty((NR, S), **f32), depth_unclamped=torch.empty((NR,), **f32),
                  tminmax=torch.empty((2,), **f32))
         dm = Dumps(*[_p(d[k]) for k in DUMP_KEYS])
+    rs_t = re_t = None
+    if ray_limits is None and not (opts.ray_end > opts.ray_start):
+        raise RuntimeError("empty depth range: rendering_options with ray_start = ray_end = 'auto' need ray_limits (per-ray limits)")
+    if ray_limits is not None:  # ray_start = ray_end = 'auto' (renderer.py:165-171): per-ray limits [N,R(,1)], already patched
+        rs_t, re_t = _chk(ray_limits[0], "ray_limits[0]"), _chk(ray_limits[1], "ray_limits[1]")
+        if rs_t.numel() != N * R or re_t.numel() != N * R:
+            raise RuntimeError(f"ray_limits must hold N*R = {N * R} values each")
     with torch.cuda.device(dev):
-        rc = L.p3d_render_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), _p(jitter), _p(u),
-                              _p(w0), _p(b0), _p(w1), _p(b1), C.byref(opts), _p(feat), _p(depth), _p(wsum), _p(xyz),
-                              _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
-    _lib.check(rc, "p3d_render_f32")
+        rc = L.p3d_render_limits_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), _p(jitter), _p(u),
+                                     _p(w0), _p(b0), _p(w1), _p(b1), _p(rs_t), _p(re_t), C.byref(opts), _p(feat), _p(depth),
+                                     _p(wsum), _p(xyz), _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
+    _lib.check(rc, "p3d_render_limits_f32")
     if stats is not None:  # synchronises: wave-level decode steps executed (32 samples each) vs the full count
         steps = int(ws[8:16].view(torch.int64).item())
         tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)

@@ -79,6 +79,13 @@ class ImportanceRenderer(torch.nn.Module):
                           binarize_clouds=binarize_clouds, fast_color=fast)
         N, R, _ = ray_origins.shape
         dev = ray_origins.device
+        limits = None
+        if rendering_options.get("ray_start") == "auto" and rendering_options.get("ray_end") == "auto":  # renderer.py:165-171
+            from . import cameras
+            limits = cameras.patch_ray_limits(*cameras.ray_limits_box(ray_origins.float(), ray_directions.float(),
+                                                                        rendering_options["box_warp"]))
+            if jitter is None:  # rand_like of linspace(...).permute(1,2,0,3) fills in memory order [Sc,N,R,1] (renderer.py:317-319)
+                jitter = torch.rand((opts.Sc, N, R, 1), dtype=torch.float32, device=dev).permute(1, 2, 0, 3).contiguous()
         if jitter is None:  # renderer.py:324
             jitter = torch.rand((N, R, opts.Sc, 1), dtype=torch.float32, device=dev)
         if u is None and opts.Sf > 0:  # renderer.py:371
@@ -87,7 +94,8 @@ class ImportanceRenderer(torch.nn.Module):
             side = int(round(R ** 0.5))
             ray_tile_w = side if side * side == R else 0
         out = ops.render(self._nhwc(planes), ray_origins.float(), ray_directions.float(), jitter, u,
-                         decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps, per_view_clamp=per_view_clamp)
+                         decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps, per_view_clamp=per_view_clamp,
+                         ray_limits=limits)
         return out  # rgb_final, depth_final, weights.sum(2), xyz_final  (renderer.py:264)
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):

@@ -111,6 +111,8 @@ class Capture:
         def strat(*a, **k):
             r = o["strat"](*a, **k)
             rec["depths_coarse_ref"] = r  # jitter is added in place before return
+            if isinstance(a[1], torch.Tensor):  # ray_start = ray_end = 'auto' (renderer.py:165-171): the per-ray limits, already patched
+                rec["ray_start"], rec["ray_end"] = a[1].clone(), a[2].clone()
             return r
 
         def imp(*a, **k):
@@ -140,12 +142,14 @@ def run_reference(planes, dec, rays_o, rays_d, ro, seed, crop, cull, binarize):
         feat, depth, wsum, xyz = rend(torch.from_numpy(planes), dec, rays_o, rays_d, ro, triplane_crop=crop,
                                       cull_clouds=cull, binarize_clouds=binarize)
     rec = cap.rec
-    jit, u = T.make_random_draws(seed, N, R, Sc, Sf)
+    jit, u = T.make_random_draws(seed, N, R, Sc, Sf, auto_limits=(ro["ray_start"] == "auto"))
     assert np.array_equal(rec["jitter"].numpy(), jit), "rand_like draw not reproduced from the seed"
     if Sf > 0:
         assert np.array_equal(rec["u"].numpy(), u), "rand draw not reproduced from the seed"
     out = dict(feat=feat.numpy(), depth=depth.numpy(), wsum=wsum.numpy(), xyz=xyz.numpy())
     out["depths_coarse"] = rec["depths_coarse_ref"].reshape(N * R, Sc).numpy()
+    if "ray_start" in rec:
+        out["ray_start"], out["ray_end"] = rec["ray_start"].reshape(N, R).numpy(), rec["ray_end"].reshape(N, R).numpy()
     rm = rec["run_model"]
     out["sigma_coarse"] = rm[0]["sigma"].reshape(N * R, Sc).numpy()
     out["rgb_coarse"] = rm[0]["rgb"].reshape(N * R, Sc, 32).numpy()
@@ -168,6 +172,7 @@ def render_case(name, *, res, Sc, Sf, N=1, H=256, W=256, seed=0, views=((0.0, 20
                 binarize=None, use_triplane=1, white_back=True, force_sigmoid=True, lr_mul=1.0, plane_scale=1.0,
                 smooth=0, sigma_gain=1.0, ray_start=0.5, ray_end=1.5, keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine",
                                                   "weights_coarse", "sigma_coarse", "sigma_fine", "depths_coarse")):
+    auto = ray_start == "auto" and ray_end == "auto"
     ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, use_triplane=use_triplane,
               white_back=white_back, ray_start=ray_start, ray_end=ray_end)
     planes = T.make_planes(seed, N, H, W, scale=plane_scale, smooth=smooth)
@@ -185,8 +190,9 @@ def render_case(name, *, res, Sc, Sf, N=1, H=256, W=256, seed=0, views=((0.0, 20
     out = run_reference(planes, dec, rays_o, rays_d, ro, seed + 2, crop, cull, binarize)
     meta = dict(res=res, Sc=Sc, Sf=Sf, N=N, H=H, W=W, seed=seed, crop=crop or 0.0, cull=cull or 0.0, binarize=binarize or 0.0,
                 use_triplane=use_triplane, white_back=int(white_back), force_sigmoid=int(force_sigmoid), lr_mul=lr_mul,
-                plane_scale=plane_scale, smooth=smooth, sigma_gain=sigma_gain, ray_start=ray_start, ray_end=ray_end, box_warp=ro["box_warp"])
-    arrs = {k: v for k, v in out.items() if k in keep}
+                plane_scale=plane_scale, smooth=smooth, sigma_gain=sigma_gain, ray_start=0.0 if auto else ray_start,
+                ray_end=0.0 if auto else ray_end, auto_limits=int(auto), box_warp=ro["box_warp"])
+    arrs = {k: v for k, v in out.items() if k in keep or (auto and k in ("ray_start", "ray_end"))}
     arrs["rays_o"] = rays_o.numpy()
     arrs["rays_d"] = rays_d.numpy()
     arrs["planes_checksum"] = np.array(T.checksum(planes))
@@ -269,7 +275,20 @@ def main():
     decode_case()
     stage_cases()
     ray_cases()
+    auto_case()
+
+
+def auto_case():
+    """ray_start = ray_end = 'auto' (renderer.py:165-171): per-ray limits from the box intersection; a wide field of view so that
+    part of the rays miss the box and take the patched limits."""
+    render_case("render_auto_limits.npz", res=20, Sc=24, Sf=16, seed=700, plane_scale=4.0, smooth=8, sigma_gain=40.0,
+                views=((10.0, 35.0, 50.0),), ray_start="auto", ray_end="auto",
+                keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine", "depths_coarse", "weights_coarse"))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "auto":  # only the fixture added in round 2 (the others are unchanged)
+        torch.set_num_threads(8)
+        auto_case()
+    else:
+        main()

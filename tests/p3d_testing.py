@@ -51,11 +51,13 @@ def make_decoder_params(seed, lr_mul=1.0, sigma_gain=1.0):
     return w0.numpy(), b0.numpy(), w1.numpy(), b1.numpy()
 
 
-def make_random_draws(seed, N, R, Sc, Sf):
+def make_random_draws(seed, N, R, Sc, Sf, auto_limits=False):
     """The two draws of ImportanceRenderer.forward in the reference's order (renderer.py:324 then :371):
-    torch.manual_seed(seed); rand_like([N,R,Sc,1]); rand(N*R, Sf)."""
+    torch.manual_seed(seed); rand_like([N,R,Sc,1]); rand(N*R, Sf).  auto_limits: with per-ray limits the depths come from
+    math_utils.linspace(...).permute(1,2,0,3) (renderer.py:317) — a [Sc,N,R,1] tensor viewed as [N,R,Sc,1] — and rand_like
+    fills it in MEMORY order."""
     torch.manual_seed(int(seed))
-    jitter = torch.rand(N, R, Sc, 1)
+    jitter = torch.rand(Sc, N, R, 1).permute(1, 2, 0, 3).contiguous() if auto_limits else torch.rand(N, R, Sc, 1)
     u = torch.rand(N * R, Sf) if Sf > 0 else torch.zeros(N * R, 0)
     return jitter.numpy(), u.numpy()
 
@@ -76,21 +78,27 @@ RENDER_GOLDENS = ["render_c1_64x64_s32", "render_32x32_16p16", "render_24x24_48p
                   "render_variant_a", "render_variant_b"]
 
 
+RENDER_GOLDENS_AUTO = ["render_auto_limits"]  # ray_start = ray_end = 'auto' (renderer.py:165-171): per-ray limits in the fixture
+
+
 def golden_render_inputs(g):
     """Rebuild the inputs of a render_*.npz fixture from its meta_* fields (see tests/golden/make_golden.py)."""
     m = {k[5:]: g[k].item() for k in g if k.startswith("meta_")}
     ro = dict(RENDERING_KWARGS, depth_resolution=int(m["Sc"]), depth_resolution_importance=int(m["Sf"]),
               use_triplane=int(m["use_triplane"]), white_back=bool(m["white_back"]), ray_start=float(m["ray_start"]),
               ray_end=float(m["ray_end"]), box_warp=float(m["box_warp"]))
+    if int(m.get("auto_limits", 0)):  # renderer.py:165-171; the fixture carries the reference's per-ray limits as ray_start / ray_end
+        ro["ray_start"] = ro["ray_end"] = "auto"
     planes = make_planes(m["seed"], m["N"], m["H"], m["W"], scale=float(m["plane_scale"]), smooth=int(m["smooth"]))
     assert checksum(planes) == str(g["planes_checksum"]), "regenerated planes differ from the fixture's"
     raw = make_decoder_params(m["seed"] + 1, float(m["lr_mul"]), float(m["sigma_gain"]))
     R = g["rays_o"].shape[1]
-    jitter, u = make_random_draws(m["seed"] + 2, m["N"], R, int(m["Sc"]), int(m["Sf"]))
+    jitter, u = make_random_draws(m["seed"] + 2, m["N"], R, int(m["Sc"]), int(m["Sf"]), auto_limits=bool(int(m.get("auto_limits", 0))))
     kw = dict(triplane_crop=float(m["crop"]) or None, cull_clouds=float(m["cull"]) or None,
               binarize_clouds=float(m["binarize"]) or None, force_sigmoid=bool(m["force_sigmoid"]))
+    limits = (g["ray_start"], g["ray_end"]) if int(m.get("auto_limits", 0)) else None
     return dict(ro=ro, planes=planes, raw_mlp=raw, lr_mul=float(m["lr_mul"]), rays_o=g["rays_o"], rays_d=g["rays_d"],
-                jitter=jitter, u=u, kw=kw, meta=m)
+                jitter=jitter, u=u, kw=kw, meta=m, ray_limits=limits)
 
 
 # ---- bench scenes (bench.py, tools/cpu_baseline_reference.py, tests/test_hip_fullsize.py share these builders) ---------------

@@ -41,13 +41,14 @@ def run_hip_render(hip, inp, tile_w=0):
     mlp = hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"])
     planes = hip.ops.planes_to_nhwc(dev(inp["planes"]))
     out = hip.ops.render(planes, dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"]), mlp, opts,
-                         ray_tile_w=tile_w, dumps=True)
+                         ray_tile_w=tile_w, dumps=True,
+                         ray_limits=None if inp.get("ray_limits") is None else tuple(dev(x) for x in inp["ray_limits"]))
     torch.cuda.synchronize()
     feat, depth, wsum, xyz, d = out
     return feat.cpu().numpy(), depth.cpu().numpy(), wsum.cpu().numpy(), xyz.cpu().numpy(), {k: v.cpu().numpy() for k, v in d.items()}
 
 
-@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS + T.RENDER_GOLDENS_AUTO)
 @pytest.mark.parametrize("tiled", [0, 1])
 def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
     g = T.load_golden(name + ".npz")
@@ -58,7 +59,8 @@ def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
         pytest.skip("not an 8x4-tileable image")
     oo = oracle.make_opts(inp["ro"], **inp["kw"])
     om = oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"])
-    of, od, ow, ox, odm = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"], om, oo, dumps=True)
+    of, od, ow, ox, odm = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"], om, oo, dumps=True,
+                                        ray_limits=inp["ray_limits"])
     hf, hd, hw, hx, hdm = run_hip_render(hip, inp, tile_w=side if tiled else 0)
     # host-side parameter preparation is part of the contract
     hm = hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"])
@@ -93,7 +95,7 @@ def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
         assert int((hdm["inds"] != g["inds"]).sum()) == 0
 
 
-@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS + T.RENDER_GOLDENS_AUTO)
 @pytest.mark.parametrize("early_out", [True, False])
 @pytest.mark.parametrize("pair", [True, False])
 def test_render_production_kernel_bit_exact(hip, oracle, name, early_out, pair):
@@ -104,19 +106,62 @@ def test_render_production_kernel_bit_exact(hip, oracle, name, early_out, pair):
     R = inp["rays_o"].shape[1]
     side = int(round(R ** 0.5))
     ref = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
-                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]))
+                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]),
+                        ray_limits=inp["ray_limits"])
     opts = hip.ops.make_opts(inp["ro"], early_out=early_out, small_launch_kernel=pair, **inp["kw"])
     planes = hip.ops.planes_to_nhwc(dev(inp["planes"]))
     st = {}
     out = hip.ops.render(planes, dev(inp["rays_o"]), dev(inp["rays_d"]), dev(inp["jitter"]), dev(inp["u"]),
                          hip_mlp(hip, inp["raw_mlp"], inp["lr_mul"]), opts,
-                         ray_tile_w=side if (side * side == R and side % 8 == 0) else 0, stats=st)
+                         ray_tile_w=side if (side * side == R and side % 8 == 0) else 0, stats=st,
+                         ray_limits=None if inp["ray_limits"] is None else tuple(dev(x) for x in inp["ray_limits"]))
     for name_, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
         assert np.array_equal(a.cpu().numpy(), b), name_
     assert st["small_launch_kernel"] == pair
     assert 0 < st["decode_steps"] <= st["decode_steps_full"]
     if not early_out:
         assert st["decode_steps"] == st["decode_steps_full"]
+
+
+def test_importance_renderer_auto_ray_limits(hip, oracle):
+    """ImportanceRenderer.forward with rendering_options ray_start = ray_end = 'auto' (renderer.py:165-171): the host restates
+    get_ray_limits_box + the patching of the rays that miss the box (bit-identical to the reference's limits in the fixture,
+    21 of 400 rays miss), the kernel math_utils.linspace + the per-ray depth_delta; exact mode equals the oracle bit for bit
+    and the reference within the fp32 tolerances; the renderer's default (tolerance) mode stays within 2e-5 of it."""
+    g = T.load_golden("render_auto_limits.npz")
+    inp = T.golden_render_inputs(g)
+    assert inp["ro"]["ray_start"] == "auto"
+    rs, re = hip.cameras.patch_ray_limits(*hip.cameras.ray_limits_box(dev(inp["rays_o"]), dev(inp["rays_d"]), inp["ro"]["box_warp"]))
+    assert np.array_equal(rs.reshape(1, -1).cpu().numpy(), g["ray_start"]) and np.array_equal(re.reshape(1, -1).cpu().numpy(), g["ray_end"])
+    assert int((g["ray_end"] <= g["ray_start"]).sum()) == 0 and float(g["ray_start"].min()) > 0  # patched limits
+    ref = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
+                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]),
+                        ray_limits=inp["ray_limits"])
+    rend = hip.ImportanceRenderer(use_triplane=bool(inp["ro"]["use_triplane"]))
+
+    class FC:
+        def __init__(self, w, b, i):
+            self.weight, self.bias, self.weight_gain, self.bias_gain = w, b, inp["lr_mul"] / np.sqrt(i), inp["lr_mul"]
+
+    class Dec:
+        force_sigmoid = bool(inp["kw"]["force_sigmoid"])
+    raw = [dev(x) for x in inp["raw_mlp"]]
+    Dec.net = [FC(raw[0], raw[1], 32), None, FC(raw[2], raw[3], 64)]
+    dec = Dec()
+    kw = {k: v for k, v in inp["kw"].items() if k != "force_sigmoid"}
+    common = dict(jitter=dev(inp["jitter"]), u=dev(inp["u"]), **kw)
+    exact = rend(dev(inp["planes"]), dec, dev(inp["rays_o"]), dev(inp["rays_d"]), inp["ro"], exact=True, **common)
+    for name, a, b in zip(("feat", "depth", "wsum", "xyz"), exact, ref):
+        assert np.array_equal(a.cpu().numpy(), b), name
+    for a, key, tol in zip(exact, ("feat", "depth", "wsum", "xyz"), (TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ)):
+        assert np.abs(a.cpu().numpy() - g[key]).max() <= tol, key
+    fast = rend(dev(inp["planes"]), dec, dev(inp["rays_o"]), dev(inp["rays_d"]), inp["ro"], **common)
+    for a, b in zip(fast, exact):
+        assert float((a - b).abs().max()) <= 2e-5
+    # without injected draws the host draws in the reference's memory order ([Sc,N,R,1] viewed as [N,R,Sc,1])
+    torch.manual_seed(int(inp["meta"]["seed"]) + 2)
+    drawn = rend(dev(inp["planes"]), dec, dev(inp["rays_o"]), dev(inp["rays_d"]), inp["ro"], exact=True, **kw)
+    assert all(torch.isfinite(t).all() for t in drawn)
 
 
 @pytest.mark.parametrize("ut", [0, 1])
@@ -198,8 +243,15 @@ def test_error_behaviour(hip):
         hip.ops.render(planes, o, d, good_j, good_u, (torch.zeros(64, 16, device="cuda"),) + mlp[1:], opts)
     with pytest.raises(RuntimeError):  # fp64 input
         hip.ops.planes_to_nhwc(torch.zeros(1, 3, 32, 8, 8, device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):  # 'auto' limits come in pairs (renderer.py:165)
+        hip.ops.make_opts(dict(ro, ray_start="auto"))
     with pytest.raises(NotImplementedError):
-        hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto"))
+        hip.ops.make_opts(dict(ro, disparity_space_sampling=True))
+    with pytest.raises(RuntimeError):  # 'auto' options without the per-ray limits
+        hip.ops.render(planes, o, d, good_j, good_u, mlp, hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto")))
+    with pytest.raises(RuntimeError):  # per-ray limits of the wrong size
+        hip.ops.render(planes, o, d, good_j, good_u, mlp, hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto")),
+                       ray_limits=(torch.zeros(3, device="cuda"), torch.zeros(3, device="cuda")))
     # a valid call on the same inputs still works afterwards (no sticky error state), incl. the single-pass branch
     out = hip.ops.render(planes, o, d, good_j, good_u, mlp, opts)
     out0 = hip.ops.render(planes, o, d, good_j, None, mlp, hip.ops.make_opts(dict(ro, depth_resolution_importance=0)))

@@ -300,3 +300,18 @@ def test_fully_connected_scaled_weight_cache(P):
         fc.load_state_dict({"weight": torch.ones(7, 12), "bias": torch.zeros(7)})
         assert torch.equal(fc(x), ref())
     assert set(fc.state_dict()) == {"weight", "bias"}
+
+
+def test_ray_limits_box_matches_the_reference(P):
+    """cameras.ray_limits_box + patch_ray_limits (math_utils.get_ray_limits_box, renderer.py:167-170) against the per-ray limits the
+    reference itself produced for rendering_options ray_start = ray_end = 'auto' (tests/golden/render_auto_limits.npz)."""
+    from panic3d_amd import cameras
+    g = T.load_golden("render_auto_limits.npz")
+    o, d = torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"])
+    a, b = cameras.ray_limits_box(o, d, float(g["meta_box_warp"]))
+    assert int((b <= a).sum()) == 21 and torch.all(a[b <= a] == -1) and torch.all(b[b <= a] == -2)  # rays that miss the box
+    a, b = cameras.patch_ray_limits(a, b)
+    assert np.array_equal(a.reshape(1, -1).numpy(), g["ray_start"]) and np.array_equal(b.reshape(1, -1).numpy(), g["ray_end"])
+    # no valid ray at all: nothing is patched (the reference's `if torch.any(is_ray_valid)`)
+    a2, b2 = cameras.patch_ray_limits(torch.full((1, 4, 1), -1.0), torch.full((1, 4, 1), -2.0))
+    assert torch.all(a2 == -1) and torch.all(b2 == -2)

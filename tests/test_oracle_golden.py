@@ -21,14 +21,14 @@ TOL_SIGMA = 1e-5    # raw decoder sigma, times max(1, sigma_gain)
 NEAR_TIE = 6e-7     # ~5 ulp at depth 1: two merged depths this close may legitimately sort either way
 
 
-@pytest.mark.parametrize("name", T.RENDER_GOLDENS)
+@pytest.mark.parametrize("name", T.RENDER_GOLDENS + T.RENDER_GOLDENS_AUTO)
 def test_render_matches_reference(oracle, name):
     g = T.load_golden(name + ".npz")
     inp = T.golden_render_inputs(g)
     opts = oracle.make_opts(inp["ro"], **inp["kw"])
     mlp = oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"])
     feat, depth, wsum, xyz, d = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"], mlp,
-                                              opts, dumps=True)
+                                              opts, dumps=True, ray_limits=inp["ray_limits"])
     assert np.abs(feat - g["feat"]).max() <= TOL_FEAT
     assert np.abs(depth - g["depth"]).max() <= TOL_DEPTH
     assert np.abs(wsum - g["wsum"]).max() <= TOL_WEIGHT
