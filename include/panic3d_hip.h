@@ -57,6 +57,10 @@ extern "C" {
                                     quad-cooperative gathers: 512^3 tolerance query 7.7 ms direct, 10.0 ms staged) */
 #define P3D_FLAG_FORCE_STAGING 8192 /* p3d_grid_density_f32: stage each wave's texel boxes through LDS and take the taps from there
                                        (north_star's "LDS-staged plane tiles"; measurement / tests; same bits as the direct gathers) */
+#define P3D_FLAG_DISPARITY 4096 /* p3d_render_f32: rendering_options.disparity_space_sampling (renderer.py:309-316): samples uniform in
+                                   1 / depth.  opts->ray_start / ray_end then hold (float)(1 / ray_start), (float)(1 / ray_end) and
+                                   depth_delta (float)(1 / (Sc - 1)): d = linspace(0, 1, Sc) + jitter * depth_delta;
+                                   t = 1 / (ray_start * (1 - d) + ray_end * d).  Not with per-ray limits. */
 #define P3D_FLAG_SHARED_PLANES 64 /* planes holds ONE image [1][3][H][W][32] shared by all N batches of rays / points (many
                                     views of one subject in one launch; the reference would pass planes.expand(N, ...)) */
 

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 FLAG_CROP, FLAG_CULL, FLAG_BINARIZE, FLAG_FORCE_SIGMOID, FLAG_WHITE_BACK = 1, 2, 4, 8, 16
+FLAG_DISPARITY = 4096
 
 
 def build(force=False):
@@ -78,6 +79,9 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         rs = re = 0.0
     else:
         rs, re = float(ro["ray_start"]), float(ro["ray_end"])
+    if ro.get("disparity_space_sampling", False):  # renderer.py:309-316: the reciprocals, and depth_delta = 1 / (Sc - 1)
+        return Opts(np.float32(2.0 / bw), np.float32(1.0 / rs), np.float32(1.0 / re), np.float32(1 / (Sc - 1)),
+                    np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags | FLAG_DISPARITY)
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / (Sc - 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
 

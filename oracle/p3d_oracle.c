@@ -33,6 +33,7 @@
 #define OR_FLAG_BINARIZE 4
 #define OR_FLAG_FORCE_SIGMOID 8
 #define OR_FLAG_WHITE_BACK 16
+#define OR_FLAG_DISPARITY 4096
 
 /* ------------------------------------------------------------------ scalar math of the contract */
 static inline float or_exp(float x) {
@@ -227,6 +228,20 @@ static void or_stratified_limits(float start, float end, int S, const float* jit
         const float prod = step * span;
         const float lin = start + prod;
         t[i] = lin + jitter[i] * delta;
+    }
+}
+
+/* renderer.py:309-316 (disparity_space_sampling): d = torch.linspace(0, 1, S) + rand * (1 / (S - 1));
+ * t = 1. / (1. / ray_start * (1. - d) + 1. / ray_end * d) with the two reciprocals formed in binary64 by Python and used as
+ * binary32 scalars: inv_start = (float)(1 / ray_start), inv_end = (float)(1 / ray_end), delta = (float)(1 / (S - 1)). */
+static void or_stratified_disparity(float inv_start, float inv_end, float delta, int S, const float* jitter, float* t) {
+    float step = (1.0f - 0.0f) / (float)(S - 1);
+    for (int i = 0; i < S; ++i) {
+        float lin = (i < S / 2) ? fmaf(step, (float)i, 0.0f) : fmaf(-step, (float)(S - 1 - i), 1.0f);
+        float d = lin + jitter[i] * delta;
+        float a = inv_start * (1.0f - d);
+        float b = inv_end * d;
+        t[i] = 1.0f / (a + b);
     }
 }
 
@@ -429,6 +444,7 @@ int p3d_oracle_render_limits(const float* planes, int N, int H, int W, const flo
         float t[384], sg[384], col[384 * 35], wts[384];
         /* coarse pass: renderer.py:174-206 */
         if (ray_start && ray_end) or_stratified_limits(ray_start[r], ray_end[r], Sc, jitter + r * Sc, t);
+        else if (o->flags & OR_FLAG_DISPARITY) or_stratified_disparity(o->ray_start, o->ray_end, o->depth_delta, Sc, jitter + r * Sc, t);
         else or_stratified(o->ray_start, o->ray_end, o->depth_delta, Sc, jitter + r * Sc, t);
         for (int i = 0; i < Sc; ++i) {
             float px = ox + t[i] * dx, py = oy + t[i] * dy, pz = oz + t[i] * dz; /* :179 (mul, then add) */

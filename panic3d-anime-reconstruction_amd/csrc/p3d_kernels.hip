@@ -249,6 +249,7 @@ struct RenderParams {
     int Sc, Sf;
     float ray_start, ray_end, depth_delta;
     const float *ray_start_arr, *ray_end_arr;  // per-ray limits [N][R] ('auto', renderer.py:165-171) or null
+    int disparity;                             // P3D_FLAG_DISPARITY
     int white_back;
     int lds_rows;     // rows (of 32 floats) of per-wave LDS
     int swz;          // XCD swizzle run length (blocks)
@@ -480,6 +481,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
                     if (limits) {  // wave-uniform
                         const float prod = ((float)i / (float)(Sc - 1)) * span;
                         t = (rs + prod) + jv[q] * rdelta;
+                    } else if (p.disparity) {  // renderer.py:309-316: uniform in 1 / depth; p.ray_start / ray_end hold the reciprocals
+                        const float s01 = 1.0f / (float)(Sc - 1);
+                        const float l01 = (i < Sc / 2) ? p3d_fma(s01, (float)i, 0.0f) : p3d_fma(-s01, (float)(Sc - 1 - i), 1.0f);
+                        const float dd = l01 + jv[q] * p.depth_delta;
+                        const float ta_ = p.ray_start * (1.0f - dd), tb_ = p.ray_end * dd;
+                        t = 1.0f / (ta_ + tb_);
                     }
                     tcA[i * 32 + j] = t;
                     unsorted |= (t < prev);
@@ -887,6 +894,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             if (limits) {
                 const float prod = ((float)i / (float)(Sc - 1)) * span;
                 t = (rs + prod) + jit[i] * rdelta;
+            } else if (p.disparity) {
+                const float s01 = 1.0f / (float)(Sc - 1);
+                const float l01 = (i < Sc / 2) ? p3d_fma(s01, (float)i, 0.0f) : p3d_fma(-s01, (float)(Sc - 1 - i), 1.0f);
+                const float dd = l01 + jit[i] * p.depth_delta;
+                const float ta_ = p.ray_start * (1.0f - dd), tb_ = p.ray_end * dd;
+                t = 1.0f / (ta_ + tb_);
             }
             tcA[i * 32 + jr] = t;
             unsorted |= (t < prev);
@@ -1467,6 +1480,8 @@ int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float*
     p.R = R; p.H = H; p.W = W; p.Sc = Sc; p.Sf = Sf;
     p.ray_start = opts->ray_start; p.ray_end = opts->ray_end; p.depth_delta = opts->depth_delta;
     p.ray_start_arr = ray_start; p.ray_end_arr = ray_end;
+    p.disparity = (opts->flags & P3D_FLAG_DISPARITY) ? 1 : 0;
+    if (p.disparity && ray_start) return P3D_E_RANGE;  // not with per-ray limits
     p.white_back = (opts->flags & P3D_FLAG_WHITE_BACK) ? 1 : 0;
     p.cfg = make_cfg(opts);
     if (ray_tile_w > 0 && R % ray_tile_w == 0 && ray_tile_w % 8 == 0 && (R / ray_tile_w) % 4 == 0) {

@@ -41,8 +41,9 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
     auto = ro.get("ray_start") == "auto" and ro.get("ray_end") == "auto"  # per-ray limits: render(..., ray_limits=...)
     if not auto and (ro.get("ray_start") == "auto" or ro.get("ray_end") == "auto"):
         raise ValueError("ray_start and ray_end must both be 'auto' or both be numbers (renderer.py:165)")
-    if ro.get("disparity_space_sampling", False):
-        raise NotImplementedError("disparity_space_sampling (renderer.py:309-316) is not used by PAniC-3D configs")
+    disparity = bool(ro.get("disparity_space_sampling", False))  # renderer.py:309-316
+    if disparity and auto:
+        raise NotImplementedError("disparity_space_sampling together with ray_start = ray_end = 'auto'")
     if ro.get("clamp_mode", "softplus") != "softplus":
         raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")  # ray_marcher.py:35
     if ro.get("density_noise", 0) > 0:
@@ -73,6 +74,10 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
     if fast_color:  # opt-in tolerance mode of the final pass (include/panic3d_hip.h P3D_FLAG_FAST_COLOR)
         flags |= _lib.P3D_FLAG_FAST_COLOR
     rs, re = (0.0, 0.0) if auto else (float(ro["ray_start"]), float(ro["ray_end"]))
+    if disparity:  # the kernel receives the reciprocals the reference forms in binary64 and multiplies as binary32 scalars
+        flags |= _lib.P3D_FLAG_DISPARITY
+        return Opts(np.float32(2.0 / bw), np.float32(1.0 / rs), np.float32(1.0 / re), np.float32(1 / max(Sc - 1, 1)),
+                    np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
     return Opts(np.float32(2.0 / bw), np.float32(rs), np.float32(re), np.float32((re - rs) / max(Sc - 1, 1)),
                 np.float32(crop_limit), np.float32(thr), Sc, Sf, int(bool(ro.get("use_triplane", False))), flags)
 
@@ -262,7 +267,9 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
                  tminmax=torch.empty((2,), **f32))
         dm = Dumps(*[_p(d[k]) for k in DUMP_KEYS])
     rs_t = re_t = None
-    if ray_limits is None and not (opts.ray_end > opts.ray_start):
+    if ray_limits is not None and (opts.flags & _lib.P3D_FLAG_DISPARITY):
+        raise NotImplementedError("disparity_space_sampling with per-ray limits")
+    if ray_limits is None and not (opts.flags & _lib.P3D_FLAG_DISPARITY) and not (opts.ray_end > opts.ray_start):
         raise RuntimeError("empty depth range: rendering_options with ray_start = ray_end = 'auto' need ray_limits (per-ray limits)")
     if ray_limits is not None:  # ray_start = ray_end = 'auto' (renderer.py:165-171): per-ray limits [N,R(,1)], already patched
         rs_t, re_t = _chk(ray_limits[0], "ray_limits[0]"), _chk(ray_limits[1], "ray_limits[1]")

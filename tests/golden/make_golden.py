@@ -170,11 +170,11 @@ def save(name, **arrs):
 
 def render_case(name, *, res, Sc, Sf, N=1, H=256, W=256, seed=0, views=((0.0, 20.0, 30.0),), ortho=False, crop=0.1, cull=0.5,
                 binarize=None, use_triplane=1, white_back=True, force_sigmoid=True, lr_mul=1.0, plane_scale=1.0,
-                smooth=0, sigma_gain=1.0, ray_start=0.5, ray_end=1.5, keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine",
+                smooth=0, sigma_gain=1.0, ray_start=0.5, ray_end=1.5, disparity=False, keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine",
                                                   "weights_coarse", "sigma_coarse", "sigma_fine", "depths_coarse")):
     auto = ray_start == "auto" and ray_end == "auto"
     ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, use_triplane=use_triplane,
-              white_back=white_back, ray_start=ray_start, ray_end=ray_end)
+              white_back=white_back, ray_start=ray_start, ray_end=ray_end, disparity_space_sampling=bool(disparity))
     planes = T.make_planes(seed, N, H, W, scale=plane_scale, smooth=smooth)
     dec = ref_decoder(seed + 1, lr_mul, force_sigmoid, sigma_gain)
     os_, ds_ = [], []
@@ -191,7 +191,7 @@ def render_case(name, *, res, Sc, Sf, N=1, H=256, W=256, seed=0, views=((0.0, 20
     meta = dict(res=res, Sc=Sc, Sf=Sf, N=N, H=H, W=W, seed=seed, crop=crop or 0.0, cull=cull or 0.0, binarize=binarize or 0.0,
                 use_triplane=use_triplane, white_back=int(white_back), force_sigmoid=int(force_sigmoid), lr_mul=lr_mul,
                 plane_scale=plane_scale, smooth=smooth, sigma_gain=sigma_gain, ray_start=0.0 if auto else ray_start,
-                ray_end=0.0 if auto else ray_end, auto_limits=int(auto), box_warp=ro["box_warp"])
+                ray_end=0.0 if auto else ray_end, auto_limits=int(auto), disparity=int(bool(disparity)), box_warp=ro["box_warp"])
     arrs = {k: v for k, v in out.items() if k in keep or (auto and k in ("ray_start", "ray_end"))}
     arrs["rays_o"] = rays_o.numpy()
     arrs["rays_d"] = rays_d.numpy()
@@ -283,6 +283,10 @@ def auto_case():
     part of the rays miss the box and take the patched limits."""
     render_case("render_auto_limits.npz", res=20, Sc=24, Sf=16, seed=700, plane_scale=4.0, smooth=8, sigma_gain=40.0,
                 views=((10.0, 35.0, 50.0),), ray_start="auto", ray_end="auto",
+                keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine", "depths_coarse", "weights_coarse"))
+    # disparity_space_sampling (renderer.py:309-316): coarse samples uniform in 1 / depth
+    render_case("render_disparity.npz", res=16, Sc=32, Sf=24, seed=710, plane_scale=4.0, smooth=8, sigma_gain=40.0,
+                views=((5.0, 320.0, 30.0),), ray_start=0.55, ray_end=1.45, disparity=True,
                 keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine", "depths_coarse", "weights_coarse"))
 
 

@@ -78,7 +78,9 @@ RENDER_GOLDENS = ["render_c1_64x64_s32", "render_32x32_16p16", "render_24x24_48p
                   "render_variant_a", "render_variant_b"]
 
 
-RENDER_GOLDENS_AUTO = ["render_auto_limits"]  # ray_start = ray_end = 'auto' (renderer.py:165-171): per-ray limits in the fixture
+# the other branches of sample_stratified: ray_start = ray_end = 'auto' (renderer.py:165-171, per-ray limits in the fixture) and
+# disparity_space_sampling (renderer.py:309-316)
+RENDER_GOLDENS_AUTO = ["render_auto_limits", "render_disparity"]
 
 
 def golden_render_inputs(g):
@@ -89,6 +91,8 @@ def golden_render_inputs(g):
               ray_end=float(m["ray_end"]), box_warp=float(m["box_warp"]))
     if int(m.get("auto_limits", 0)):  # renderer.py:165-171; the fixture carries the reference's per-ray limits as ray_start / ray_end
         ro["ray_start"] = ro["ray_end"] = "auto"
+    if int(m.get("disparity", 0)):
+        ro["disparity_space_sampling"] = True
     planes = make_planes(m["seed"], m["N"], m["H"], m["W"], scale=float(m["plane_scale"]), smooth=int(m["smooth"]))
     assert checksum(planes) == str(g["planes_checksum"]), "regenerated planes differ from the fixture's"
     raw = make_decoder_params(m["seed"] + 1, float(m["lr_mul"]), float(m["sigma_gain"]))

@@ -245,8 +245,8 @@ def test_error_behaviour(hip):
         hip.ops.planes_to_nhwc(torch.zeros(1, 3, 32, 8, 8, device="cuda", dtype=torch.float64))
     with pytest.raises(ValueError):  # 'auto' limits come in pairs (renderer.py:165)
         hip.ops.make_opts(dict(ro, ray_start="auto"))
-    with pytest.raises(NotImplementedError):
-        hip.ops.make_opts(dict(ro, disparity_space_sampling=True))
+    with pytest.raises(NotImplementedError):  # the one combination of sampling options that is not built
+        hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto", disparity_space_sampling=True))
     with pytest.raises(RuntimeError):  # 'auto' options without the per-ray limits
         hip.ops.render(planes, o, d, good_j, good_u, mlp, hip.ops.make_opts(dict(ro, ray_start="auto", ray_end="auto")))
     with pytest.raises(RuntimeError):  # per-ray limits of the wrong size
