@@ -107,7 +107,7 @@ P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t
     float ix = (gx + 1.0f) * g.halfW - 0.5f;
     float iy = (gy + 1.0f) * g.halfH - 0.5f;
     // !live: this lane's result is known not to matter (cropped / dead ray): give it out-of-bounds offsets so that it issues
-    // no L1 lookups (the gather rate is the kernel's binding limit) — it then decodes an all-zero feature vector
+    // no L1 lookups — it then decodes an all-zero feature vector
     bool inr = live && (ix > -1.0f) && (ix < g.fW) && (iy > -1.0f) && (iy < g.fH);
     float fx0 = __builtin_floorf(ix), fy0 = __builtin_floorf(iy);
     float wx1 = ix - fx0, wy1 = iy - fy0;
@@ -127,11 +127,10 @@ P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t
     off[3] = (vx1 && vy1) ? base + row + 128u : P3D_OOB_OFFSET;
 }
 
-// The lane's 64 B of one tap as four 16-B loads.  (Rotating the 16-B slot by the quad index removes the L1 slot conflicts
-// and makes this very access pattern 1.75x faster in a micro-benchmark that keeps 32 waves per CU gathering
-// (tools/ubench/l1_gather_real.hip: 53.8 -> 30.8 clk per instruction); in the kernel — 8 waves per CU, <= 16 loads in flight
-// each — it was measured twice and changes nothing: the kernel waits on the LATENCY of its gathers, not on the L1's
-// throughput; profiles/r02_notes.txt.)
+// The lane's 64 B of one tap as four 16-B loads (per-lane gathers: one lane = one sample's half texel).  The vector L1 charges
+// such an instruction by the distinct texels it touches (tools/ubench/l1_gather*.hip, in-kernel ablations in
+// profiles/r02_notes.txt); rotating the 16-B slot by the quad index helps in the micro-benchmark and not in the kernels, sharing
+// a texel inside a quad helps in both: p3d_load16_quad below.
 template <typename RSRC>
 P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
     f32x16 v;

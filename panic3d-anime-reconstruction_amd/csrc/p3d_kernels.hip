@@ -384,7 +384,7 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
 //     (alpha <= 1; Td can grow by at most (1 + 1e-10) per step), so its remaining samples cannot change any output;
 //   * cropped samples: triplane_crop masks by POSITION (renderer.py:138-149), so sigma = -1000 is known without a decode.
 //   A step whose 32 rays are all dead or cropped skips gather + MLP; in a mixed step the dead / cropped LANES get
-//   out-of-bounds gather offsets, i.e. they issue no L1 lookups (the gather rate is the binding limit).
+//   out-of-bounds gather offsets, i.e. they issue no L1 lookups.
 //   In the final pass a skipped sample's colour is needed only if one of its two interval weights is non-zero (sigma of
 //   the neighbour >= ~794); that is checked on the exact weights and, if it ever happens, the sample is decoded after
 //   all — results are bit-identical by construction.
@@ -1419,9 +1419,8 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     // multiple of the tiles per grid row: with P3D_FLAG_SKIP_CROPPED the masked ends of every row would otherwise always fall
     // on the same waves (measured: 10.7 ms instead of the expected ~7.5 at 512^3 with half of the grid masked)
     if (blocks > 256 * 16 - 1) blocks = 256 * 16 - 1;
-    // four variants: exact / tolerance-mode decoder (P3D_FLAG_FAST_COLOR), texel boxes staged through LDS or direct gathers.
-    // Measured at 512^3: the exact decoder is ALU-bound and the direct gathers are L1-service-bound at the SAME
-    // level, so staging pays only together with the cheap decoder; it is therefore on only in the tolerance mode.
+    // four variants: exact / tolerance-mode decoder (P3D_FLAG_FAST_COLOR), texel boxes staged through LDS or direct gathers
+    // (measurements: DESIGN.md §4.3)
     const bool fastd = (opts->flags & P3D_FLAG_FAST_COLOR) != 0;
     // LDS-staged texel boxes only on request: with quad-cooperative gathers the direct tolerance query is faster (512^3: 7.7 ms
     // direct, 10.0 staged; exact: 12.7 direct, 22.8 staged); P3D_FLAG_NO_STAGING is accepted and has nothing left to switch off
