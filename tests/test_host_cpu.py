@@ -183,6 +183,7 @@ rank, world = dist.get_rank(), dist.get_world_size()
 K, res = 7, 4
 frames = torch.zeros((K, res, res, 4))
 g = sharding.FrameGather(frames, K, dst=0)
+g.p2p = {p2p}  # True: the batched point-to-point fallback instead of gather()
 chunk = 3
 for i in range(K):  # "render" frame i, hand finished slices over while the loop goes on
     frames[i] = 100.0 * rank + i
@@ -204,14 +205,15 @@ dist.destroy_process_group()
 """
 
 
-def test_streamed_frame_gather_gloo_world3(tmp_path):
+@pytest.mark.parametrize("p2p", [False, True])
+def test_streamed_frame_gather_gloo_world3(tmp_path, p2p):
     """sharding.FrameGather (bench.py's collective: slices of the sweep sent while the next ones render) at world size 3:
-    rank order, slice order and the ragged last slice."""
+    rank order, slice order and the ragged last slice; with gather() and with the batched point-to-point fallback."""
     script = tmp_path / "worker.py"
-    script.write_text(_STREAM_WORKER.format(root=ROOT))
+    script.write_text(_STREAM_WORKER.format(root=ROOT, p2p=p2p))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
-                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(29547 + int(p2p)), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
