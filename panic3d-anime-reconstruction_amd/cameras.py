@@ -114,3 +114,24 @@ def patch_ray_limits(ray_start, ray_end):
     some = valid.any()
     fix = (~valid) & some
     return torch.where(fix, lo, ray_start), torch.where(fix, hi, ray_end)
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=512)
+def _cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype):
+    label = camera_label(elev, azim, dist, fov).to(dtype).to(device)
+    if fov < 0:  # negative fov = orthographic view (training/triplane.py:402-414)
+        r = ortho_rays(elev, azim, dist, boxwarp, resolution, device=device)
+        return label, r["ray_origins"][0], r["ray_directions"][0]
+    ro, rd = perspective_rays(label[:16].view(1, 4, 4), label[16:25].view(1, 3, 3), resolution)
+    chw = lambda t: t.reshape(resolution, resolution, 3).permute(2, 0, 1).contiguous()
+    return label, chw(ro), chw(rd)
+
+
+def cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.float32):
+    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res]) of one view, memoised on the view's parameters:
+    generate.py renders the same 16 poses for every subject, and the ray generation is a dozen small launches plus host maths.
+    The tensors are shared between calls: callers stack / copy them, they never write into them."""
+    return _cached_view(float(elev), float(azim), float(dist), float(fov), int(resolution), float(boxwarp), torch.device(device), dtype)

@@ -228,16 +228,20 @@ class TriPlaneGenerator(torch.nn.Module):
                 x["z"] = torch.tensor(np.stack([np.random.RandomState(s).randn(self.z_dim) for s in x["seeds"]]),
                                       device=device, dtype=dtype)
             x["zs"] = x["z"][:, None, :].expand(-1, self.backbone.num_ws, -1)
+        force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
+        res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
         if "camera_params" not in x:
             if "distances" not in x:
                 x["distances"] = torch.ones_like(x["elevations"])
             if "fovs" not in x:
                 x["fovs"] = 30 * torch.ones_like(x["elevations"])
-            x["camera_params"] = torch.stack([
-                cameras.camera_label(e, a, d, fv)
-                for e, a, d, fv in zip(x["elevations"], x["azimuths"], x["distances"], x["fovs"])]).to(dtype).to(device)
-        force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
-        res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
+            # one device -> host copy for all view parameters, then labels and rays memoised per view (cameras.cached_view)
+            vals = torch.stack([torch.as_tensor(x[k]).reshape(-1).double() for k in ("elevations", "azimuths", "distances", "fovs")]).cpu().tolist()
+            views = [cameras.cached_view(e, a, d, fv, res, self.rendering_kwargs["box_warp"], device, dtype) for e, a, d, fv in zip(*vals)]
+            x["camera_params"] = torch.stack([v[0] for v in views])
+            if force_rays is None:
+                x["force_rays"] = force_rays = {"ray_origins": torch.stack([v[1] for v in views]),
+                                                "ray_directions": torch.stack([v[2] for v in views])}
         if force_rays is None:
             cp = x["camera_params"]
             intr = cp[:, 16:25].view(-1, 3, 3)
