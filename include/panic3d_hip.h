@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 4
+#define P3D_ABI_VERSION 5
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -213,16 +213,16 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
  * 32 cycles per 16 channels instead of 8 of 64.  w_f16x2: 2 x [O][ks*ks][I] f16, the hi parts followed by the lo parts, made
  * once per layer by p3d_conv_weights_to_f16x2 (16-byte aligned, O*I*ks*ks*2 bytes a multiple of 16; the weights are stored
  * scaled by 2^6, the kernel scales s*x by 2^4 and the accumulators back by 2^-10, because the matrix cores flush f16
- * subnormals).  Domain: |s*x| < 8188, |w| < 2047 (beyond that the operand saturates; it does not become inf).  Same arguments
- * and semantics as p3d_modconv2d_f32 otherwise; I % 16 == 0. */
+ * subnormals).  Domain: |s*x| <= 4094 (= 65504 / 2^4), |w| < 1023: a modulated activation beyond that (or NaN) is clamped to the
+ * f16 range — finite, wrong — and reported through `saturated`: a CALLER-OWNED device word (or null: not reported) that the
+ * kernels OR with 1, stream-ordered like every other output; the caller zeroes it and reads it when it wants to know (ABI 5:
+ * the library keeps no flag of its own — "no global mutable state").  Same arguments and semantics as
+ * p3d_modconv2d_f32 otherwise; I % 16 == 0. */
 int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream);
-/* 1 if any two-term convolution since the last reset met a modulated activation outside its domain (|s*x| > 8188, or NaN) and
- * saturated it, else 0 (-1: the device could not be read).  Synchronises the device: a debugging / validation call. */
-int p3d_conv_f16x2_saturated(int reset);
 int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
                                const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
                                const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               void* workspace, size_t workspace_bytes, uint32_t* saturated, void* stream);
 
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by

@@ -43,21 +43,45 @@ def built_hash(so=SO):
     return info.rsplit("src=", 1)[1].strip() if "src=" in info else None
 
 
+def sources_present():
+    return all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES + HEADERS)
+
+
 def needs_build():
     """True when the library is missing or was compiled from other sources than the ones on disk (content hash, not mtimes:
-    a copied tree keeps no useful timestamps)."""
-    return not os.path.exists(SO) or built_hash() != source_hash()
+    a copied tree keeps no useful timestamps).  A deployment that ships only the .so (no csrc/) has nothing to compare with:
+    the existing library is trusted."""
+    if not os.path.exists(SO):
+        return True
+    if not sources_present():
+        return False
+    return built_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> libpanic3d_hip.so next to this file.  Returns the path."""
+    """Compile csrc/*.hip -> libpanic3d_hip.so next to this file.  Returns the path.
+    Safe under torch.distributed.run (every rank may get here at once): one process compiles under an exclusive file lock into
+    its own temporary file and renames it into place; the others wait on the lock and then find the library up to date."""
+    import fcntl
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DP3D_SRC_HASH="{source_hash()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(SO + ".tmp", SO)
+    with open(SO + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another rank built it while this one waited
+                return SO
+            tmp = f"{SO}.{os.getpid()}.tmp"
+            cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DP3D_SRC_HASH="{source_hash()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, SO)  # atomic: a process that is dlopen-ing the old file keeps its inode
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return SO
 
 

@@ -11,7 +11,7 @@ SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D
 P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP, P3D_FLAG_NO_STAGING, P3D_FLAG_FORCE_STAGING = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192
 P3D_FLAG_DISPARITY = 4096
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 4  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 5  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -59,8 +59,7 @@ SIGNATURES = {
     "p3d_conv_weights_to_f16": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
-    "p3d_conv_f16x2_saturated": (_I, [_I]),
-    "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
+    "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_upsample2d_add_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "p3d_bias_act_f32": (_I, [_P, _P, _L, _I, _L, _I, _F, _F, _F, _P, _P]),
@@ -88,7 +87,7 @@ def lib():
             if _build.needs_build():  # compiled from other sources than the ones on disk: never run stale kernels silently
                 import sys
                 print(f"panic3d_amd: {SO} does not match csrc/ (source hash): rebuilding", file=sys.stderr)
-                _build.build(force=True)
+                _build.build()  # (not force: under torch.distributed.run the rank that gets the lock builds, the others find it done)
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -119,7 +119,11 @@ def patch_ray_limits(ray_start, ray_end):
 import functools
 
 
-@functools.lru_cache(maxsize=512)
+# generate.py renders 16 fixed poses per subject (4 ortho + 12 perspective): 32 entries hold that set at two resolutions.  The
+# entries are device tensors (2 x [3,res,res] fp32: 6 MB per view at 512^2), so the cache is kept SMALL — a 360-degree sweep or
+# random evaluation poses would otherwise pin one entry per unique pose (3 GB at 512^2 with the old 512 entries) — and is
+# dropped by cached_view_clear() (e.g. after moving a generator to another device).
+@functools.lru_cache(maxsize=32)
 def _cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype):
     label = camera_label(elev, azim, dist, fov).to(dtype).to(device)
     if fov < 0:  # negative fov = orthographic view (training/triplane.py:402-414)
@@ -135,3 +139,8 @@ def cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.
     generate.py renders the same 16 poses for every subject, and the ray generation is a dozen small launches plus host maths.
     The tensors are shared between calls: callers stack / copy them, they never write into them."""
     return _cached_view(float(elev), float(azim), float(dist), float(fov), int(resolution), float(boxwarp), torch.device(device), dtype)
+
+
+def cached_view_clear():
+    """Drop the memoised views (device tensors)."""
+    _cached_view.cache_clear()

@@ -55,6 +55,7 @@ struct ConvParams {
     float alpha, gain, clamp;
     int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
     int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
+    unsigned int* sat;    // caller-owned device word, OR-ed with 1 when a two-term operand left its domain (or null: not reported)
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
@@ -380,14 +381,15 @@ DEV ConvStagePlanH conv_plan_h(const ConvParams& p, int tid, int gy0, int gx0, i
 // behind the hi ones, and the weights single-buffered (hi + lo of a chunk are 36 KB for 3x3: two workgroups per CU still fit).
 // The matrix cores flush f16 subnormals, so the operands are scaled by a power of two before they are split — the weights by
 // 2^6 (lo parts of |w| >= 2^-8 stay normal), the modulated activations s*x by 2^4 (|s*x| >= 2^-6; more headroom at the top:
-// hi + lo saturate, they do not overflow, at |s*x| = 2 * 65504 / 16 = 8188) — and the accumulators are scaled back by 2^-10
+// hi saturates, it does not overflow, at |s*x| = 65504 / 16 = 4094) — and the accumulators are scaled back by 2^-10
 // when they are stored; all exact.  A value below those thresholds loses its lo part (absolute error <= 2^-11 |v|, i.e.
 // below 8e-6 / 2e-6): rare and small next to the 2^-22 relative rounding of the ordinary terms.
 #define HX_SPLIT_SCALE_X 16.0f
 #define HX_SPLIT_SCALE_W 64.0f
 #define HX_SPLIT_UNSCALE (1.0f / 1024.0f)
-// set (never cleared by a kernel) when a two-term operand left the representable range: p3d_conv_f16x2_saturated()
-__device__ unsigned int g_f16x2_saturated = 0u;
+// Out of domain: a scaled operand beyond the f16 range (|s*x| > 65504 / 16 = 4094, or NaN) is clamped to +-65504 — finite, wrong —
+// and the CALLER's flag word (ConvParams::sat, the `saturated` argument of p3d_modconv2d_f16x2mma_f32) is OR-ed with 1: no state
+// lives in the library.
 template <int NT, bool SPLIT = false>
 struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[NT ? (NT * 128 + 255) / 256 : 1]; i32x4 wl[SPLIT ? (NT * 128 + 255) / 256 : 1]; };  // NT = 0: activations only
 
@@ -421,7 +423,7 @@ DEV void conv_gload_h(const ConvParams& p, const ConvStagePlanH& pl, const float
 }
 
 template <int NT, bool SPLIT, typename REGS>
-DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const REGS& r) {
+DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const REGS& r, unsigned int* satp = nullptr) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (pl.xdst[u] < 0) continue;
@@ -432,14 +434,14 @@ DEV void conv_lstore_hx(char* xs, const ConvStagePlanH& pl, const REGS& r) {
             float m = r.s[u][i >> 2][i & 3] * r.x[u][i];
             if constexpr (SPLIT) {
                 m *= HX_SPLIT_SCALE_X;
-                sat = sat || !(__builtin_fabsf(m) <= 2.0f * 65504.0f);  // beyond hi + lo (or NaN)
+                sat = sat || !(__builtin_fabsf(m) <= 65504.0f);  // beyond the f16 range (or NaN): hi is clamped, lo = 0
                 m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
             }
             v[i] = (_Float16)m;  // RNE
             if constexpr (SPLIT) l[i] = (_Float16)(m - (float)v[i]);
         }
         if constexpr (SPLIT) {
-            if (sat) atomicOr(&g_f16x2_saturated, 1u);
+            if (sat && satp) atomicOr(satp, 1u);
         }
         *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
         if constexpr (SPLIT) *reinterpret_cast<f16x8*>(xs + HX_BYTES + pl.xdst[u]) = l;
@@ -458,7 +460,7 @@ DEV void conv_lstore_hw(char* ws, int tid, const ConvStageRegsH<NT, SPLIT>& r) {
 }
 template <int NT, bool SPLIT = false>
 DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
-    conv_lstore_hx<NT, SPLIT>(xs, pl, r);
+    conv_lstore_hx<NT, SPLIT>(xs, pl, r, p.sat);
     conv_lstore_hw<NT, SPLIT>(ws, tid, r);
 }
 // the weight pieces of one chunk (hi and lo) straight from L2 into LDS (buffer_load_dwordx4 ... lds: wave-uniform LDS base +
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
     if constexpr (SPLIT) {
         conv_gload_h<0, false>(p, pl, xn, sn, ic_beg, ic_end, rg);
         conv_glds_w2<NT>(p, pl, ws[0], tid, ic_beg, ic_end);
-        conv_lstore_hx<0, true>(xs[0], pl, rg);
+        conv_lstore_hx<0, true>(xs[0], pl, rg, p.sat);
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the LDS-direct loads have landed
     } else {
         conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);  // the stores (and their vmcnt waits) stay behind the MFMAs
         if constexpr (SPLIT) {  // single-buffered weights: everybody has to be done with them first
-            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg);
+            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg, p.sat);
             __syncthreads();
             if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end);
             __builtin_amdgcn_s_waitcnt(0);
@@ -639,7 +641,7 @@ DEV void conv_gload_w(const ConvParams& p, const ConvStagePlanW& pl, const float
     }
 }
 // hi image at xs, lo image at xs + 2 * WX_BYTES (the two buffers of one kind are adjacent)
-DEV void conv_lstore_w(char* xs, const ConvStagePlanW& pl, const ConvStageRegsW& r) {
+DEV void conv_lstore_w(char* xs, const ConvStagePlanW& pl, const ConvStageRegsW& r, unsigned int* satp) {
 #pragma unroll
     for (int u = 0; u < WX_ROUNDS; ++u) {
         if (pl.xdst[u] < 0) continue;
@@ -648,14 +650,14 @@ DEV void conv_lstore_w(char* xs, const ConvStagePlanW& pl, const ConvStageRegsW&
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float m = r.s[u][i >> 2][i & 3] * r.x[u][i] * HX_SPLIT_SCALE_X;
-            sat = sat || !(__builtin_fabsf(m) <= 2.0f * 65504.0f);
+            sat = sat || !(__builtin_fabsf(m) <= 65504.0f);
             m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
             v[i] = (_Float16)m;
             l[i] = (_Float16)(m - (float)v[i]);
         }
         *reinterpret_cast<f16x8*>(xs + pl.xdst[u]) = v;
         *reinterpret_cast<f16x8*>(xs + 2 * WX_BYTES + pl.xdst[u]) = l;
-        if (sat) atomicOr(&g_f16x2_saturated, 1u);
+        if (sat && satp) atomicOr(satp, 1u);
     }
 }
 // one half (hi: which = 0, lo: which = 1) of a chunk's weight image, L2 -> LDS
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
     conv_gload_w(p, pl, xn, sn, ic_beg, ic_end, rg);
     conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 0);
     conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 1);
-    conv_lstore_w(xs[0][0], pl, rg);
+    conv_lstore_w(xs[0][0], pl, rg, p.sat);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     int buf = 0;
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) conv_lstore_w(xs[0][buf ^ 1], pl, rg);   // (waits for this chunk's a_lo too: it was requested before phase 1)
+        if (more) conv_lstore_w(xs[0][buf ^ 1], pl, rg, p.sat);   // (waits for this chunk's a_lo too: it was requested before phase 1)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();                                    // a_hi is free, a_lo has landed everywhere
         if (more) conv_glds_wh(p, pl, ws, tid, ic0 + 16, ic_end, 0);
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
     if constexpr (SPLIT) {
         conv_gload_h<0, false>(p, pl, xn, sn, ic_beg, ic_end, rg);
         conv_glds_w2<NT>(p, pl, ws[0], tid, ic_beg, ic_end);
-        conv_lstore_hx<0, true>(xs[0], pl, rg);
+        conv_lstore_hx<0, true>(xs[0], pl, rg, p.sat);
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the LDS-direct loads have landed
     } else {
         conv_gload_h<NT>(p, pl, xn, sn, ic_beg, ic_end, rg);
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
             run_pass(0, HX_BYTES);   // a_hi x b_lo
             run_pass(0, 0);          // a_hi x b_hi
             __builtin_amdgcn_sched_barrier(0);
-            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg);
+            if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg, p.sat);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();         // a_hi is free, a_lo (requested before this chunk's first pass) has landed everywhere
             if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end, 0);
@@ -1180,7 +1182,7 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
 static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int wsplit, int O, int ks,
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, void* stream, unsigned int* sat = nullptr) {
     if (!x || !w || !styles || !y || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
     // 32-bit byte offsets inside one image / the weight tensor (raw buffer addressing)
     if ((long long)I * H * W * 4 >= (1ll << 31) || (long long)O * I * ks * ks * 4 >= (1ll << 31)) return P3D_E_RANGE;
@@ -1203,7 +1205,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     ConvParams p;
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
-    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW;
+    p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
     float* conv_dst = (ksplit > 1) ? part : (up == 2 ? tmp : y);
     p.y = conv_dst;
@@ -1268,16 +1270,6 @@ int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, v
 int p3d_conv_weights_to_f16x2(const float* w, int O, int I, int ks, void* w_f16x2, void* stream) {
     return weights_to_f16(w, O, I, ks, w_f16x2, 1, stream);
 }
-int p3d_conv_f16x2_saturated(int reset) {
-    unsigned int v = 0u;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f16x2_saturated), sizeof(v)) != hipSuccess) return -1;  // (synchronises the device)
-    if (reset && v) {
-        const unsigned int z = 0u;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16x2_saturated), &z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return v ? 1 : 0;
-}
-
 int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16, int O, int ks,
                              const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias,
                              int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
@@ -1291,11 +1283,11 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
 int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
                                const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
                                const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               void* workspace, size_t workspace_bytes, uint32_t* saturated, void* stream) {
     if (!w_f16x2) return P3D_E_ARG;
     if (I % 16 != 0 || ((uintptr_t)w_f16x2 & 15) || ((size_t)O * I * ks * ks * 2) % 16 != 0) return P3D_E_RANGE;
     return modconv_impl(x, N, I, H, W, w, w_f16x2, 1, O, ks, styles, demodulate, demod_coefs, noise, noise_per_sample, bias, up, act,
-                        alpha, gain, clamp, fir, y, workspace, workspace_bytes, stream);
+                        alpha, gain, clamp, fir, y, workspace, workspace_bytes, stream, (unsigned int*)saturated);
 }
 
 int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, int fh, int fw, int up, int down, int padx0,

@@ -287,21 +287,42 @@ class TriPlaneGenerator(torch.nn.Module):
             ret["image_prepaste"] = ret["image"]
             ret["paste"] = paste_front(self, x, ret, **x["paste_params"])
             ret["image"] = ret["paste"]["image"]
-        if os.environ.get("P3D_CHECK_CONV_DOMAIN"):  # validation runs: did a two-term convolution leave its domain? (synchronises)
-            from . import ops
-            if ops.conv_f16x2_saturated(reset=True):
-                import warnings
-                warnings.warn("a two-term f16 convolution met |s*x| > 8188 and saturated it: use set_conv_mma('f32') for this model",
-                              RuntimeWarning)
+        if os.environ.get("P3D_CHECK_CONV_DOMAIN") and self.conv_domain_violated():  # validation runs (synchronises)
+            import warnings
+            warnings.warn("a two-term f16 convolution met |s*x| > 4094 and saturated it: use set_conv_mma('f32') for this model",
+                          RuntimeWarning)
         return ret
+
+    def watch_conv_domain(self, device=None):
+        """Give every modulated 3x3 layer of THIS generator one flag word (owned by the generator, on its device) that the two-term
+        f16 convolutions raise when a modulated activation leaves their domain |s*x| <= 4094.  Per generator, not per process:
+        two generators on two streams do not share it (the C ABI keeps no such state, include/panic3d_hip.h ABI 5)."""
+        from . import ops
+        device = device if device is not None else next(self.parameters()).device
+        flag = ops.conv_domain_flag(device)
+        for m in list(self.backbone.modules()) + list(self.superresolution.modules()):
+            if isinstance(m, stylegan2.SynthesisLayer):
+                m.conv_domain_flag = flag
+        self._conv_domain_flag = flag
+        return flag
+
+    def conv_domain_violated(self, reset=True):
+        """True if a two-term convolution of this generator saturated an operand since the last reset (synchronises).  The flag is
+        created on first use: convolutions that ran before `watch_conv_domain()` were not watched."""
+        from . import ops
+        flag = getattr(self, "_conv_domain_flag", None)
+        if flag is None or flag.device != next(self.parameters()).device:
+            self.watch_conv_domain()
+            return False
+        return ops.conv_domain_violated(flag, reset)
 
     def set_force_sigmoid(self, state):
         return self.decoder.set_force_sigmoid(state)
 
     def set_conv_mma(self, mode):
         """How the 3x3 convolutions of the backbone and of the super-resolution feed the matrix cores: "f32" (fp32 operands,
-        v_mfma_f32_32x32x2_f32), "x2" (two-term f16 operands: fp32-class results, ~2x faster; domain |s*x| < 8188, checked by
-        ops.conv_f16x2_saturated()), "f16" (one f16 term: the precision of the reference's fp16 blocks) or None (the
+        v_mfma_f32_32x32x2_f32), "x2" (two-term f16 operands: fp32-class results, ~2x faster; domain |s*x| <= 4094, watched by
+        watch_conv_domain() / conv_domain_violated()), "f16" (one f16 term: the precision of the reference's fp16 blocks) or None (the
         package default, stylegan2.DEFAULT_CONV_MMA)."""
         val = {"f32": False, "x2": "x2", "f16": True, None: None}[mode]
         for m in list(self.backbone.modules()) + list(self.superresolution.modules()):

@@ -520,13 +520,18 @@ def conv_weights_to_f16(weight, split=False):
     return wh
 
 
-def conv_f16x2_saturated(reset=True):
-    """True if a two-term f16 convolution met a modulated activation outside its domain (|s*x| > 8188) since the last reset.
-    Synchronises the device."""
-    rc = _lib.lib().p3d_conv_f16x2_saturated(int(bool(reset)))
-    if rc < 0:
-        raise RuntimeError("p3d_conv_f16x2_saturated: device not readable")
-    return bool(rc)
+def conv_domain_flag(device):
+    """A caller-owned flag word for the two-term f16 convolutions (`saturated` argument of p3d_modconv2d_f16x2mma_f32, ABI 5): the
+    kernels OR it with 1 when a modulated activation leaves the domain |s*x| <= 4094 (or is NaN).  Zeroed here."""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def conv_domain_violated(flag, reset=True):
+    """Read a conv_domain_flag (synchronises the stream); reset: zero it again."""
+    hit = bool(flag.item() != 0)
+    if hit and reset:
+        flag.zero_()
+    return hit
 
 
 def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
@@ -538,13 +543,14 @@ def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
-                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None):
+                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
     noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
     weight_f16 (from conv_weights_to_f16): run the matrix cores on f16 operands (fp32 accumulate, fp32 in/out) — what the
     reference's fp16 super-resolution blocks do on the GPU, with less rounding; needs I % 16 == 0.  A [2,O,k*k,I] tensor
-    (conv_weights_to_f16(split=True)) selects the two-term variant: fp32-class results on the f16 matrix cores."""
+    (conv_weights_to_f16(split=True)) selects the two-term variant: fp32-class results on the f16 matrix cores; `saturated`: an
+    int32 [1] device tensor of the caller (conv_domain_flag) that the two-term kernels OR with 1 when |s*x| > 4094."""
     x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
     N, I, H, W = x.shape
     O, I2, kh, kw = weight.shape
@@ -582,10 +588,14 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
             if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape)[-3:] != (O, kh * kw, I) or not weight_f16.is_contiguous() \
                     or (split and weight_f16.shape[0] != 2):
                 raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] / [2,O,k*k,I] float16 tensor of conv_weights_to_f16")
-            fn, name = (L.p3d_modconv2d_f16x2mma_f32, "p3d_modconv2d_f16x2mma_f32") if split else (L.p3d_modconv2d_f16mma_f32, "p3d_modconv2d_f16mma_f32")
-            rc = fn(_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
-                    _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
-            _lib.check(rc, name)
+            args = (_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
+                    _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb)
+            if split:
+                if saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != x.device):
+                    raise RuntimeError("saturated must be an int32 [1] tensor on x's device (ops.conv_domain_flag)")
+                _lib.check(L.p3d_modconv2d_f16x2mma_f32(*args, _p(saturated), _stream()), "p3d_modconv2d_f16x2mma_f32")
+            else:
+                _lib.check(L.p3d_modconv2d_f16mma_f32(*args, _stream()), "p3d_modconv2d_f16mma_f32")
         else:
             rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(dcoef), _p(noise), nps,
                                      _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())

@@ -3,8 +3,42 @@ GPU; the ONLY collective is one gather of final RGBA frames to rank 0 (RCCL over
 in the CPU tests).  The reference's eval path is single-GPU (_scripts/eval/generate.py:16); its view loop
 (generate.py:108-117) and the 360-degree sweep (_train/eg3dc/util/eg3dc_v0.py:64-87 quickspin) are what gets sharded.
 """
+import os
+import socket
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def ensure_ranks(gpus, argv=None):
+    """`--gpus N` of bench.py / tools/sweep360.py / tools/bench_c5.py: make sure N ranks exist, one process per GPU.
+
+    * under a launcher (RANK in the environment — `python -m torch.distributed.run ...`, the driver's form for N > 1):
+      WORLD_SIZE must equal N (N = None: accept whatever the launcher started), else SystemExit;
+    * no launcher and N > 1: this process re-executes itself under `python -m torch.distributed.run --nnodes=1
+      --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` with the same command line (does not return) — the
+      reference's multi-process entry point spawns its own ranks too (_train/eg3dc/trainers/train_eclustrousC.py:39-50,109-114);
+    * no launcher and N in (None, 1): single process, returns.
+    Device-count checks are the caller's (they need torch.cuda, which a CPU dry launch must not touch)."""
+    if "RANK" in os.environ:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if gpus is not None and world != int(gpus):
+            raise SystemExit(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if gpus is None or int(gpus) <= 1:
+        return
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = list(sys.argv if argv is None else argv)
+    env = dict(os.environ, P3D_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + argv
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def partition(n_items, world_size, rank):
@@ -33,6 +67,18 @@ def frames_rgba(feat, wsum, res, out=None, channels_last=False):
     return out
 
 
+_COMM_READY = set()  # (backend, world) whose default communicator has seen a group-wide collective in this process
+
+
+def _ensure_communicator(device):
+    """RCCL/NCCL build a communicator lazily, and PyTorch requires EVERY rank to take part in the first batched point-to-point
+    operation of a group — ranks without frames skip the P2P batch, so one tiny group-wide all_reduce goes first (once per process)."""
+    key = (dist.get_backend(), dist.get_world_size())
+    if key not in _COMM_READY:
+        dist.all_reduce(torch.zeros(1, device=device))
+        _COMM_READY.add(key)
+
+
 def gather_frames(local, counts=None, dst=0, force=False):
     """Gather per-rank frame stacks [n_r, ...] to rank `dst` in rank order: a TRUE gather — every rank sends its own frames
     to dst once and nothing else moves (north_star: "RCCL gather over xGMI of final RGBA only").  Issued as one batch of
@@ -50,6 +96,7 @@ def gather_frames(local, counts=None, dst=0, force=False):
     if local.shape[0] != counts[rank]:
         raise RuntimeError(f"rank {rank} holds {local.shape[0]} frames but counts[{rank}] = {counts[rank]}")
     local = local.contiguous()
+    _ensure_communicator(local.device)
     if rank != dst:
         if counts[rank] > 0:
             for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst)]):
@@ -84,7 +131,16 @@ class FrameGather:
         if self.rank == self.dst:
             self.out = torch.empty((self.world * self.per_rank,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         self.pending = []
-        self.p2p = False  # set if the backend refuses gather(): batched point-to-point from then on
+        # gather() or batched point-to-point: decided ONCE, collectively (a rank that switched on its own — e.g. after an
+        # exception only dst sees — would leave the others inside gather()): P3D_GATHER_P2P=1 or a backend without gather(),
+        # then the maximum over ranks, which is also the group-wide collective that has to precede the first P2P batch
+        want = os.environ.get("P3D_GATHER_P2P", "0") == "1" or (self.active and dist.get_backend() not in ("nccl", "gloo"))
+        if self.active and self.world > 1:
+            flag = torch.tensor([1.0 if want else 0.0], device=local.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            want = bool(flag.item() > 0)
+            _COMM_READY.add((dist.get_backend(), self.world))
+        self.p2p = want
 
     def push(self, lo, hi):
         """Frames [lo, hi) of every rank's stack are final: start moving them."""
@@ -98,11 +154,8 @@ class FrameGather:
         # asynchronous: it runs on the collective's stream, this rank's render stream goes on
         dests = [self.out[r * self.per_rank + lo:r * self.per_rank + hi] for r in range(self.world)] if self.rank == self.dst else None
         if not self.p2p:
-            try:
-                self.pending.append(dist.gather(self.local[lo:hi], gather_list=dests, dst=self.dst, async_op=True))
-                return
-            except (NotImplementedError, TypeError, ValueError):  # argument-level refusal (the same on every rank): batched P2P instead
-                self.p2p = True
+            self.pending.append(dist.gather(self.local[lo:hi], gather_list=dests, dst=self.dst, async_op=True))
+            return
         if self.rank != self.dst:
             self.pending += dist.batch_isend_irecv([dist.P2POp(dist.isend, self.local[lo:hi], self.dst)])
             return

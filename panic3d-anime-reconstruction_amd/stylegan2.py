@@ -169,7 +169,7 @@ class SynthesisLayer(_CacheFree):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
-                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self),
+                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None),
                                     dcoef=dcoef)
 
 
@@ -185,7 +185,7 @@ class ToRGBLayer(_CacheFree):
     def forward(self, x, w, fused_modconv=True, pre=None):
         styles = pre[0] if pre is not None else self.affine(w) * self.weight_gain
         return ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
-                                    clamp=self.conv_clamp, weight_f16=_f16_operand(self))
+                                    clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None))
 
 
 class StylePlan:

@@ -35,16 +35,33 @@ def _check_line(d, steps):
     assert abs(d["value"] - 512 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]  # whole-job rays / wall time of the K steps
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0 and "traffic" in r
-    # achieved = algorithmic bytes per launch / the every-sample kernel's time (HIP events)
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_no_early_out"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    assert d["verify"]["ok"] is True
+    assert r["unit"] == "GB/s" and r["bound"] in ("hbm", "l2") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0  # never achieved > peak under its own label
+    hbm_equiv = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_no_early_out"] * 1e-3) / 1e9  # the SURVEY 8(d) contract figure
+    if r["bound"] == "hbm":  # achieved = algorithmic bytes per launch / the every-sample kernel's time (HIP events)
+        assert r["peak"] == 8000.0 and abs(r["achieved"] - hbm_equiv) < 1e-6 * hbm_equiv
+    else:  # the yardstick exceeded the HBM peak: relabelled to the L2-level gather fraction, contract figure kept beside it
+        assert r["peak"] == 34500.0 and abs(r["hbm_algorithmic_equiv_frac"] - hbm_equiv / 8000.0) < 1e-6 and hbm_equiv > 8000.0
+    ph = r["physical"]["l2_gather"]
+    assert 0 < ph["frac_no_early_out"] <= 1.0 and 0 < ph["frac_timed"] <= 1.0
+    v = d["verify"]
+    assert v["ok"] is True and v["exact"]["ok"] and v["tolerance"]["ok"]
+    # non-vacuous: the verified scene has a real surface, the exact mode is bit-identical to the oracle, PSNR vs the reference itself
+    assert v["exact"]["wsum_mean"] > 0.2 and all(v["exact"][k]["bit_exact_vs_oracle"] for k in ("feat", "depth", "wsum", "xyz"))
+    for m in ("exact", "tolerance"):
+        rb = v[m]["reference_block"]
+        assert rb["ok"] and (isinstance(rb["psnr_vs_reference_db"], str) or rb["psnr_vs_reference_db"] > 80.0)
 
 
 def test_bench_default_invocation_prints_the_contract_line():
     d = _bench(SMALL, launched=False)
     _check_line(d, 6)
+    assert d["dtype"] == "f32" and d["config"]["final_pass"] == "exact" and d["config"]["scene"] == "canonical"  # the exact contract is what is timed
+    rows = {(r["scene"], r["mode"]) for r in d["results"]}
+    assert rows == {(s, m) for s in ("canonical", "surface") for m in ("exact", "tolerance")}
+    assert all(r["kernel_ms"] > 0 and r["kernel_ms_no_early_out"] > 0 and 0 < r["decode_steps_executed_frac"] <= 1 for r in d["results"])
+    assert len(d["eval_faithful"]["rows"]) == 4 and all(r["Sc"] == 96 and r["Sf"] == 96 for r in d["eval_faithful"]["rows"])
+    assert d["sustained"]["seconds"] >= 2.0 and d["sustained"]["sustained_ms_per_step"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "rays/s" and c["sample"]
     assert "per_rank" not in d
@@ -55,6 +72,8 @@ def test_bench_under_torch_distributed_run_streams_the_frames():
     _check_line(d, 6)
     assert len(d["per_rank"]["ms_per_step_render"]) == 1 and len(d["per_rank"]["gather_ms"]) == 1
     assert "slices sent while the next frames render" in d["config"]["workload"]
-    e = _bench(SMALL + ["--no-cpu-baseline", "--gather", "end", "--exact"], launched=True)
+    assert d["n_ranks_seen"] == 1
+    e = _bench(SMALL + ["--no-cpu-baseline", "--no-table", "--gather", "end", "--fast"], launched=True)
     _check_line(e, 6)
-    assert e["dtype"] == "f32" and "ONE gather" in e["config"]["workload"]
+    assert e["dtype"].startswith("f32 (final-pass MLP operands as two-term f16") and "ONE gather" in e["config"]["workload"]
+    assert "results" not in e

@@ -46,6 +46,17 @@ def test_c5_grid_same_sigma_for_world_size_1_and_2():
 
 
 def test_bench_two_ranks_prints_per_rank_times_and_verifies():
-    out = _run("bench.py", ["--gpus", "2", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"], 2, 29554)
-    assert out["n_gpus"] == 2 and out["verify"]["ok"]
+    out = _run("bench.py", ["--gpus", "2", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-table"], 2, 29554)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["verify"]["ok"]
     assert len(out["per_rank"]["ms_per_step_render"]) == 2 and len(out["per_rank"]["gather_ms"]) == 2
+
+
+def test_unwrapped_gpus_flag_starts_its_own_ranks():
+    """The driver's plain form `python bench.py --gpus 2` (no torch.distributed.run around it) and the tools' `--gpus 2`."""
+    out = _run("bench.py", ["--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-table", "--no-verify"], 1, 0)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and len(out["per_rank"]["gather_ms"]) == 2
+    a = _run("tools/sweep360.py", ["--views", "8", "--res", "256", "--check"], 1, 0)
+    b = _run("tools/sweep360.py", ["--views", "8", "--res", "256", "--check", "--gpus", "2"], 1, 0)
+    assert b["n_gpus"] == 2 and a["sha256"] == b["sha256"]
+    c = _run("tools/bench_c5.py", ["--grid", "128", "--check", "--gpus", "2"], 1, 0)
+    assert c["n_gpus"] == 2

@@ -377,21 +377,30 @@ def test_modconv_f16x2_operands_are_fp32_class(hip, I, O, H, up, ks, N):
 
 
 def test_modconv_f16x2_saturation_is_reported(hip):
-    """Outside its domain (|s*x| > 8188) the two-term convolution saturates the operand — finite, wrong — and says so."""
+    """Outside its domain (|s*x| > 4094 = 65504 / 16) the two-term convolution saturates the operand — finite, wrong — and says so
+    in the CALLER's flag word (ABI 5: no flag lives in the library); inside it the result is fp32-class.  ADVICE r02: the band
+    4094 < |s*x| <= 8188 used to be clamped silently — probed at 6000."""
     ops = hip.ops
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 32, 16, 16, generator=g).cuda(); w = torch.randn(64, 32, 3, 3, generator=g).cuda()
     s = torch.ones(1, 32).cuda()
     w2 = ops.conv_weights_to_f16(w, split=True)
-    ops.conv_f16x2_saturated(reset=True)
-    y = ops.modulated_conv2d(x * 100, w, s, padding=1, weight_f16=w2)
-    assert not ops.conv_f16x2_saturated() and torch.isfinite(y).all()
+    flag, other = ops.conv_domain_flag(x.device), ops.conv_domain_flag(x.device)
+    y = ops.modulated_conv2d(x * 100, w, s, padding=1, weight_f16=w2, saturated=flag)
+    assert not ops.conv_domain_violated(flag) and torch.isfinite(y).all()
     y32 = ops.modulated_conv2d(x * 100, w, s, padding=1)
     assert (y - y32).abs().max() < 1e-5 * y32.abs().max()
-    x[0, 3, 5, 5] = 9000.0
-    y = ops.modulated_conv2d(x, w, s, padding=1, weight_f16=w2)
-    assert torch.isfinite(y).all()
-    assert ops.conv_f16x2_saturated(reset=True) and not ops.conv_f16x2_saturated()
+    xe = x.clone(); xe[0, 3, 5, 5] = 4000.0  # the edge of the domain: still exact to fp32 class
+    ye = ops.modulated_conv2d(xe, w, s, padding=1, weight_f16=w2, saturated=flag)
+    ye32 = ops.modulated_conv2d(xe, w, s, padding=1)
+    assert not ops.conv_domain_violated(flag) and (ye - ye32).abs().max() < 1e-5 * ye32.abs().max()
+    for big in (6000.0, 9000.0, float("nan")):
+        xb = x.clone(); xb[0, 3, 5, 5] = big
+        y = ops.modulated_conv2d(xb, w, s, padding=1, weight_f16=w2, saturated=flag)
+        assert torch.isfinite(y).all()
+        assert ops.conv_domain_violated(flag, reset=True) and not ops.conv_domain_violated(flag), big
+        ops.modulated_conv2d(xb, w, s, padding=1, weight_f16=w2)  # no flag passed: nothing to report to, must not fault
+    assert not ops.conv_domain_violated(other)  # a flag of another caller never moves
 
 
 def test_generator_conv_mma_modes_agree(hip):
@@ -405,13 +414,14 @@ def test_generator_conv_mma_modes_agree(hip):
              seeds=[3], cond={}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
     out = {}
     with torch.no_grad():
+        G.watch_conv_domain()
         for mode in ("f32", "x2", "f16"):
             G.set_conv_mma(mode)
             G._inject_draws = (dev(g["jitter"])[:1], dev(g["u"])[:256])
             out[mode] = G.f(dict(x))
     G._inject_draws = None
     G.set_conv_mma(None)
-    assert not hip.ops.conv_f16x2_saturated()
+    assert not G.conv_domain_violated()
     used = [m for m in list(G.backbone.modules()) + list(G.superresolution.modules()) if getattr(m, "_wh", None) is not None]
     assert len(used) >= 6
     psnr = lambda a, b: 10 * np.log10(4.0 / max(float(((a - b).double() ** 2).mean()), 1e-30))

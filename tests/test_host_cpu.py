@@ -219,6 +219,25 @@ def test_streamed_frame_gather_gloo_world3(tmp_path, p2p):
     assert "GATHER_OK" in r.stdout
 
 
+def test_bench_gpus_flag_starts_its_own_ranks_dry_launch():
+    """`python bench.py --gpus 2` — the driver's plain form, no torch.distributed.run around it — must start two ranks itself
+    (the flag used to be parsed and never read).  --dry-launch stops after the rendezvous: gloo on CPU, no kernels."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_ranks_seen"] == 2 and line["world_size"] == 2 and "itself" in line["launcher"]
+    # under a launcher the world size must match --gpus: a 3-rank launch of `--gpus 2` refuses to run
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
 def test_stylegan2_state_dict_matches_reference_names(P):
     """Drop-in requirement (eg3dc_v0.py:49 copy_params_and_buffers(require_all=True)): identical parameter / buffer names
     and shapes as the reference's Generator — checked against the state_dict the reference itself produced."""

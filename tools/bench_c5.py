@@ -3,7 +3,7 @@
 grid's slowest axis split into one contiguous slab per GPU, ONE RCCL gather of the sigma slabs to rank 0, iso-surface on rank 0.
 
     python tools/bench_c5.py [--grid 512]                                                        # one GPU
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_c5.py   # 8 GPUs
+    python tools/bench_c5.py --gpus 8                                                            # 8 GPUs: starts its own 8 ranks (or run it under torch.distributed.run)
 Prints one JSON line on rank 0."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,13 @@ ap.add_argument("--grid", type=int, default=512)
 ap.add_argument("--crop", type=float, default=None, help="triplane_crop (generate.py uses 0.1): masked points are not decoded")
 ap.add_argument("--fast", action="store_true", help="tolerance-mode density decoder + LDS-staged texel boxes (opt-in)")
 ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered sigma grid (must not depend on the world size)")
+ap.add_argument("--gpus", type=int, default=None, help="N > 1 without a launcher: start the N ranks (one per GPU) under torch.distributed.run")
 a = ap.parse_args()
+from panic3d_amd import sharding as _sh
+_sh.ensure_ranks(a.gpus)  # re-executes under torch.distributed.run when needed; under a launcher WORLD_SIZE must match --gpus
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+if a.gpus is not None and torch.cuda.device_count() < a.gpus:
+    raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} device(s) visible")
 torch.cuda.set_device(lrank)
 dev = torch.device("cuda", lrank)
 if "RANK" in os.environ:

@@ -3,7 +3,7 @@
 (one process per GPU), one RCCL gather of the final RGBA frames to rank 0.
 
     python tools/sweep360.py [--views 120] [--res 512]                       # one GPU
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/sweep360.py
+    python tools/sweep360.py --gpus 8                                        # 8 GPUs: starts its own 8 ranks (or run it under torch.distributed.run)
 
 The subject's planes come from a random-init StyleGAN2-256 backbone run ONCE per rank on the HIP synthesis path (same
 seed on every rank -> identical planes; cheaper than broadcasting 25 MB); every view is one fused-renderer launch.
@@ -20,8 +20,13 @@ ap.add_argument("--batch", type=int, default=1, help="views per launch (planes s
 ap.add_argument("--check", action="store_true", help="print a sha256 of the gathered [views,4,res,res] tensor: every view draws from "
                 "its own seeded generator (the reference seeds each view: _train/eg3dc/util/eg3dc_v0.py:72), so the hash must be the "
                 "same for every world size and batch size")
+ap.add_argument("--gpus", type=int, default=None, help="N > 1 without a launcher: start the N ranks (one per GPU) under torch.distributed.run")
 a = ap.parse_args()
+from panic3d_amd import sharding as _sh
+_sh.ensure_ranks(a.gpus)  # re-executes under torch.distributed.run when needed; under a launcher WORLD_SIZE must match --gpus
 rank, world, lrank = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+if a.gpus is not None and torch.cuda.device_count() < a.gpus:
+    raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} device(s) visible")
 torch.cuda.set_device(lrank)
 dev = torch.device("cuda", lrank)
 if "RANK" in os.environ:
