@@ -278,9 +278,14 @@ P3D_DEV float p3d_march_weight(MarchState& st, float t, float sigma, float& tm_o
     return w;
 }
 
-// Batcher odd-even merge sort network on N (power of two) register-resident keys; fully unrolled at compile time.
-template <int N>
-P3D_DEV void p3d_sort_network(float (&a)[N]) {
+// Batcher odd-even merge sort network on NR register-resident keys; fully unrolled at compile time.  The network is the one for
+// N = the next power of two with keys NR..N-1 = +inf: a comparator writes min to the lower and max to the upper index, so one
+// whose upper index is >= NR never changes anything and is simply not emitted (NR = 48: 543 -> 384 comparators, NR = 96: 1471 ->
+// 1056).
+P3D_DEV constexpr int p3d_pow2_ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+template <int NR>
+P3D_DEV void p3d_sort_network(float (&a)[NR]) {
+    constexpr int N = p3d_pow2_ceil(NR);
 #pragma unroll
     for (int pp = 1; pp < N; pp <<= 1) {
 #pragma unroll
@@ -289,7 +294,7 @@ P3D_DEV void p3d_sort_network(float (&a)[N]) {
             for (int jj = k % pp; jj + k < N; jj += 2 * k) {
 #pragma unroll
                 for (int i = 0; i < k; ++i) {
-                    if (i + jj + k < N && (i + jj) / (2 * pp) == (i + jj + k) / (2 * pp)) {
+                    if (i + jj + k < NR && (i + jj) / (2 * pp) == (i + jj + k) / (2 * pp)) {
                         float x = a[i + jj], y = a[i + jj + k];
                         a[i + jj] = __builtin_fminf(x, y);
                         a[i + jj + k] = __builtin_fmaxf(x, y);
@@ -373,10 +378,18 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
         if (den < 1e-5f) den = 1.0f;
         const float bb = 0.5f * (t0[q] + t1[q]), ba = 0.5f * (t2[q] + t3[q]);
         out[q] = bb + ((ui[q] - cb[q]) / den) * (ba - bb);
+        // the result exists HERE: without this the optimiser sinks the lerp (and keeps its six LDS operands alive) down to the
+        // first use — the sorting network behind the last batch: 6 x Sf live values, 82-169 spilled VGPRs in the NF = 48 / 96 kernels
+        asm volatile("" : "+v"(out[q]));
     }
 }
 
 // NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
+//   NF = 48 / 96: Sf == NF exactly (the trainer's 48+48 and the eval-faithful 96+96 of eg3dc_v0.py:30-31): no padding keys, no
+//   `i < Sf` predicates (64 uniform predicates held in SGPR pairs were the 102-107 SGPR spills of round 2's NF = 64 kernels);
+//   NF = 64: any Sf <= 64, padded with +inf.  Sf in (64, 128] other than 96 takes the LDS path.
+//   NF >= 96 is compiled for ONE wave per SIMD (512 registers): its LDS rows (Sc + Sf + bit rows, 26 KB per wave at 96+96) cap a
+//   CU at 4-5 waves anyway, and round 2's 128-key variant under the 256-register cap spilled 31-39 VGPRs to scratch.
 // DUMP: per-stage dumps (parity tests; disables the early-outs so that every dumped density is a real decode).
 //
 // Exact early-outs (EARLY = !DUMP && !(flags & P3D_FLAG_NO_EARLY_OUT)), both decided per wavefront:
@@ -392,8 +405,10 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
 // FAST (P3D_FLAG_FAST_COLOR): the FINAL pass decodes in tolerance mode (p3d_decode_wave_fast); the coarse pass, and with it
 // the importance resampling (inverse-CDF indices, fine depths, merged depth order), stays on the exact contract.
 // EARLY: the exact early-outs (compile-time, so that the measurement / dump variant is the plain uniform loop).
+#define P3D_NF_EXACT(NF) ((NF) == 48 || (NF) == 96)
+#define P3D_NF_OCC(NF) ((NF) >= 96 ? 1 : P3D_RENDER_OCC)
 template <int NF, bool DUMP, bool FAST, bool EARLY>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_render(RenderParams p) {
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_render(RenderParams p) {
     static_assert(!(DUMP && EARLY), "dumps need every sample decoded");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_RENDER_OCC) void k_rende
     if (tile >= p.ntiles) return;  // no workgroup barrier below this line
     float* wl = lds + (FAST ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4 + (size_t)wave * p.lds_rows * 32;  // per-wave rows, 16-B aligned
 
-    const int Sc = p.Sc, Sf = p.Sf, S = Sc + Sf;
+    const int Sc = p.Sc, Sf = P3D_NF_EXACT(NF) ? NF : p.Sf, S = Sc + Sf;
     long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
     long long r;
     if (p.tile_w > 0) {
@@ -843,7 +858,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
     if (tile >= p.ntiles) return;  // no workgroup barrier below this line
     float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;
 
-    const int Sc = p.Sc, Sf = p.Sf, S = Sc + Sf;
+    const int Sc = p.Sc, Sf = P3D_NF_EXACT(NF) ? NF : p.Sf, S = Sc + Sf;
     long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
     long long r;
     if (p.tile_w > 0) {  // 4x4 pixel tile, Morton lane order
@@ -966,13 +981,25 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
         }
         const float* uu = p.u + ray * Sf;
         if constexpr (NF > 0) {
+            // as in k_render: every load of the row issued before the first search, eight draws in lock-step (the eight LDS
+            // reads of a search step in flight together; one draw at a time was a chain of 8 dependent LDS round trips x Sf)
+            constexpr int DB = 8;
             float tf[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                tf[i] = __builtin_inff();
-                if (i < Sf) {
-                    int k;
-                    tf[i] = p3d_inverse_cdf(wcA, tcA, Ns, jr, uu[i], k);
+            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? uu[i] : 0.0f;
+#pragma unroll
+            for (int i0 = 0; i0 < NF; i0 += DB) {
+                if (i0 < Sf) {  // wave-uniform
+                    float ub[DB], vb[DB];
+                    int kb[DB];
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) ub[q] = tf[i0 + q];
+                    p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, jr, ub, vb, kb);
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) tf[i0 + q] = (i0 + q < Sf) ? vb[q] : __builtin_inff();
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) tf[i0 + q] = __builtin_inff();
                 }
             }
             p3d_sort_network<NF>(tf);
@@ -1494,7 +1521,10 @@ int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float*
     }
     p.ntiles = p.tiles_per_img * N;
     // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
-    const int nf = (Sf == 0) ? 64 : (Sf <= 64 ? 64 : (Sf <= 128 ? 128 : 0));
+    // register-resident fine depths: 48 / 96 exactly (the trainer's and the eval-faithful rates), any other Sf <= 64 padded to 64;
+    // the rest sorts in LDS
+    const int nf = (Sf == 48) ? 48 : (Sf == 96) ? 96 : (Sf <= 64 ? 64 : 0);
+    const int occ = (nf >= 96) ? 1 : P3D_RENDER_OCC;  // waves per SIMD the instantiation is compiled for (P3D_NF_OCC)
     // + two bit rows over the merged list (is-coarse / known-masked) + the known-masked bits of the coarse samples
     p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0) + 2 * ((Sc + Sf + 31) >> 5) + ((Sc + 31) >> 5);
     int nwaves = P3D_RENDER_WAVES;
@@ -1512,7 +1542,7 @@ int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float*
             const size_t per_wg = lds_fixed + w * lds_wave;
             if (per_wg > 160 * 1024) continue;
             int wgs = (int)((160 * 1024) / per_wg);
-            int waves = wgs * w > 4 * P3D_RENDER_OCC ? 4 * P3D_RENDER_OCC / w * w : wgs * w;
+            int waves = wgs * w > 4 * occ ? 4 * occ / w * w : wgs * w;
             if (waves > best_waves) { best_waves = waves; best = w; }
         }
         if (best == 0) return P3D_E_RANGE;
@@ -1546,9 +1576,14 @@ int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float*
         e2 = p3d_ensure_dynamic_lds(k_render_pair<NFV>, lds_bytes);                                                  \
         if (e2 == hipSuccess) hipLaunchKernelGGL((k_render_pair<NFV>), grid2, blk2, lds_bytes, st, p);              \
     } while (0)
-        if (nf == 64) P3D_LAUNCH2(64);
-        else if (nf == 128) P3D_LAUNCH2(128);
+#ifdef P3D_ONLY_NF
+        P3D_LAUNCH2(P3D_ONLY_NF);
+#else
+        if (nf == 48) P3D_LAUNCH2(48);
+        else if (nf == 64) P3D_LAUNCH2(64);
+        else if (nf == 96) P3D_LAUNCH2(96);
         else P3D_LAUNCH2(0);
+#endif
         if (e2 != hipSuccess) return (int)e2;
         int rc2 = p3d_check_launch();
         if (rc2) return rc2;
@@ -1573,9 +1608,14 @@ int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float*
         else P3D_LAUNCH(NFV, false, FV, true);                                                                       \
     } while (0)
 #define P3D_LAUNCH_P(NFV) do { if (fast) P3D_LAUNCH_F(NFV, true); else P3D_LAUNCH_F(NFV, false); } while (0)
-    if (nf == 64) P3D_LAUNCH_P(64);
-    else if (nf == 128) P3D_LAUNCH_P(128);
+#ifdef P3D_ONLY_NF  // development builds (tools/resource_usage.py -D P3D_ONLY_NF=48): compile ONE fine-depth capacity
+    P3D_LAUNCH_P(P3D_ONLY_NF);
+#else
+    if (nf == 48) P3D_LAUNCH_P(48);
+    else if (nf == 64) P3D_LAUNCH_P(64);
+    else if (nf == 96) P3D_LAUNCH_P(96);
     else P3D_LAUNCH_P(0);
+#endif
     if (e != hipSuccess) return (int)e;
     int rc = p3d_check_launch();
     if (rc) return rc;

@@ -460,7 +460,7 @@ DEV void conv_lstore_hw(char* ws, int tid, const ConvStageRegsH<NT, SPLIT>& r) {
 }
 template <int NT, bool SPLIT = false>
 DEV void conv_lstore_h(char* xs, char* ws, int tid, const ConvStagePlanH& pl, const ConvStageRegsH<NT, SPLIT>& r) {
-    conv_lstore_hx<NT, SPLIT>(xs, pl, r, p.sat);
+    conv_lstore_hx<NT, SPLIT>(xs, pl, r);
     conv_lstore_hw<NT, SPLIT>(ws, tid, r);
 }
 // the weight pieces of one chunk (hi and lo) straight from L2 into LDS (buffer_load_dwordx4 ... lds: wave-uniform LDS base +

@@ -148,20 +148,12 @@ def test_bench_scene_512_frame_vs_oracle(hip, oracle, scene):
     same kernel, and that equals the CPU oracle bit for bit (the check bench.py itself runs outside its timed region)."""
     import bench
     res, Sc, Sf = 512, 48, 48
-    planes_np, raw = T.make_bench_scene(scene)
     ro = T.bench_rendering_kwargs(Sc, Sf)
-    o, d = hip.cameras.rays_from_label(hip.cameras.camera_label(0.0, 20.0, 1.0, 30.0)[None], res)
-    o, d = o.cuda(), d.cuda()
-    gen = torch.Generator(device="cuda").manual_seed(7)
-    jit = torch.rand((1, res * res, Sc, 1), device="cuda", generator=gen)
-    u = torch.rand((res * res, Sf), device="cuda", generator=gen)
-    mlp = hip.ops.prescale_mlp(*(torch.from_numpy(x).cuda() for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
-    nhwc = hip.ops.planes_to_nhwc(torch.from_numpy(planes_np).cuda())
+    w = bench.Workload(scene, torch.device("cuda"), res, 20.0, 7)
     for early in (True, False):
-        opts = hip.ops.make_opts(ro, early_out=early, **T.BENCH_KW)
-        frame = hip.ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
-        v = bench.verify_block(hip.ops, planes_np, raw, nhwc, o, d, jit, u, mlp, opts, frame, ro, T.BENCH_KW, res, Sc, Sf, exact=True)
-        assert v["ok"], v
+        v, frame, (jit, u) = w.verify_block(Sc, Sf, False, early=early, return_frame=True)
+        assert v["ok"] and all(v[k]["bit_exact_vs_oracle"] for k in ("feat", "depth", "wsum", "xyz")), v
+    nhwc, o, d, mlp = hip.ops.planes_to_nhwc(w.planes), w.o, w.d, w.mlp
     feat, depth, wsum, xyz = (t.cpu().numpy() for t in frame)
     check_properties(feat, depth, wsum, xyz, ro)
     if scene == "surface":

@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--sc", type=int, default=48)
 ap.add_argument("--sf", type=int, default=48)
+ap.add_argument("--seed", type=int, default=5)
+ap.add_argument("--no-timing", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda")
 res, Sc, Sf = a.res, a.sc, a.sf
@@ -39,13 +41,15 @@ for scene in ("canonical", "surface"):
     mlp = ops.prescale_mlp(*(torch.from_numpy(x).to(dev) for x in raw), 1 / np.sqrt(32), 1.0, 1 / np.sqrt(64), 1.0)
     o, d = P.cameras.rays_from_label(P.cameras.camera_label(0.0, 20.0, 1.0, 30.0)[None], res)
     o, d = o.to(dev), d.to(dev)
-    g = torch.Generator(device=dev).manual_seed(5)
+    g = torch.Generator(device=dev).manual_seed(a.seed)
     jit = torch.rand((1, R, Sc, 1), device=dev, generator=g)
     u = torch.rand((R, Sf), device=dev, generator=g)
     rec = {}
     for early in (True, False):
         ex = ops.make_opts(ro, early_out=early, **T.BENCH_KW)
         fa = ops.make_opts(ro, early_out=early, fast_color=True, **T.BENCH_KW)
+        if a.no_timing:
+            continue
         t_ex = timeit(lambda: ops.render(nhwc, o, d, jit, u, mlp, ex, ray_tile_w=res))
         t_fa = timeit(lambda: ops.render(nhwc, o, d, jit, u, mlp, fa, ray_tile_w=res))
         rec["ms_exact" + ("" if early else "_no_early_out")] = t_ex
@@ -63,4 +67,4 @@ for scene in ("canonical", "surface"):
     rec["psnr_fast_vs_exact_db"] = float("inf") if mse == 0 else 10 * np.log10(1 / mse)
     out[scene] = rec
     print(scene, json.dumps(rec))
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fast_color_check.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"fast_color_check_{Sc}p{Sf}_seed{a.seed}.json"), "w"), indent=1)
