@@ -224,6 +224,30 @@ int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const
                                const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
                                void* workspace, size_t workspace_bytes, uint32_t* saturated, void* stream);
 
+/* The same operator with every argument in one POD (what the Python host calls: one pointer through the FFI instead of 26
+ * scalars).  mma: P3D_CONV_MMA_F32 (w_f16 unused), _F16 (w_f16 from p3d_conv_weights_to_f16) or _F16X2 (from
+ * p3d_conv_weights_to_f16x2; `saturated` as in p3d_modconv2d_f16x2mma_f32, may be null). */
+#define P3D_CONV_MMA_F32 0
+#define P3D_CONV_MMA_F16 1
+#define P3D_CONV_MMA_F16X2 2
+typedef struct p3d_conv_args {
+    const float* x;            /* [N][I][H][W] */
+    const float* w;            /* [O][I][ks][ks] */
+    const void* w_f16;         /* f16 operand copy of w, or null (mma = F32) */
+    const float* styles;       /* [N][I] */
+    const float* demod_coefs;  /* [N][O] from p3d_demod_coefs_f32, or null */
+    const float* noise;        /* null, [OH*OW] or [N][OH*OW] */
+    const float* bias;         /* [O] or null */
+    const float* fir;          /* up = 2: the 4x4 filter, flipped, times up^2 */
+    float* y;                  /* [N][O][H*up][W*up] */
+    void* workspace;           /* p3d_modconv2d_workspace_bytes(N, I, O, H, W, up) */
+    uint32_t* saturated;       /* see p3d_modconv2d_f16x2mma_f32, or null */
+    size_t workspace_bytes;
+    int32_t N, I, H, W, O, ks, up, demodulate, noise_per_sample, act, mma;
+    float alpha, gain, clamp;
+} p3d_conv_args;
+int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
+
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by
  * `down`.  x [NC][H][W] -> y [NC][(H*up+pady0+pady1-fh)/down+1][(W*up+padx0+padx1-fw)/down+1]. */

@@ -36,6 +36,16 @@ class PasteArgs(C.Structure):
                [(n, C.c_float) for n in ("thresh_weight", "thresh_edges", "thresh_occ", "thresh_dxyz", "box_warp")]
 
 
+class ConvArgs(C.Structure):
+    """p3d_conv_args"""
+    _fields_ = [(n, C.c_void_p) for n in ("x", "w", "w_f16", "styles", "demod_coefs", "noise", "bias", "fir", "y", "workspace",
+                                          "saturated")] + [("workspace_bytes", C.c_size_t)] + \
+               [(n, C.c_int32) for n in ("N", "I", "H", "W", "O", "ks", "up", "demodulate", "noise_per_sample", "act", "mma")] + \
+               [(n, C.c_float) for n in ("alpha", "gain", "clamp")]
+
+
+P3D_CONV_MMA_F32, P3D_CONV_MMA_F16, P3D_CONV_MMA_F16X2 = 0, 1, 2
+
 # symbol -> (restype, argtypes); every function include/panic3d_hip.h declares
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -60,6 +70,7 @@ SIGNATURES = {
     "p3d_modconv2d_f16mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P]),
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P]),
+    "p3d_modconv2d_ex_f32": (_I, [C.POINTER(ConvArgs), _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_upsample2d_add_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "p3d_bias_act_f32": (_I, [_P, _P, _L, _I, _L, _I, _F, _F, _F, _P, _P]),

@@ -615,18 +615,28 @@ P3D_DEV float p3d_sigmoid_hw(float x) {
 // Same interface and lane layout as p3d_decode_wave<true>; lds must also hold the f16 images (p3d_load_mlp_f16_to_lds).
 // Domain: |interpolated feature| and hidden activations below the f16 range (65504); results agree with the exact decode to
 // ~1e-6 (sigma, relative to the magnitude of the sum's terms) / ~3e-7 (colours).
-template <bool WANT_RGB, bool LAZY = false>
+// GUARD (k_render's final pass; needs the fp32 layer-1 image W0A in LDS, which the exact coarse pass of the same kernel uses):
+// the cull / binarize masks are THRESHOLD decisions, the one place where a 1e-6 difference in sigma can move an output by a whole
+// interval weight.  A sample whose opacity comes out within P3D_FAST_MASK_BAND of the threshold has its density re-decoded on the
+// exact contract (layer 1 on f32 MFMAs + the sigma row, the coarse pass's decoder: ~1/3 of a colour decode, on the features
+// already gathered) and takes the exact sigma and mask — at wave level, for the rare wave-step that holds such a sample
+// (surface scene: 0.4 % of the final steps).  With it the tolerance mode makes the SAME mask decisions as the exact contract
+// (as long as the tolerance decoder's own error in the opacity stays below the band: |sigma error| < 8e-3, i.e. sigma-row
+// products up to ~10^4), and its outputs differ from the exact ones by arithmetic round-off only: a stated, asserted bound
+//  instead of "a few rays flip".
+#define P3D_FAST_MASK_BAND 2e-3f
+template <bool WANT_RGB, bool LAZY = false, bool GUARD = false>
 P3D_DEV bool p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
                                       f32x16& rgb, bool live = true);
 
-template <bool WANT_RGB = true, bool QUADG = false, bool LAZY = false, typename RSRC>
+template <bool WANT_RGB = true, bool QUADG = false, bool LAZY = false, bool GUARD = false, typename RSRC>
 P3D_DEV bool p3d_decode_wave_fast(const float* lds, RSRC rs, const P3dPlaneGeom& g, const P3dDecodeCfg& cfg, float px,
                                   float py, float pz, float& sigma_out, f32x16& rgb, bool live = true) {
     const f32x16 X = p3d_gather_features<QUADG>(rs, g, cfg, px, py, pz, live);
-    return p3d_decode_features_fast<WANT_RGB, LAZY>(lds, cfg, X, px, pz, sigma_out, rgb, live);
+    return p3d_decode_features_fast<WANT_RGB, LAZY, GUARD>(lds, cfg, X, px, pz, sigma_out, rgb, live);
 }
 
-template <bool WANT_RGB, bool LAZY>
+template <bool WANT_RGB, bool LAZY, bool GUARD>
 P3D_DEV bool p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg, const f32x16& X, float px, float pz, float& sigma_out,
                                       f32x16& rgb, bool live) {
     const int lane = __lane_id();
@@ -679,10 +689,19 @@ P3D_DEV bool p3d_decode_features_fast(const float* lds, const P3dDecodeCfg& cfg,
     }
     if (cfg.flags & (P3D_FLAG_CULL | P3D_FLAG_BINARIZE)) {
         float a = 1.0f - __builtin_amdgcn_exp2f(-p3d_softplus_hw(sigma - 1.0f) * P3D_LOG2E);
+        const bool near = live && sigma != P3D_SIGMA_MASKED && __builtin_fabsf(a - cfg.cull_thresh) < P3D_FAST_MASK_BAND;
         if (cfg.flags & P3D_FLAG_BINARIZE)
             sigma = (a < cfg.cull_thresh) ? P3D_SIGMA_MASKED : P3D_SIGMA_SOLID;
         else if (a < cfg.cull_thresh)
             sigma = P3D_SIGMA_MASKED;
+        if constexpr (GUARD) {
+            if (__builtin_amdgcn_ballot_w64(near) != 0) {  // rare: the exact density (and mask) for the samples on the threshold
+                float sx;
+                f32x16 unused;
+                p3d_decode_features<false>(lds, cfg, X, px, pz, sx, unused);
+                sigma = near ? sx : sigma;
+            }
+        }
     }
     sigma_out = sigma;
     if constexpr (LAZY) {

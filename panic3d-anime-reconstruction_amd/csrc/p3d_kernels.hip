@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
             bool skipped = true;
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
                 bool have_rgb;  // EARLY: colour on demand (p3d_decode.hpp, LAZY): a step whose live samples are all masked has none
-                if constexpr (FAST) have_rgb = p3d_decode_wave_fast<true, true, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                if constexpr (FAST) have_rgb = p3d_decode_wave_fast<true, true, EARLY, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 else have_rgb = p3d_decode_wave<true, P3D_QUAD_EXACT != 0, EARLY>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 if constexpr (!DUMP) ndec += 1;
                 skipped = !live || !have_rgb;  // per lane: a lane whose gathers were suppressed has no colour

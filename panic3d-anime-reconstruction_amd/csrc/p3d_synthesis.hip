@@ -989,6 +989,8 @@ struct FirParams {
     int C, H, W, OH, OW, fh, fw, up, down, padx0, pady0;
     int noise_per_sample, act, epilogue;
     float alpha, gain, clamp;
+    int ksplit;           // k_fir4x4_tiled: x holds ksplit split-K partial tensors, `slice` elements apart, summed in slice order
+    long long slice;      // while the tile is loaded (shallow splits only: see modconv_impl); 1 / 0 otherwise
 };
 
 // y[Y][X] = sum_{fy,fx} f[fy][fx] * xz[Y*down + fy - pady0][X*down + fx - padx0],  xz = zero-inserted x (xz[u*up][v*up] = x[u][v])
@@ -1087,7 +1089,13 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
     for (int idx = tid; idx < 35 * 35; idx += 256) {
         int r = idx / 35, c = idx - r * 35;
         int u = Y0 + r - p.pady0, v = X0 + c - p.padx0;
-        tile[r * 36 + c] = (u >= 0 && u < p.H && v >= 0 && v < p.W) ? xc[(size_t)u * p.W + v] : 0.0f;
+        float val = 0.0f;
+        if (u >= 0 && u < p.H && v >= 0 && v < p.W) {
+            const float* q = xc + (size_t)u * p.W + v;
+            val = q[0];
+            for (int k = 1; k < p.ksplit; ++k) val += q[(size_t)k * p.slice];  // split-K partials, slice order (= k_splitk_reduce)
+        }
+        tile[r * 36 + c] = val;
     }
     __syncthreads();
     const int lx = (tid & 15) * 2, ly = (tid >> 4) * 2;
@@ -1154,13 +1162,16 @@ static void launch_conv(ConvParams p, hipStream_t st) {
     else hipLaunchKernelGGL((k_modconv<MODE>), grid, dim3(256), 0, st, p);
 }
 
+#ifndef P3D_KSPLIT_TARGET
+#define P3D_KSPLIT_TARGET 256  // workgroups a launch is split towards.  Batch-1 backbone, ms: 64 -> 1.31, 128 -> 1.15, 256 -> 1.08, 512 (rounds 1-2) -> 1.15, 1024 -> 1.36 (profiles/r03_notes.txt)
+#endif
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
 static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) {
     long long wgs = (long long)((GW + tw - 1) / tw) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
     // down to ONE 8-channel chunk per workgroup: at batch 1 the 4^2..16^2 layers are a weight stream (9.4 MB for 512 -> 512 x 3x3)
     // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/r02_notes.txt
-    while (ks < 64 && wgs * ks < 512 && I / (ks * 2) >= 8) ks *= 2;
+    while (ks < 64 && wgs * ks < P3D_KSPLIT_TARGET && I / (ks * 2) >= 8) ks *= 2;
     return ks;
 }
 
@@ -1220,7 +1231,13 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         else if (p.wh) hipLaunchKernelGGL(k_modconv_up_h<false>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
-    if (ksplit > 1) {
+    // Split-K partial sums.  Up-sampling layer with a SHALLOW split (<= 8 slices: the 64^2 .. 256^2 layers at batch 1): the FIR pass
+    // below sums the slices while it loads its tiles — one launch and one round trip of the (2H+1)x(2W+1) intermediate less, the
+    // same slice-ordered sum.  Deep splits (the 4^2 .. 32^2 layers, up to 64 slices) keep the separate, chip-wide reduction:
+    // measured (profiles/r03_notes.txt) both a per-element slice loop inside the FIR pass (4.8 + 5.8 -> 37 us at 64 slices) and an
+    // in-launch last-arriver reduction of the plain convolutions (release / ticket / acquire: +15 .. +50 us per layer) lose to it.
+    const bool fir_sums = up == 2 && ksplit > 1 && ksplit <= 8;
+    if (ksplit > 1 && !fir_sums) {
         ReduceParams r;
         r.part = part; r.y = (up == 2) ? tmp : y; r.dcoef = p.dcoef; r.noise = noise; r.bias = bias;
         r.per_slice = (long long)out_elems; r.ksplit = ksplit; r.O = O; r.OHW = OH * OW; r.noise_per_sample = noise_per_sample;
@@ -1230,7 +1247,8 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     if (up == 1) return chk();
     // FIR (pad 1; the caller passes the 4x4 filter already flipped and multiplied by up^2, upfirdn2d.py:193-196) + epilogue
     FirParams q;
-    q.x = tmp; q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
+    q.x = fir_sums ? part : tmp; q.ksplit = fir_sums ? ksplit : 1; q.slice = (long long)out_elems;
+    q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
     q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
     q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
     q.alpha = alpha; q.gain = gain; q.clamp = clamp;
@@ -1280,6 +1298,22 @@ int p3d_modconv2d_f16mma_f32(const float* x, int N, int I, int H, int W, const f
                         gain, clamp, fir, y, workspace, workspace_bytes, stream);
 }
 
+int p3d_modconv2d_ex_f32(const p3d_conv_args* a, void* stream) {
+    if (!a) return P3D_E_ARG;
+    const void* wh = nullptr;
+    int wsplit = 0;
+    if (a->mma != P3D_CONV_MMA_F32) {
+        if (!a->w_f16) return P3D_E_ARG;
+        wsplit = a->mma == P3D_CONV_MMA_F16X2;
+        if (a->mma != P3D_CONV_MMA_F16 && !wsplit) return P3D_E_RANGE;
+        if (a->I % 16 != 0 || ((uintptr_t)a->w_f16 & 15) || (wsplit && ((size_t)a->O * a->I * a->ks * a->ks * 2) % 16 != 0)) return P3D_E_RANGE;
+        wh = a->w_f16;
+    }
+    return modconv_impl(a->x, a->N, a->I, a->H, a->W, a->w, wh, wsplit, a->O, a->ks, a->styles, a->demodulate, a->demod_coefs, a->noise,
+                        a->noise_per_sample, a->bias, a->up, a->act, a->alpha, a->gain, a->clamp, a->fir, a->y, a->workspace, a->workspace_bytes,
+                        stream, wsplit ? (unsigned int*)a->saturated : nullptr);
+}
+
 int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
                                const float* styles, int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample,
                                const float* bias, int up, int act, float alpha, float gain, float clamp, const float* fir, float* y,
@@ -1301,7 +1335,7 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
     q.OW = (W * up + padx0 + padx1 - fw) / down + 1;
     if (q.OH <= 0 || q.OW <= 0) return P3D_E_RANGE;
     q.fh = fh; q.fw = fw; q.up = up; q.down = down; q.padx0 = padx0; q.pady0 = pady0;
-    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1;
+    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1; q.ksplit = 1; q.slice = 0;
     long long total = q.NC * q.OH * q.OW;
     hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
     return chk();

@@ -319,6 +319,12 @@ class TriPlaneGenerator(torch.nn.Module):
     def set_force_sigmoid(self, state):
         return self.decoder.set_force_sigmoid(state)
 
+    def set_render_exact(self, state=True):
+        """True: every render of this generator runs the exact fp32 contract (bit-identical to the arithmetic contract); False: the
+        tolerance mode of the final pass (P3D_FLAG_FAST_COLOR); None: the package default (tolerance unless P3D_EXACT=1)."""
+        self.renderer.exact = state
+        return state
+
     def set_conv_mma(self, mode):
         """How the 3x3 convolutions of the backbone and of the super-resolution feed the matrix cores: "f32" (fp32 operands,
         v_mfma_f32_32x32x2_f32), "x2" (two-term f16 operands: fp32-class results, ~2x faster; domain |s*x| <= 4094, watched by

@@ -542,6 +542,21 @@ def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
     return out
 
 
+_CONV_SCRATCH = {}  # (device index, stream handle) -> workspace tensor
+
+
+def _conv_scratch(device, nbytes):
+    """The convolution workspace (demodulation coefficients, the transposed-conv intermediate, split-K partial sums), per
+    (device, stream): launches on one stream are ordered, so consecutive convolutions share ONE workspace instead of allocating
+    one per call (the batch-1 backbone is host-bound in its 4^2 .. 32^2 layers)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _CONV_SCRATCH.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((int(nbytes * 1.25) + 4096,), dtype=torch.uint8, device=device)
+        _CONV_SCRATCH[key] = ws
+    return ws
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
                      bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
@@ -580,24 +595,23 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
             raise RuntimeError("dcoef must hold N*O demodulation coefficients")
     y = torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=x.device)
     L = _lib.lib()
-    wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    mma = _lib.P3D_CONV_MMA_F32
+    if weight_f16 is not None:
+        split = weight_f16.ndim == 4
+        if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape)[-3:] != (O, kh * kw, I) or not weight_f16.is_contiguous() \
+                or (split and weight_f16.shape[0] != 2):
+            raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] / [2,O,k*k,I] float16 tensor of conv_weights_to_f16")
+        mma = _lib.P3D_CONV_MMA_F16X2 if split else _lib.P3D_CONV_MMA_F16
+        if split and saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != x.device):
+            raise RuntimeError("saturated must be an int32 [1] tensor on x's device (ops.conv_domain_flag)")
     with torch.cuda.device(x.device):
-        if weight_f16 is not None:
-            split = weight_f16.ndim == 4
-            if weight_f16.dtype != torch.float16 or tuple(weight_f16.shape)[-3:] != (O, kh * kw, I) or not weight_f16.is_contiguous() \
-                    or (split and weight_f16.shape[0] != 2):
-                raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] / [2,O,k*k,I] float16 tensor of conv_weights_to_f16")
-            args = (_p(x), N, I, H, W, _p(weight), _p(weight_f16), O, kh, _p(styles), int(bool(demodulate)),
-                    _p(dcoef), _p(noise), nps, _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb)
-            if split:
-                if saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != x.device):
-                    raise RuntimeError("saturated must be an int32 [1] tensor on x's device (ops.conv_domain_flag)")
-                _lib.check(L.p3d_modconv2d_f16x2mma_f32(*args, _p(saturated), _stream()), "p3d_modconv2d_f16x2mma_f32")
-            else:
-                _lib.check(L.p3d_modconv2d_f16mma_f32(*args, _stream()), "p3d_modconv2d_f16mma_f32")
-        else:
-            rc = L.p3d_modconv2d_f32(_p(x), N, I, H, W, _p(weight), O, kh, _p(styles), int(bool(demodulate)), _p(dcoef), _p(noise), nps,
-                                     _p(bias), int(up), idx, float(da), gain, clampv, _p(fir), _p(y), _p(ws), wsb, _stream())
-            _lib.check(rc, "p3d_modconv2d_f32")
+        wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
+        ws = _conv_scratch(x.device, wsb)
+        a = _lib.ConvArgs(x.data_ptr(), weight.data_ptr(), weight_f16.data_ptr() if weight_f16 is not None else None,
+                          styles.data_ptr(), dcoef.data_ptr() if dcoef is not None else None,
+                          noise.data_ptr() if noise is not None else None, bias.data_ptr() if bias is not None else None,
+                          fir.data_ptr() if fir is not None else None, y.data_ptr(), ws.data_ptr(),
+                          saturated.data_ptr() if (saturated is not None and mma == _lib.P3D_CONV_MMA_F16X2) else None,
+                          ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv)
+        _lib.check(L.p3d_modconv2d_ex_f32(C.byref(a), _stream()), "p3d_modconv2d_ex_f32")
     return y

@@ -12,6 +12,7 @@ Differences that are deliberate:
     OSGDecoder-shaped module: net[0] 32->64, Softplus, net[2] 64->33 (training/triplane.py:516-544);
   * CPU tensors raise: the product path has no CPU fallback.
 """
+import os
 import weakref
 
 import torch
@@ -23,7 +24,9 @@ from . import ops
 # transcendentals; 15 % faster at 512^2 x 96, PSNR > 90 dB against the exact path, inverse-CDF indices untouched — DESIGN.md
 # §4.6).  The reference itself only promises "minor hardware variations" between GPUs (readme.md:74).  Set to False (or pass
 # exact=True to forward) for results that are bit-identical to the arithmetic contract (include/p3d_numerics.h).
-DEFAULT_FAST_COLOR = True
+# How to pin the exact contract: environment P3D_EXACT=1 (process-wide default), ImportanceRenderer(..., exact=True) /
+# renderer.exact = True (per instance; TriPlaneGenerator.set_render_exact), or forward(..., exact=True) (per call).
+DEFAULT_FAST_COLOR = os.environ.get("P3D_EXACT", "0") != "1"
 
 
 def decoder_params(decoder):
@@ -34,9 +37,10 @@ def decoder_params(decoder):
 
 
 class ImportanceRenderer(torch.nn.Module):
-    def __init__(self, use_triplane=False):
+    def __init__(self, use_triplane=False, exact=None):
         super().__init__()
         self.use_triplane = bool(use_triplane)  # generate_planes(use_triplane): renderer.py:26-50
+        self.exact = exact  # None: the module default (tolerance mode unless P3D_EXACT=1); True / False: this instance's final pass
         self._planes_cache = (None, None, None)
 
     def _nhwc(self, planes):
@@ -74,6 +78,8 @@ class ImportanceRenderer(torch.nn.Module):
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None,
                 cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False,
                 per_view_clamp=False, exact=None):
+        if exact is None:
+            exact = getattr(self, "exact", None)
         fast = DEFAULT_FAST_COLOR if exact is None else not exact
         opts = self._opts(rendering_options, decoder, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
                           binarize_clouds=binarize_clouds, fast_color=fast)

@@ -114,6 +114,7 @@ class MappingNetwork(torch.nn.Module):
 # "x2" = two-term f16 operands on v_mfma_f32_32x32x16_f16 (fp32-class results: tests/test_hip_synthesis.py measures its error
 # against float64 next to the f32 kernel's; ~1.8x faster).  The environment variable is for A/B runs.
 DEFAULT_CONV_MMA = os.environ.get("P3D_CONV_MMA", "x2")
+DEFAULT_CONV_MMA_1X1 = os.environ.get("P3D_CONV_MMA_1X1", "f32")  # the 1x1 ToRGB layers (A/B knob, measured in round 3)
 
 
 def _f16_operand(layer):
@@ -123,7 +124,7 @@ def _f16_operand(layer):
     the reference's."""
     mode = getattr(layer, "mma_f16", None)  # None | False | True | "x2"
     if mode is None:
-        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and layer.weight.shape[-1] == 3) else False
+        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and (layer.weight.shape[-1] == 3 or DEFAULT_CONV_MMA_1X1 == "x2")) else False
     if not mode or layer.in_channels % 16 != 0:
         return None
     key = (layer.weight.data_ptr(), layer.weight._version, mode)
@@ -324,7 +325,9 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), **layer_kwargs)
             x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
         y = self.torgb(x, next(w_iter), pre=pre.get("torgb"))
-        # img = upsample2d(img, resample_filter); img = img.add_(y) (networks_stylegan2.py:476-478) in one launch
+        # img = upsample2d(img, resample_filter); img = img.add_(y) (networks_stylegan2.py:476-478) in one launch.  (Folding that
+        # add into the ToRGB convolution's own final store was measured in round 3 and lost — 49 + 21 -> 91 us at 256^2: per-lane
+        # 4-byte gathers in the MFMA accumulator layout, profiles/r03_notes.txt.)
         img = ops.upsample2d_add(img, self.resample_filter, y) if img is not None else y
         return x, img
 

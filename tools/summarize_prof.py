@@ -3,11 +3,11 @@
 
     python tools/summarize_prof.py <tag>
 
-Writes, per scene (canonical / surface) and mode (early = the default launch: tolerance-mode final pass, exact early-outs on;
-noearly = every sample decoded; exact_early / exact_noearly = the same with the exact-contract final pass, bench.py --exact):
+Writes, per scene (canonical / surface) and mode (exact_early = the default launch since round 3: exact-contract final pass,
+exact early-outs on; exact_noearly = every sample decoded; early / noearly = the same in the tolerance mode, bench.py --fast):
   profiles/<tag>_<scene>_<mode>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names cut to 80 chars)
   profiles/<tag>_pmc.json                          per-launch averages of every counter for k_render + dispatch info
-  profiles/pmc_latest.json                         {scene: {kernel_src_sha, hbm_bytes_per_launch, bounds, source}} of the DEFAULT mode —
+  profiles/pmc_latest.json                         {"<scene>/<exact|tolerance>": {kernel_src_sha, hbm_bytes_per_launch, bounds, source}} —
                                                    bench.py prints it only when kernel_src_sha matches the sources it runs.
 Units / corrections: FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE gets the gfx950 x2 correction of
 /opt/skills/guides/MI355X_MICROARCH.md §HBM (the gathers are 16-B-per-lane loads); GRBM_GUI_ACTIVE is summed over the 8 XCDs
@@ -91,9 +91,10 @@ def main():
                 ent["write_bytes"] = c["WRITE_SIZE"] * 1024
                 ent["hbm_bytes_per_launch"] = ent["fetch_bytes_corrected"] + ent["write_bytes"]
             allpmc[f"{scene}/{mode}"] = ent
-            if mode == "early":
-                latest[scene] = {"kernel_src_sha": sha, "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "bounds": b,
-                                 "rocprof_kernel_avg_ms": ent["rocprof_kernel_avg_ms"], "source": f"profiles/{tag}_pmc.json [{scene}/early]"}
+            if mode in ("early", "exact_early"):  # the two timed launches of bench.py: --fast and the default (exact)
+                latest[f"{scene}/{'tolerance' if mode == 'early' else 'exact'}"] = {
+                    "kernel_src_sha": sha, "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "bounds": b,
+                    "rocprof_kernel_avg_ms": ent["rocprof_kernel_avg_ms"], "source": f"profiles/{tag}_pmc.json [{scene}/{mode}]"}
     json.dump({"tag": tag, "kernel_src_sha": sha, "captures": allpmc}, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1)
     if latest:
         json.dump(latest, open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
