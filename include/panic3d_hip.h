@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 5
+#define P3D_ABI_VERSION 5  /* 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -247,6 +247,19 @@ typedef struct p3d_conv_args {
     float alpha, gain, clamp;
 } p3d_conv_args;
 int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
+
+/* ToRGBLayer.forward (networks_stylegan2.py:366-380: 1x1 modulated convolution without demodulation + bias [+ clamp]) fused with
+ * the skip connection of SynthesisBlock.forward (:476-478: img = upsample2d(img) + y) — ONE launch that reads the activation
+ * once: a [O x I] x [I x H*W] GEMM on v_mfma_f32_32x32x2_f32 (exact fp32) whose B operand goes from global memory straight into
+ * MFMA registers.  x [N][I][H][W]; w_t = the layer's weights [O][I] transposed and padded by p3d_torgb_weights_f32 (once per
+ * layer: [I][32] for O <= 32, [I][96] for O <= 96; O > 96: P3D_E_RANGE, use p3d_modconv2d_f32); styles [N][I] already
+ * multiplied by the layer's weight_gain; bias [O] or null; clamp < 0: none; skip [N][O][H/2][W/2] + skip_fir (the 4x4 resample
+ * filter flipped and multiplied by 4, upfirdn2d.py:341-350) or both null; y [N][O][H][W].  Without skip the result equals
+ * p3d_modconv2d_f32(ks = 1, demodulate = 0) bit for bit wherever that runs without split-K; the skip term uses
+ * p3d_upfirdn2d_f32's summation order (bit-identical to the three-launch form). */
+int p3d_torgb_weights_f32(const float* w, int O, int I, float* w_t, void* stream);
+int p3d_torgb_f32(const float* x, int N, int I, int H, int W, const float* w_t, int O, const float* styles, const float* bias, float clamp,
+                  const float* skip, const float* skip_fir, float* y, void* stream);
 
 /* upfirdn2d (torch_utils/ops/upfirdn2d.py:120-167; plugin signature upfirdn2d.cpp:20): zero-insert by `up`, pad/crop,
  * correlate with f [fh][fw] (pass the filter already flipped for convolution and multiplied by the gain), decimate by

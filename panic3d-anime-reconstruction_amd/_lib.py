@@ -71,6 +71,8 @@ SIGNATURES = {
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P]),
     "p3d_modconv2d_ex_f32": (_I, [C.POINTER(ConvArgs), _P]),
+    "p3d_torgb_weights_f32": (_I, [_P, _I, _I, _P, _P]),
+    "p3d_torgb_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "p3d_upsample2d_add_f32": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "p3d_bias_act_f32": (_I, [_P, _P, _L, _I, _L, _I, _F, _F, _F, _P, _P]),

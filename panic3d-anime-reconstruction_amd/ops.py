@@ -506,6 +506,45 @@ def upsample2d_add(x, f, add=None):
     return y
 
 
+def torgb_weights(weight):
+    """ToRGB weights [O,I,1,1] -> the transposed, channel-padded [I, 32 or 96] copy p3d_torgb_f32 streams (made once per layer)."""
+    weight = _chk(weight, "weight")
+    O, I = weight.shape[0], weight.shape[1]
+    if weight.shape[2:] != (1, 1) or O > 96:
+        raise RuntimeError("torgb_weights: [O <= 96, I, 1, 1]")
+    wt = torch.empty((I, 32 if O <= 32 else 96), dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().p3d_torgb_weights_f32(_p(weight), O, I, _p(wt), _stream()), "p3d_torgb_weights_f32")
+    return wt
+
+
+def torgb(x, weight_t, out_channels, styles, bias=None, clamp=None, skip=None, skip_filter=None):
+    """ToRGBLayer.forward (networks_stylegan2.py:366-380) + the skip connection of SynthesisBlock.forward (:476-478) in ONE launch:
+    `upsample2d(skip, skip_filter) + (conv1x1(x * styles) + bias)`.  weight_t from torgb_weights; styles [N,I] already multiplied
+    by the layer's weight_gain; skip [N,O,H/2,W/2] or None."""
+    x, weight_t, styles = _chk(x, "x"), _chk(weight_t, "weight_t"), _chk(styles, "styles")
+    N, I, H, W = x.shape
+    O = int(out_channels)
+    if tuple(weight_t.shape) != (I, 32 if O <= 32 else 96) or tuple(styles.shape) != (N, I):
+        raise RuntimeError("torgb: x [N,I,H,W], weight_t [I,32|96] (torgb_weights), styles [N,I]")
+    if bias is not None:
+        bias = _chk(bias, "bias")
+    skipf = None
+    if skip is not None:
+        skip = _chk(skip, "skip")
+        if tuple(skip.shape) != (N, O, H // 2, W // 2) or H % 2 or W % 2:
+            raise RuntimeError("skip must be [N,O,H/2,W/2] (the previous block's image)")
+        skipf = prepared_filter(skip_filter, x.device, 4.0, False)  # upsample2d: up 2, gain up^2 (upfirdn2d.py:341-350)
+        if tuple(skipf.shape) != (4, 4):
+            raise NotImplementedError("skip_filter must be the 4x4 [1,3,3,1] filter")
+    y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().p3d_torgb_f32(_p(x), N, I, H, W, _p(weight_t), O, _p(styles), _p(bias), float(clamp if clamp is not None else -1),
+                                      _p(skip), _p(skipf), _p(y), _stream())
+    _lib.check(rc, "p3d_torgb_f32")
+    return y
+
+
 def conv_weights_to_f16(weight, split=False):
     """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer); split: the
     [2,O,k*k,I] hi / lo pair of the two-term variant (hi = f16(w), lo = f16(w - hi))."""

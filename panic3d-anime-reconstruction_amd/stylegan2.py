@@ -18,7 +18,7 @@ from . import ops
 SQRT2 = float(np.sqrt(2))
 
 # derived tensors the modules keep as plain attributes (never part of the state_dict, dropped when pickled / deep-copied)
-_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_noise_cache", "_style_plan")
+_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan")
 
 
 class _CacheFree(torch.nn.Module):
@@ -183,10 +183,20 @@ class ToRGBLayer(_CacheFree):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True, pre=None):
+    def forward(self, x, w, fused_modconv=True, pre=None, skip=None, skip_filter=None):
+        """skip / skip_filter: the previous block's image and the block's resample filter -> `upsample2d(skip) + torgb(x)`, the
+        skip connection of SynthesisBlock.forward (networks_stylegan2.py:476-478), from the same launch."""
         styles = pre[0] if pre is not None else self.affine(w) * self.weight_gain
-        return ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
-                                    clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None))
+        if self.weight.shape[0] <= 96 and self.weight.shape[-1] == 1 and not getattr(self, "mma_f16", None) and x.shape[-1] % 2 == 0 \
+                and x.shape[-2] % 2 == 0:
+            # the dedicated GEMM kernel (p3d_torgb_f32): the activation is read once, the skip image is added in the same launch
+            key = (self.weight.data_ptr(), self.weight._version)
+            if getattr(self, "_wt_key", None) != key:
+                self._wt, self._wt_key = ops.torgb_weights(self.weight.detach()), key
+            return ops.torgb(x, self._wt, self.weight.shape[0], styles, bias=self.bias, clamp=self.conv_clamp, skip=skip, skip_filter=skip_filter)
+        y = ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
+                                 clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None))
+        return ops.upsample2d_add(skip, skip_filter, y) if skip is not None else y
 
 
 class StylePlan:
@@ -324,11 +334,9 @@ class SynthesisBlock(torch.nn.Module):
         else:
             x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), **layer_kwargs)
             x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
-        y = self.torgb(x, next(w_iter), pre=pre.get("torgb"))
-        # img = upsample2d(img, resample_filter); img = img.add_(y) (networks_stylegan2.py:476-478) in one launch.  (Folding that
-        # add into the ToRGB convolution's own final store was measured in round 3 and lost — 49 + 21 -> 91 us at 256^2: per-lane
-        # 4-byte gathers in the MFMA accumulator layout, profiles/r03_notes.txt.)
-        img = ops.upsample2d_add(img, self.resample_filter, y) if img is not None else y
+        # y = torgb(x); img = upsample2d(img, resample_filter); img = img.add_(y)  (networks_stylegan2.py:476-478): one launch
+        img = self.torgb(x, next(w_iter), pre=pre.get("torgb"), skip=None if img is None else img.to(torch.float32),
+                         skip_filter=self.resample_filter)
         return x, img
 
 

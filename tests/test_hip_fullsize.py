@@ -138,7 +138,11 @@ def test_large_launch_other_sampling_rates(hip, oracle, Sc, Sf):
                           torch.from_numpy(u).cuda(), mlp, hip.ops.make_opts(ro, fast_color=True, **KW), ray_tile_w=res)
     for name, a, b in zip(("feat", "depth", "wsum", "xyz"), fast, out):
         err = (a - b).abs().reshape(res * res, -1).amax(dim=-1)
-        assert float(err.median()) <= 2e-6 and float((err > 2e-5).float().mean()) <= 2e-3, (name, float(err.max()))
+        print(f"{Sc}+{Sf} tolerance vs exact {name}: max {float(err.max()):.2e}")
+        assert float(err.median()) <= 2e-6 and float(err.max()) <= FAST_MAX[name], (name, float(err.max()))  # every ray
+
+
+FAST_MAX = dict(feat=1e-5, depth=2e-5, wsum=1e-5, xyz=1e-5)  # the tolerance mode's stated bound vs the exact contract
 
 
 # ---- full-size holes closed in round 2 (VERDICT r01 "What's weak" 1-2) ---------------------------------------------------
@@ -159,8 +163,13 @@ def test_bench_scene_512_frame_vs_oracle(hip, oracle, scene):
     if scene == "surface":
         assert 0.3 < (wsum > 0.5).mean() < 0.9
         fast = hip.ops.render(nhwc, o, d, jit, u, mlp, hip.ops.make_opts(ro, fast_color=True, **T.BENCH_KW), ray_tile_w=res)
-        err = (fast[0] - frame[0]).abs().amax(dim=-1).reshape(-1)
-        assert float(err.median()) < 2e-6 and float((err > 2e-5).float().mean()) < 1e-4  # tolerance mode at full size
+        # tolerance mode at full size: the stated hard bound on every ray of every output, and PSNR >= 120 dB (measured 138.8)
+        for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), fast, frame):
+            err = (a - b).abs().reshape(res * res, -1).amax(dim=-1)
+            print(f"surface 512^2 tolerance vs exact {nm}: max {float(err.max()):.2e}")
+            assert float(err.median()) < 2e-6 and float(err.max()) <= FAST_MAX[nm], (nm, float(err.max()), int((err > FAST_MAX[nm]).sum()))
+        mse = float((((fast[0][..., :3] - frame[0][..., :3]) * 0.5).double() ** 2).mean())
+        assert 10 * np.log10(1.0 / max(mse, 1e-30)) >= 120.0
     else:
         assert wsum.max() == 0.0  # SURVEY 8(d)'s decoder never clears cull_clouds = 0.5: an empty volume
 

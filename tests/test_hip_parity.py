@@ -424,13 +424,17 @@ def _psnr(a, b):
     return np.inf if mse == 0 else 10 * np.log10(1.0 / mse)
 
 
+# the stated bound of the tolerance mode against the exact contract, every ray, every output
+FAST_MAX = dict(feat=1e-5, depth=2e-5, wsum=1e-5, xyz=1e-5)
+
+
 @pytest.mark.parametrize("name", [n for n in T.RENDER_GOLDENS if n != "render_c1_64x64_s32"])
 def test_fast_color_keeps_the_coarse_pass_exact_and_the_outputs_close(hip, oracle, name):
     """The opt-in tolerance mode may only touch the FINAL pass: everything the importance resampling produces — coarse
     sigma / weights, the inverse-CDF bin indices ("ray hit indices"), the fine depths and the merged depth order — stays
-    bit-exact vs the oracle; feat / depth / wsum / xyz stay within fp32 tolerance of it (2e-5; a sample whose density sits
-    within ~1e-6 of the cull threshold may flip, hence a 0.1 % allowance of rays at the reference tolerances), and the PSNR
-    against the REFERENCE's own render moves by less than 0.01 dB."""
+    bit-exact vs the oracle; feat / depth / wsum / xyz of EVERY ray stay within FAST_MAX of it (round 2 allowed 0.1 % of the rays
+    to flip a cull mask; the exact mask guard removed those), and the PSNR against the REFERENCE's own render moves by less
+    than 0.01 dB."""
     g = T.load_golden(name + ".npz")
     inp = T.golden_render_inputs(g)
     oo = oracle.make_opts(inp["ro"], **inp["kw"])
@@ -449,15 +453,18 @@ def test_fast_color_keeps_the_coarse_pass_exact_and_the_outputs_close(hip, oracl
     assert np.array_equal(hdm["depths_sorted"], np.take_along_axis(all_d, odm["perm"], axis=1))
     assert np.array_equal(hdm["tminmax"], odm["tminmax"])
     # production launch (no dumps, early-outs on) against the oracle
-    prod = hip.ops.render(*args, fast)
+    # (small_launch_kernel=False: these fixtures are small launches, which would otherwise take the always-exact 16-ray kernel)
+    prod = hip.ops.render(*args, hip.ops.make_opts(inp["ro"], fast_color=True, small_launch_kernel=False, **inp["kw"]))
     R = inp["rays_o"].shape[0] * inp["rays_o"].shape[1]
-    for nm, a, b, tol_close, tol_ref in zip(("feat", "depth", "wsum", "xyz"), prod, ref[:4], (2e-5, 2e-5, 2e-5, 2e-5),
-                                             (TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ)):
+    # HARD bound (round 3): the exact mask guard (p3d_decode.hpp, P3D_FAST_MASK_BAND) makes the tolerance mode take the same
+    # crop / cull decisions as the exact contract, so what is left is arithmetic round-off (two-term f16 products, hardware
+    # exp2 / log2 / rcp, ray termination at Td < 2e-6): EVERY ray within FAST_MAX of the oracle, no allowance for flipped rays.
+    for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), prod, ref[:4]):
         a = a.cpu().numpy()
         err = np.abs(a - b).reshape(R, -1).max(axis=1)
+        print(f"{name} fast-vs-oracle {nm}: max {err.max():.2e} median {np.median(err):.2e}")
         assert np.median(err) <= 2e-6, (nm, float(np.median(err)))
-        assert (err > tol_close).mean() <= 2e-3, (nm, float((err > tol_close).mean()), float(err.max()))
-        assert (err > tol_ref).mean() <= 1e-3, (nm, float((err > tol_ref).mean()))
+        assert err.max() <= FAST_MAX[nm], (nm, float(err.max()), int((err > FAST_MAX[nm]).sum()))
     # PSNR against the reference's own image_raw (first three feature channels mapped to [0,1]) must not move
     exact = hip.ops.render(*args, hip.ops.make_opts(inp["ro"], **inp["kw"]))
     img_ref = g["feat"][..., :3] * 0.5 + 0.5 if "feat" in g else None  # the reference's own output (tests/golden/make_golden.py)

@@ -570,3 +570,28 @@ def test_up_conv_fir_sums_shallow_splitk_partials(hip, mma):
         assert torch.equal(a, c)
         ref = F.leaky_relu(torch_modconv_ref(x, w3, s, noise, 2, True, b, filt), 0.2) * np.sqrt(2)
         assert rel_err(a.cpu().numpy(), ref.numpy()) < 3e-6 * np.sqrt(I * 9), (N, I, O, H)
+
+
+@pytest.mark.parametrize("N,I,O,H", [(1, 128, 96, 256), (1, 512, 96, 64), (2, 256, 96, 32), (1, 512, 96, 4), (1, 128, 3, 512), (3, 64, 96, 16), (1, 72, 40, 18)])
+def test_torgb_gemm_kernel_vs_the_three_launch_form(hip, N, I, O, H):
+    """p3d_torgb_f32 (round 3: ToRGB as a GEMM that reads its activation once, the skip image added in the same launch) against
+    the form it replaces — p3d_modconv2d_f32 (1x1) [+ k_splitk_reduce] + p3d_upsample2d_add_f32.  Large maps (no split-K in the
+    old kernel, no K split across waves in the new one) must agree BIT FOR BIT; small maps sum their K slices in another order:
+    fp32 tolerance.  Channel tails (I = 72), O < 32 (the super-resolution's RGB), batch > 1, bias, clamp."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(N * 1000 + I + O + H)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    x, w, s, b = rn(N, I, H, H), rn(O, I, 1, 1), rn(N, I) * 0.3 + 1.0, rn(O) * 0.2
+    prev, filt = rn(N, O, H // 2, H // 2), ops.setup_filter([1, 3, 3, 1]).cuda()
+    wt = ops.torgb_weights(w)
+    for clamp in (None, 2.0):
+        y_old = ops.modulated_conv2d(x, w, s, demodulate=False, bias=b, clamp=clamp)
+        old = ops.upsample2d_add(prev, filt, y_old)
+        new = ops.torgb(x, wt, O, s, bias=b, clamp=clamp, skip=prev, skip_filter=filt)
+        new_noskip = ops.torgb(x, wt, O, s, bias=b, clamp=clamp)
+        scale = float(y_old.abs().max())
+        if N * ((H * H + 127) // 128) >= 512:  # PX shape and the old kernel without split-K: the same fma chains
+            assert torch.equal(new_noskip, y_old) and torch.equal(new, old), (float((new - old).abs().max()), scale)
+        else:
+            assert float((new_noskip - y_old).abs().max()) < 3e-6 * np.sqrt(I) * scale and float((new - old).abs().max()) < 3e-6 * np.sqrt(I) * scale
+        assert torch.equal(new - 0, ops.torgb(x, wt, O, s, bias=b, clamp=clamp, skip=prev, skip_filter=filt))  # deterministic

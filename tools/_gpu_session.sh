@@ -1,2 +1,2 @@
-for T in 64 128 256; do echo ks$T; P3D_LIB=$GRAFT_REPO_ROOT/tools/experiments/lib_ks$T.so python tools/graph_backbone.py 2>/dev/null | tail -1; done
-echo default; python tools/graph_backbone.py 2>/dev/null | tail -1
+O=gpurun_out/r03i; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; tail -4 $O/pytest.log; grep "fast-vs-oracle\|tolerance vs exact" $O/pytest.log | sort | tail -40
