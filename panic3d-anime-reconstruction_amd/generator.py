@@ -54,9 +54,21 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             size = (self.input_resolution, self.input_resolution)
             x = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=self.sr_antialias)
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode="bilinear", align_corners=False, antialias=self.sr_antialias)
-        x, rgb = self.block0(x.contiguous(), rgb.contiguous(), ws, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        # the six affine layers and the four demodulations of the two blocks in one StylePlan (one GEMM + four small launches
+        # instead of six addmm + two scalings + four k_demod: networks_stylegan2.py:342,377,70-73), as the backbone does
+        plan = self.__dict__.get("_style_plan")
+        if plan is None:
+            plan = stylegan2.StylePlan(stylegan2.plan_entries([("block0", self.block0), ("block1", self.block1)], [0, 0]))
+            self.__dict__["_style_plan"] = plan
+        pre = plan(ws)
+        x, rgb = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], **block_kwargs)
         return rgb
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_style_plan", None)  # derived tensors stay out of pickles / deep copies
+        return state
 
 
 _SR_MODULES = {"training.superresolution.SuperresolutionHybrid8XDC": SuperresolutionHybrid8XDC}

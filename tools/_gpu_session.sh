@@ -1,2 +1,5 @@
-O=gpurun_out/r03i; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; tail -4 $O/pytest.log; grep "fast-vs-oracle\|tolerance vs exact" $O/pytest.log | sort | tail -40
+O=gpurun_out/r03j; mkdir -p $O
+timeout 900 python -m pytest tests/test_hip_synthesis.py tests/test_hip_parity.py -m gpu -q -x 2>&1 | tail -3
+python tools/graph_backbone.py 2>/dev/null | tail -1
+python tools/profile_f.py 2>/dev/null | tail -1
+python tools/generate_subject.py 2>/dev/null | tail -3
