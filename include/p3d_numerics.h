@@ -110,6 +110,13 @@
  *   delta = (float)((double)(end - start... as python floats) / (S-1))
  *   t[i] = lin[i] + jitter[i] * delta                     (two roundings)
  *
+ * ---- device draws (p3d_render_rng_f32; opt-in replacement of the two torch.rand tensors) ----
+ *   fmix32(h): h ^= h >> 16; h *= 0x85EBCA6B; h ^= h >> 13; h *= 0xC2B2AE35; h ^= h >> 16      (32-bit unsigned arithmetic)
+ *   draw(seed, stream, ray, i):  ray = n * R + r (64-bit), stream 0 = jitter (renderer.py:324), 1 = u (:371), i = sample index
+ *     h = fmix32((uint32)seed ^ ((uint32)ray * 0x9E3779B1))
+ *     h = fmix32(h ^ (uint32)(seed >> 32) ^ ((uint32)(ray >> 32) * 0x7FEB352D) ^ (((uint32)i * 2 + stream) * 0x846CA68B))
+ *     value = (float)(h >> 8) * 2^-24          (24 random bits, [0, 1), exact in binary32 — torch.rand's float32 grid)
+ *
  * ---- compositing (ray_marcher.py:25-57) over S sorted samples, K colour channels ----
  *   for i in 0..S-2:
  *     dl = t[i+1] - t[i];  sm = (sg[i] + sg[i+1]) * 0.5f;  tm = (t[i] + t[i+1]) * 0.5f;  cm[k] = (c[i][k] + c[i+1][k]) * 0.5f

@@ -148,6 +148,18 @@ int p3d_render_limits_f32(const float* planes_nhwc, int N, int H, int W, const f
                           float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
                           size_t workspace_bytes, const p3d_dumps* dumps, void* stream);
 
+/* The same with the two random draws made INSIDE the kernel (opt-in): instead of reading jitter [N][R][Sc] and u [N*R][Sf] — 200 MB
+ * written by torch.rand and read back per 512^2 x (48+48) frame, 59 % of the launch's compulsory HBM bytes, and two extra launches —
+ * every draw is a pure function of (seed, stream, flat ray index n*R + r, sample index): the counter-based generator of
+ * include/p3d_numerics.h ("device draws"), 24 random bits in [0, 1) like torch.rand's float32 output.  Another random stream
+ * than torch's, the same distribution; the CPU oracle restates the generator, so results stay bit-exact checkable.  ray_start /
+ * ray_end as in p3d_render_limits_f32 (may both be NULL). */
+int p3d_render_rng_f32(const float* planes_nhwc, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                       int ray_tile_w, uint64_t seed, const float* w0, const float* b0, const float* w1, const float* b1,
+                       const float* ray_start, const float* ray_end, const p3d_opts* opts, float* out_feat, float* out_depth,
+                       float* out_wsum, float* out_xyz, void* workspace, size_t workspace_bytes, const p3d_dumps* dumps,
+                       void* stream);
+
 /* sample_stratified (renderer.py:303-326, numeric ray_start/ray_end branch).  jitter, out [NR][S]. */
 int p3d_sample_stratified_f32(float ray_start, float ray_end, float depth_delta, int S, const float* jitter, int64_t NR,
                               float* out_depths, void* stream);

@@ -246,3 +246,32 @@ def sigma2density(sigma, cropmask=None, cull=None):
     lib().p3d_oracle_sigma2density(ps, None if cm is None else cm.ctypes.data_as(C.c_void_p), C.c_long(sigma.size),
                                    C.c_float(-1.0 if cull is None else cull), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def device_draws(seed, N, R, Sc, Sf):
+    """The two draw tensors p3d_render_rng_f32 makes inside the kernel (include/p3d_numerics.h "device draws"), restated with
+    numpy integer arithmetic: (jitter [N,R,Sc,1], u [N*R,Sf]) for oracle.render — the checker of the opt-in in-kernel generator."""
+    M32 = np.uint64(0xFFFFFFFF)
+
+    def fmix32(h):
+        h = h & M32
+        h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & M32
+        h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & M32
+        h ^= h >> np.uint64(16)
+        return h
+
+    seed = int(seed) & (2 ** 64 - 1)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    ray = np.arange(N * R, dtype=np.uint64)
+
+    def draws(stream, S):
+        i = np.arange(S, dtype=np.uint64)
+        h = fmix32(lo ^ ((ray & M32) * np.uint64(0x9E3779B1) & M32))[:, None]
+        rhi = (((ray >> np.uint64(32)) * np.uint64(0x7FEB352D)) & M32)[:, None]
+        k = (((i * np.uint64(2) + np.uint64(stream)) & M32) * np.uint64(0x846CA68B)) & M32
+        h = fmix32(h ^ hi ^ rhi ^ k[None, :])
+        return ((h >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+    jit = draws(0, Sc).reshape(N, R, Sc, 1)
+    u = draws(1, Sf) if Sf > 0 else np.zeros((N * R, 0), np.float32)
+    return np.ascontiguousarray(jit), np.ascontiguousarray(u)

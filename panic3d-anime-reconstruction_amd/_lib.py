@@ -57,6 +57,8 @@ SIGNATURES = {
                             _Z, C.POINTER(Dumps), _P]),
     "p3d_render_limits_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
                                    _Z, C.POINTER(Dumps), _P]),
+    "p3d_render_rng_f32": (_I, [_P, _I, _I, _I, _P, _P, _L, _I, C.c_uint64, _P, _P, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P, _P, _P,
+                                _Z, C.POINTER(Dumps), _P]),
     "p3d_sample_stratified_f32": (_I, [_F, _F, _F, _I, _P, _L, _P, _P]),
     "p3d_composite_workspace_bytes": (_Z, [_L, _I, _I]),
     "p3d_depth_minmax_f32": (_I, [_P, _L, _P, _P, _Z, _P]),

@@ -252,6 +252,8 @@ struct RenderParams {
     int disparity;                             // P3D_FLAG_DISPARITY
     int white_back;
     int lds_rows;     // rows (of 32 floats) of per-wave LDS
+    int rng;          // p3d_render_rng_f32: the two draws come from the counter-based generator of include/p3d_numerics.h
+    uint32_t seed_lo, seed_hi;
     int swz;          // XCD swizzle run length (blocks)
     P3dDecodeCfg cfg;
 };
@@ -262,6 +264,18 @@ struct MarchState {
     float W, D;
     float prev_t, prev_sigma;
 };
+
+// The counter-based generator of p3d_render_rng_f32 (include/p3d_numerics.h "device draws"): stream 0 = the jitter of
+// sample_stratified (renderer.py:324), stream 1 = the u of sample_pdf (:371); a pure function of (seed, stream, ray, index).
+P3D_DEV uint32_t p3d_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+P3D_DEV float p3d_draw(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, size_t ray, int idx) {
+    uint32_t h = p3d_fmix32(seed_lo ^ ((uint32_t)ray * 0x9E3779B1u));
+    h = p3d_fmix32(h ^ seed_hi ^ ((uint32_t)((unsigned long long)ray >> 32) * 0x7FEB352Du) ^ (((uint32_t)idx * 2u + stream) * 0x846CA68Bu));
+    return (float)(h >> 8) * 0x1p-24f;  // 24 random bits in [0, 1): exact in binary32
+}
 
 // weight of interval (prev, cur); advances the transmittance.  ray_marcher.py:26-42
 P3D_DEV float p3d_march_weight(MarchState& st, float t, float sigma, float& tm_out) {
@@ -486,7 +500,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
         for (int i0 = 0; i0 < Sc; i0 += 8) {  // eight loads of the jitter row in flight (one at a time exposed a global-load latency per sample)
             float jv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) jv[q] = jit[i0 + q < Sc ? i0 + q : Sc - 1];
+            for (int q = 0; q < 8; ++q) {
+                const int iq = i0 + q < Sc ? i0 + q : Sc - 1;
+                jv[q] = p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 0u, ray, iq) : jit[iq];
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int i = i0 + q;
@@ -575,7 +592,8 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
         if constexpr (NF > 0) {
             float tf[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? uu[i] : 0.0f;  // every load of the row issued before the first search
+            for (int i = 0; i < NF; ++i)  // every load of the row issued before the first search
+                tf[i] = (i < Sf) ? (p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, i) : uu[i]) : 0.0f;
 #pragma unroll
             for (int i0 = 0; i0 < NF; i0 += DB) {
                 if (i0 < Sf) {  // wave-uniform
@@ -606,7 +624,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
                 float ub[DB], vb[DB];
                 int kb[DB];
 #pragma unroll
-                for (int q = 0; q < DB; ++q) ub[q] = uu[i0 + q < Sf ? i0 + q : Sf - 1];
+                for (int q = 0; q < DB; ++q) {
+                    const int iq = i0 + q < Sf ? i0 + q : Sf - 1;
+                    ub[q] = p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, iq) : uu[iq];
+                }
                 p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, j, ub, vb, kb);
 #pragma unroll
                 for (int q = 0; q < DB; ++q) {
@@ -905,14 +926,15 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
         float prev = -__builtin_inff();
         for (int i = 0; i < Sc; ++i) {
             float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
-            float t = lin + jit[i] * p.depth_delta;
+            const float ji = p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 0u, ray, i) : jit[i];
+            float t = lin + ji * p.depth_delta;
             if (limits) {
                 const float prod = ((float)i / (float)(Sc - 1)) * span;
-                t = (rs + prod) + jit[i] * rdelta;
+                t = (rs + prod) + ji * rdelta;
             } else if (p.disparity) {
                 const float s01 = 1.0f / (float)(Sc - 1);
                 const float l01 = (i < Sc / 2) ? p3d_fma(s01, (float)i, 0.0f) : p3d_fma(-s01, (float)(Sc - 1 - i), 1.0f);
-                const float dd = l01 + jit[i] * p.depth_delta;
+                const float dd = l01 + ji * p.depth_delta;
                 const float ta_ = p.ray_start * (1.0f - dd), tb_ = p.ray_end * dd;
                 t = 1.0f / (ta_ + tb_);
             }
@@ -986,7 +1008,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             constexpr int DB = 8;
             float tf[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? uu[i] : 0.0f;
+            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? (p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, i) : uu[i]) : 0.0f;
 #pragma unroll
             for (int i0 = 0; i0 < NF; i0 += DB) {
                 if (i0 < Sf) {  // wave-uniform
@@ -1011,7 +1033,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             float* tmpA = tfA;
             for (int i = 0; i < Sf; ++i) {
                 int k;
-                float v = p3d_inverse_cdf(wcA, tcA, Ns, jr, uu[i], k);
+                float v = p3d_inverse_cdf(wcA, tcA, Ns, jr, p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, i) : uu[i], k);
                 tmpA[i * 32 + jr] = v;
             }
             if (slot == 0 && h == 0) p3d_lds_insertion_sort(tfA, Sf, jr);
@@ -1481,23 +1503,47 @@ int p3d_render_f32(const float* planes, int N, int H, int W, const float* rays_o
                                  out_feat, out_depth, out_wsum, out_xyz, workspace, workspace_bytes, dumps, stream);
 }
 
+static int render_impl(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                       int ray_tile_w, const float* jitter, const float* u, int rng, uint64_t seed, const float* w0, const float* b0,
+                       const float* w1, const float* b1, const float* ray_start, const float* ray_end, const p3d_opts* opts,
+                       float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
+                       size_t workspace_bytes, const p3d_dumps* dumps, void* stream);
+
 int p3d_render_limits_f32(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
                           int ray_tile_w, const float* jitter, const float* u, const float* w0, const float* b0,
                           const float* w1, const float* b1, const float* ray_start, const float* ray_end, const p3d_opts* opts,
                           float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
                           size_t workspace_bytes, const p3d_dumps* dumps, void* stream) {
+    return render_impl(planes, N, H, W, rays_o, rays_d, R, ray_tile_w, jitter, u, 0, 0, w0, b0, w1, b1, ray_start, ray_end, opts, out_feat,
+                       out_depth, out_wsum, out_xyz, workspace, workspace_bytes, dumps, stream);
+}
+
+int p3d_render_rng_f32(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R, int ray_tile_w,
+                       uint64_t seed, const float* w0, const float* b0, const float* w1, const float* b1, const float* ray_start,
+                       const float* ray_end, const p3d_opts* opts, float* out_feat, float* out_depth, float* out_wsum, float* out_xyz,
+                       void* workspace, size_t workspace_bytes, const p3d_dumps* dumps, void* stream) {
+    return render_impl(planes, N, H, W, rays_o, rays_d, R, ray_tile_w, nullptr, nullptr, 1, seed, w0, b0, w1, b1, ray_start, ray_end, opts,
+                       out_feat, out_depth, out_wsum, out_xyz, workspace, workspace_bytes, dumps, stream);
+}
+
+static int render_impl(const float* planes, int N, int H, int W, const float* rays_o, const float* rays_d, int64_t R,
+                       int ray_tile_w, const float* jitter, const float* u, int rng, uint64_t seed, const float* w0, const float* b0,
+                       const float* w1, const float* b1, const float* ray_start, const float* ray_end, const p3d_opts* opts,
+                       float* out_feat, float* out_depth, float* out_wsum, float* out_xyz, void* workspace,
+                       size_t workspace_bytes, const p3d_dumps* dumps, void* stream) {
     if ((ray_start == nullptr) != (ray_end == nullptr)) return P3D_E_ARG;  // both or neither
-    if (!planes || !rays_o || !rays_d || !jitter || !w0 || !b0 || !w1 || !b1 || !opts || !out_feat || !out_depth ||
+    if (!planes || !rays_o || !rays_d || (!jitter && !rng) || !w0 || !b0 || !w1 || !b1 || !opts || !out_feat || !out_depth ||
         !out_wsum || !out_xyz || !workspace || N <= 0 || R <= 0)
         return P3D_E_ARG;
     const int Sc = opts->Sc, Sf = opts->Sf;
     if (Sc < 4 || Sc > P3D_MAX_S || Sf < 0 || Sf > P3D_MAX_S) return P3D_E_RANGE;
-    if (Sf > 0 && !u) return P3D_E_ARG;
+    if (Sf > 0 && !u && !rng) return P3D_E_ARG;
     if (H <= 0 || W <= 0 || (long long)H * W * 128 * 3 >= 0x7ffffff0LL) return P3D_E_RANGE;
     if (workspace_bytes < p3d_render_workspace_bytes(N, R, Sc, Sf)) return P3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RenderParams p;
     p.planes = planes; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.u = u;
+    p.rng = rng; p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
     p.out_feat = out_feat; p.out_depth = out_depth; p.out_wsum = out_wsum; p.out_xyz = out_xyz;
     p.gminmax = (uint32_t*)workspace;

@@ -1290,11 +1290,16 @@ __global__ __launch_bounds__(256) void k_upsample2x_add(const float* __restrict_
 }
 
 // 4x4 FIR without resampling (the filter pass after the stride-2 transposed conv), LDS-tiled: a 256-thread block produces
-// a 32x32 output tile of one (n,c) plane from a 35x35 input tile; each thread computes a 2x2 output block from a 5x5 LDS
-// window.  Every input element is read from HBM/L2 once (the generic kernel above re-reads each 16 times through L1).
+// a 32x32 output tile of one (n,c) plane from a 35x35 input tile.  Every input element is read from HBM/L2 once (the generic
+// kernel above re-reads each 16 times through L1).
 // y[Y][X] = sum_{fy,fx} f[fy][fx] * x[Y + fy - pady0][X + fx - padx0]
+// Round 3: a thread computes FOUR consecutive outputs of one row from a 4 x 7 window = 8 ds_read_b128 (was 2 x 2 outputs from a
+// 5 x 5 window = 25 ds_read_b32 at a 2-float lane stride: LDS bank-conflict cycles 0.52 of the LDS cycles, VALU-active 0.66;
+// profiles/r03a_mfma_util.json).  Row pitch 96 floats: consecutive rows start 32 banks apart (of the 64 a b128 read sees), so the
+// 16 lanes of every b128 group — 2-4 rows x 4-8 column quads — hit 64 distinct banks.  Same fma order (fy, then fx): same bits.
+#define FIR_PITCH 96
 __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
-    __shared__ float tile[35 * 36];
+    __shared__ __attribute__((aligned(16))) float tile[35 * FIR_PITCH];
     __shared__ float fs[16];
     const int tid = threadIdx.x;
     const int tiles_x = (p.OW + 31) / 32;
@@ -1302,24 +1307,32 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
     const long long nc = blockIdx.y;
     const float* xc = p.x + nc * p.H * p.W;
     if (tid < 16) fs[tid] = p.f[tid];
-    for (int idx = tid; idx < 35 * 35; idx += 256) {
-        int r = idx / 35, c = idx - r * 35;
-        int u = Y0 + r - p.pady0, v = X0 + c - p.padx0;
-        float val = 0.0f;
-        if (u >= 0 && u < p.H && v >= 0 && v < p.W) {
-            const float* q = xc + (size_t)u * p.W + v;
-            val = q[0];
-            for (int k = 1; k < p.ksplit; ++k) val += q[(size_t)k * p.slice];  // split-K partials, slice order (= k_splitk_reduce)
+    {   // 7 rows x 36 columns per pass (column 35 only pads the b128 reads)
+        const int r0 = tid / 36, c = tid - r0 * 36;
+        const int v = X0 + c - p.padx0;
+        const bool cv = tid < 252 && v >= 0 && v < p.W;
+#pragma unroll
+        for (int ps = 0; ps < 5; ++ps) {
+            const int r = ps * 7 + r0, u = Y0 + r - p.pady0;
+            float val = 0.0f;
+            if (cv && u >= 0 && u < p.H) {
+                const float* q = xc + (size_t)u * p.W + v;
+                val = q[0];
+                for (int k = 1; k < p.ksplit; ++k) val += q[(size_t)k * p.slice];  // split-K partials, slice order (= k_splitk_reduce)
+            }
+            if (tid < 252) tile[r * FIR_PITCH + c] = val;
         }
-        tile[r * 36 + c] = val;
     }
     __syncthreads();
-    const int lx = (tid & 15) * 2, ly = (tid >> 4) * 2;
-    float win[5][5];
+    const int lx = (tid & 7) * 4, ly = tid >> 3;
+    float win[4][8];
 #pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) win[r][c] = tile[(ly + r) * 36 + lx + c];
+    for (int r = 0; r < 4; ++r) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tile + (ly + r) * FIR_PITCH + lx);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tile + (ly + r) * FIR_PITCH + lx + 4);
+        win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
+        win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
+    }
     float dco = 1.0f, bias = 0.0f;
     const int ch = (int)(nc % p.C);
     const long long n = nc / p.C;
@@ -1327,25 +1340,44 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
         if (p.dcoef) dco = p.dcoef[nc];
         if (p.bias) bias = p.bias[ch];
     }
+    const int Y = Y0 + ly, Xb = X0 + lx;
+    if (Y >= p.OH || Xb >= p.OW) return;
+    float out[4];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.0f;
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int Y = Y0 + ly + dy, X = X0 + lx + dx;
-            if (Y >= p.OH || X >= p.OW) continue;
-            float acc = 0.0f;
+        for (int fy = 0; fy < 4; ++fy)
 #pragma unroll
-            for (int fy = 0; fy < 4; ++fy)
+            for (int fx = 0; fx < 4; ++fx) acc = __builtin_fmaf(fs[fy * 4 + fx], win[fy][j + fx], acc);
+        out[j] = acc;
+    }
+    const float* nz = (p.epilogue && p.noise) ? p.noise + (p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + Xb : nullptr;
+    float* yo = p.y + (nc * p.OH + Y) * p.OW + Xb;
+    const bool vec = (p.OW & 3) == 0;  // a row of 4-aligned width: the four outputs are one 16-byte store (Xb is a multiple of 4)
+    float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (nz) {
+        if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(nz); nv[0] = t.x; nv[1] = t.y; nv[2] = t.z; nv[3] = t.w; }
+        else {
 #pragma unroll
-                for (int fx = 0; fx < 4; ++fx) acc = __builtin_fmaf(fs[fy * 4 + fx], win[dy + fy][dx + fx], acc);
-            if (p.epilogue) {
-                acc = acc * dco;
-                if (p.noise) acc = acc + p.noise[(p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + X];
-                acc = acc + bias;
-                acc = act_apply(acc, p.act, p.alpha, p.gain, p.clamp);
-            }
-            p.y[(nc * p.OH + Y) * p.OW + X] = acc;
+            for (int j = 0; j < 4; ++j) nv[j] = (Xb + j < p.OW) ? nz[j] : 0.0f;
         }
+    }
+    if (p.epilogue) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = out[j] * dco;
+            if (nz) acc = acc + nv[j];
+            acc = acc + bias;
+            out[j] = act_apply(acc, p.act, p.alpha, p.gain, p.clamp);
+        }
+    }
+    if (vec) *reinterpret_cast<f32x4*>(yo) = (f32x4){out[0], out[1], out[2], out[3]};
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (Xb + j < p.OW) yo[j] = out[j];
+    }
 }
 
 // x viewed as [outer][C][inner]

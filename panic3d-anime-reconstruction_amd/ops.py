@@ -186,11 +186,35 @@ def sigma2density(sigma, cropmask=None, cull=None):
     return out
 
 
-def marching_cubes(vol, level, flip0=False):
+def drop_degenerate_faces(verts, faces, normals, values):
+    """skimage's `allow_degenerate=False` (the reference: _util/eg3d_metrics3d.py:189-194): a grid value exactly on the level puts
+    several edge crossings on the same grid point, i.e. zero-area triangles.  As skimage does: a face with two coincident
+    vertices is dropped, the coincident vertices are merged (the higher index follows the lower), vertices no face uses any
+    more are removed and the faces re-indexed.  Index compaction on the device; nothing is downloaded."""
+    if faces.shape[0] == 0:
+        return verts, faces, normals, values
+    f = faces.long()
+    tri = verts[f]  # [F,3,3]
+    vmap = torch.arange(verts.shape[0], device=verts.device)
+    deg = torch.zeros(f.shape[0], dtype=torch.bool, device=verts.device)
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        same = (tri[:, a] == tri[:, b]).all(dim=1)
+        deg |= same
+        hi, lo = torch.maximum(f[same, a], f[same, b]), torch.minimum(f[same, a], f[same, b])
+        vmap[hi] = torch.minimum(vmap[hi], lo)
+    f = vmap[f[~deg]]
+    used = torch.zeros(verts.shape[0], dtype=torch.bool, device=verts.device)
+    used[f.reshape(-1)] = True
+    new_index = torch.cumsum(used, 0) - 1
+    return verts[used], new_index[f].to(torch.int32), normals[used], values[used]
+
+
+def marching_cubes(vol, level, flip0=False, allow_degenerate=True):
     """Iso-surface of vol [n,n,n] (device, f32) at `level`, on the device (csrc/p3d_mcubes.hip; specification: DESIGN.md §4.5,
     case table include/p3d_mc_table.h).  flip0: vol is the un-flipped flat grid of grid_density (axis 0 is read reversed).
     Returns verts [V,3] (index space, axis 0/1/2 order), faces [F,3] int32, normals [V,3], values [V] — device tensors.
-    One 16-byte D2H read (the counts) sits between the two launches groups because the caller owns the output buffers."""
+    One 16-byte D2H read (the counts) sits between the two launches groups because the caller owns the output buffers.
+    allow_degenerate=False: zero-area triangles are removed like skimage does (drop_degenerate_faces)."""
     vol = _chk(vol, "vol")
     n = vol.shape[0]
     if vol.dim() != 3 or vol.shape != (n, n, n):
@@ -212,6 +236,8 @@ def marching_cubes(vol, level, flip0=False):
         faces = torch.empty((F, 3), dtype=torch.int32, device=dev)
         _lib.check(L.p3d_mc_emit_f32(_p(vol), n, int(bool(flip0)), np.float32(level), _p(ws), wsb, V, F, _p(verts), _p(normals),
                                      _p(values), _p(faces), _stream()), "p3d_mc_emit_f32")
+    if not allow_degenerate:
+        return drop_degenerate_faces(verts, faces, normals, values)
     return verts, faces, normals, values
 
 
@@ -220,18 +246,24 @@ DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "
 
 
 def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False,
-           ray_limits=None):
+           ray_limits=None, rng_seed=None):
     """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
     jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
     Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps).
     `stats`: pass a dict to receive the number of decode steps the launch executed (exact early-outs, see k_render).
     per_view_clamp: clamp each image's depth to its own sample range (N batched views = N calls of the reference).
     ray_limits: (ray_start, ray_end) per ray [N,R(,1)] for rendering_options['ray_start'] == ['ray_end'] == 'auto'
-    (renderer.py:165-171; cameras.ray_limits_box + cameras.patch_ray_limits compute them)."""
+    (renderer.py:165-171; cameras.ray_limits_box + cameras.patch_ray_limits compute them).
+    rng_seed (int, with jitter = u = None): the two draws are made inside the kernel by the counter-based generator of
+    include/p3d_numerics.h (p3d_render_rng_f32) — no draw tensors exist."""
     if per_view_clamp:
         opts = _with_flag(opts, _lib.P3D_FLAG_PER_VIEW_CLAMP)
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
-    rays_o, rays_d, jitter = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions"), _chk(jitter, "jitter")
+    if rng_seed is not None and (jitter is not None or u is not None):
+        raise RuntimeError("render: pass either the two draws (jitter, u) or rng_seed, not both")
+    rays_o, rays_d = _chk(rays_o, "ray_origins"), _chk(rays_d, "ray_directions")
+    if rng_seed is None:
+        jitter = _chk(jitter, "jitter")
     N, three, H, W, Cc = planes_nhwc.shape
     if N == 1 and rays_o.dim() == 3 and rays_o.shape[0] > 1:  # many views of ONE subject in one launch: planes are shared
         N, opts = rays_o.shape[0], _with_flag(opts, _lib.P3D_FLAG_SHARED_PLANES)
@@ -239,9 +271,9 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         raise RuntimeError("planes_nhwc must be [N,3,H,W,32] (or [1,...] shared by all views); ray_origins / ray_directions [N,R,3]")
     R = rays_o.shape[1]
     Sc, Sf = opts.Sc, opts.Sf
-    if jitter.numel() != N * R * Sc:
+    if rng_seed is None and jitter.numel() != N * R * Sc:
         raise RuntimeError(f"jitter must hold N*R*Sc = {N * R * Sc} values")
-    if Sf > 0:
+    if Sf > 0 and rng_seed is None:
         u = _chk(u, "u")
         if u.numel() != N * R * Sf:
             raise RuntimeError(f"u must hold N*R*Sf = {N * R * Sf} values")
@@ -276,10 +308,15 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         if rs_t.numel() != N * R or re_t.numel() != N * R:
             raise RuntimeError(f"ray_limits must hold N*R = {N * R} values each")
     with torch.cuda.device(dev):
-        rc = L.p3d_render_limits_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), _p(jitter), _p(u),
-                                     _p(w0), _p(b0), _p(w1), _p(b1), _p(rs_t), _p(re_t), C.byref(opts), _p(feat), _p(depth),
-                                     _p(wsum), _p(xyz), _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
-    _lib.check(rc, "p3d_render_limits_f32")
+        if rng_seed is not None:
+            rc = L.p3d_render_rng_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), int(rng_seed) & (2 ** 64 - 1),
+                                      _p(w0), _p(b0), _p(w1), _p(b1), _p(rs_t), _p(re_t), C.byref(opts), _p(feat), _p(depth),
+                                      _p(wsum), _p(xyz), _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
+        else:
+            rc = L.p3d_render_limits_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), _p(jitter), _p(u),
+                                         _p(w0), _p(b0), _p(w1), _p(b1), _p(rs_t), _p(re_t), C.byref(opts), _p(feat), _p(depth),
+                                         _p(wsum), _p(xyz), _p(ws), wsb, C.byref(dm) if dm is not None else None, _stream())
+    _lib.check(rc, "p3d_render_rng_f32" if rng_seed is not None else "p3d_render_limits_f32")
     if stats is not None:  # synchronises: wave-level decode steps executed (32 samples each) vs the full count
         steps = int(ws[8:16].view(torch.int64).item())
         tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)

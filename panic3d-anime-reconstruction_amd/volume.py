@@ -90,16 +90,17 @@ def density_grid_sharded(G, ws, cond, resolution=256, dst=0, **kw):
     return res
 
 
-def marching_cubes(vol, rgbs, boxwarp, level=0.5, flip0=False):
+def marching_cubes(vol, rgbs, boxwarp, level=0.5, flip0=False, allow_degenerate=False):
     """`_util/eg3d_metrics3d.py:186-210 marching_cubes(vol, rgbs, boxwarp, level)` with the surface extracted on the device.
     vol [n,n,n] (device tensor; numpy is uploaded), rgbs: [>=3,n,n,n] tensor indexed like the reference does
     (`rgbs[:3, a, b, c]` at `verts.astype(int)`), or a callable `rgbs(ijk[V,3] long) -> [V,3]`, or None.
     Returns the reference's dict (verts scaled by /n*bw - bw/2 as eg3d_metrics3d.py:201-202 — sic, n not n-1; numpy
-    arrays).  The triangulation is this repo's, not Lewiner's."""
+    arrays).  The triangulation is this repo's, not Lewiner's.  allow_degenerate=False is what the reference
+    passes to skimage (eg3d_metrics3d.py:189-194): zero-area triangles (a grid value exactly on the level) are removed."""
     if not torch.is_tensor(vol):
         vol = torch.as_tensor(np.ascontiguousarray(vol, dtype=np.float32)).cuda()
     n = vol.shape[-1]
-    verts, faces, normals, values = ops.marching_cubes(vol.contiguous(), level, flip0=flip0)
+    verts, faces, normals, values = ops.marching_cubes(vol.contiguous(), level, flip0=flip0, allow_degenerate=allow_degenerate)
     out = {}
     if rgbs is not None:
         ijk = verts.long()  # .astype(int): truncation; coordinates are >= 0

@@ -144,5 +144,32 @@ def test_mesh_flow_colors(hip):
     assert len(mc["faces"]) > 100 and mc["colors"].shape == (len(mc["verts"]), 3)
     for k in ("verts", "faces", "normals", "values", "colors"):
         assert np.array_equal(mc[k], ref[k]), k
-    idx = hip.ops.marching_cubes(dens, level)[0].cpu().numpy()
+    # (the level IS a grid value here: the reference's allow_degenerate=False, the default of volume.marching_cubes / mesh, applies)
+    idx = hip.ops.marching_cubes(dens, level, allow_degenerate=False)[0].cpu().numpy()
     assert np.array_equal(mc["verts"], (idx / N * 0.7 - 0.5 * 0.7).astype(np.float32))
+    assert hip.ops.marching_cubes(dens, level)[1].shape[0] >= len(mc["faces"])
+
+
+def test_degenerate_triangles_are_dropped_like_skimage_allow_degenerate_false(hip):
+    """The reference extracts its meshes with allow_degenerate=False (_util/eg3d_metrics3d.py:189-194).  A volume with grid values
+    EXACTLY on the level (integer distances, integer level) makes zero-area triangles; volume.marching_cubes removes them, merges
+    the coincident vertices and drops unused ones; the raw extractor (ops.marching_cubes) keeps them."""
+    n = 24
+    g = torch.arange(n, dtype=torch.float32) - 11.0
+    vol = (g[:, None, None] ** 2 + g[None, :, None] ** 2 + g[None, None, :] ** 2).cuda().contiguous()  # integers; 25 occurs (3,4,0) ...
+    v0, f0, n0, s0 = hip.ops.marching_cubes(vol, 25.0)
+    tri = v0[f0.long()]
+    deg0 = ((tri[:, 0] == tri[:, 1]).all(1) | (tri[:, 0] == tri[:, 2]).all(1) | (tri[:, 1] == tri[:, 2]).all(1))
+    assert int(deg0.sum()) > 0  # the fixture really has degenerate faces
+    v1, f1, n1, s1 = hip.ops.marching_cubes(vol, 25.0, allow_degenerate=False)
+    tri1 = v1[f1.long()]
+    deg1 = ((tri1[:, 0] == tri1[:, 1]).all(1) | (tri1[:, 0] == tri1[:, 2]).all(1) | (tri1[:, 1] == tri1[:, 2]).all(1))
+    assert int(deg1.sum()) == 0 and f1.shape[0] == f0.shape[0] - int(deg0.sum())
+    assert f1.dtype == torch.int32 and int(f1.min()) >= 0 and int(f1.max()) < v1.shape[0]
+    assert torch.unique(f1).numel() == v1.shape[0] and v1.shape[0] < v0.shape[0]  # every vertex is used; coincident ones merged
+    assert n1.shape == v1.shape and s1.shape[0] == v1.shape[0]
+    # the surface itself is unchanged: same set of non-degenerate triangles (as vertex coordinates)
+    key = lambda t: set(map(tuple, t.reshape(-1, 9).cpu().numpy().round(5).tolist()))
+    assert key(tri[~deg0]) == key(tri1)
+    out = hip.volume.marching_cubes(vol, None, 0.7, level=25.0)  # the mirror of eg3d_metrics3d.marching_cubes: drops them by default
+    assert out["faces"].shape[0] == f1.shape[0] and out["verts"].shape[0] == v1.shape[0]

@@ -528,3 +528,36 @@ def test_grid_density_staged_equals_direct_gather(hip, oracle, n, H, W, use_trip
     else:
         cropped = ((pts[0, :, 0].abs() > np.float32(lim)) | (pts[0, :, 2].abs() > np.float32(lim))).numpy()
         assert np.array_equal(got[~cropped], osig[0, ~cropped, 0]) and np.all(got[cropped] == -1000.0)
+
+
+@pytest.mark.parametrize("Sc,Sf,res", [(48, 48, 32), (96, 96, 16), (12, 12, 24), (32, 0, 16)])
+def test_in_kernel_draws_match_the_restated_generator(hip, oracle, Sc, Sf, res):
+    """p3d_render_rng_f32 (round 3, opt-in): the two random draws are made inside the kernel by the counter-based generator of
+    include/p3d_numerics.h instead of being read from 200 MB of torch.rand output.  The oracle restates the generator
+    (oracle.device_draws) and renders with those arrays: every output bit-identical, on both render kernels and with the
+    tolerance-mode final pass within its stated bound.  Also: the draws are in [0, 1) on torch.rand's 2^-24 grid, and two seeds
+    give different images."""
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    planes = T.make_planes(61, 2, 64, 64, scale=4.0, smooth=8)
+    raw = T.make_decoder_params(62, 1.0, 30.0)
+    lab = torch.stack([hip.cameras.camera_label(0.0, 20.0, 1.0, 30.0), hip.cameras.camera_label(10.0, 200.0, 1.0, 30.0)])
+    o, d = hip.cameras.rays_from_label(lab, res)
+    kw = dict(triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+    seed = 0x1234_5678_9ABC_DEF1
+    jit, u = oracle.device_draws(seed, 2, res * res, Sc, Sf)
+    assert jit.min() >= 0 and jit.max() < 1 and np.all(jit * 2 ** 24 == np.floor(jit * 2 ** 24)) and abs(float(jit.mean()) - 0.5) < 0.02
+    ref = oracle.render(planes, o.numpy(), d.numpy(), jit, u if Sf > 0 else None, oracle.prescale_mlp(*raw), oracle.make_opts(ro, **kw))
+    mlp = hip_mlp(hip, raw, 1.0)
+    nhwc = hip.ops.planes_to_nhwc(dev(planes))
+    for small in (True, False):
+        out = hip.ops.render(nhwc, o.cuda(), d.cuda(), None, None, mlp, hip.ops.make_opts(ro, small_launch_kernel=small, **kw), ray_tile_w=res,
+                             rng_seed=seed)
+        for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
+            assert np.array_equal(a.cpu().numpy(), b), (nm, small)
+    if Sf > 0:
+        fast = hip.ops.render(nhwc, o.cuda(), d.cuda(), None, None, mlp,
+                              hip.ops.make_opts(ro, small_launch_kernel=False, fast_color=True, **kw), ray_tile_w=res, rng_seed=seed)
+        for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), fast, ref):
+            assert float(np.abs(a.cpu().numpy() - b).max()) <= FAST_MAX[nm], nm
+    other = hip.ops.render(nhwc, o.cuda(), d.cuda(), None, None, mlp, hip.ops.make_opts(ro, **kw), ray_tile_w=res, rng_seed=seed + 1)
+    assert not torch.equal(other[0], out[0])
