@@ -201,7 +201,9 @@ def drop_degenerate_faces(verts, faces, normals, values):
         same = (tri[:, a] == tri[:, b]).all(dim=1)
         deg |= same
         hi, lo = torch.maximum(f[same, a], f[same, b]), torch.minimum(f[same, a], f[same, b])
-        vmap[hi] = torch.minimum(vmap[hi], lo)
+        vmap.scatter_reduce_(0, hi, lo, reduce="amin")  # deterministic for repeated indices (a plain indexed store is not)
+    for _ in range(4):  # follow chains a -> b -> c (coincident vertices of one grid point: at most a handful)
+        vmap = vmap[vmap]
     f = vmap[f[~deg]]
     used = torch.zeros(verts.shape[0], dtype=torch.bool, device=verts.device)
     used[f.reshape(-1)] = True
