@@ -62,6 +62,9 @@ def test_bench_default_invocation_prints_the_contract_line():
     assert all(r["kernel_ms"] > 0 and r["kernel_ms_no_early_out"] > 0 and 0 < r["decode_steps_executed_frac"] <= 1 for r in d["results"])
     assert len(d["eval_faithful"]["rows"]) == 4 and all(r["Sc"] == 96 and r["Sf"] == 96 for r in d["eval_faithful"]["rows"])
     assert d["sustained"]["seconds"] >= 2.0 and d["sustained"]["sustained_ms_per_step"] > 0
+    assert d["device_rng"]["ms_per_step"] > 0 and d["device_rng"]["kernel_ms"] > 0  # the opt-in in-kernel draws, beside the contract step
+    rec = d["roofline"]["recorded"]  # PMC numbers are builder-recorded and say so; absent capture -> nulls, never stale numbers
+    assert "source" in rec and (rec["bounds"] is None or rec["bounds"].get("valu_active_frac", 0) <= 1.0)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "rays/s" and c["sample"]
     assert "per_rank" not in d
