@@ -1,4 +1,2 @@
-O=gpurun_out/r03n; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench.err; echo "bench rc $?"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python tools/experiments/ablate/time_layers.py 2>/dev/null | tail -1
+for t in base w2_nox w2_now nostore up_nox up_now; do P3D_LIB=$GRAFT_REPO_ROOT/tools/experiments/ablate/lib_$t.so python tools/experiments/ablate/time_layers.py 2>/dev/null | tail -1; done
