@@ -10,7 +10,10 @@ HEADERS = ["p3d_math.hpp", "p3d_decode.hpp", os.path.join("..", "..", "include",
            os.path.join("..", "..", "include", "p3d_numerics.h"), os.path.join("..", "..", "include", "p3d_mc_table.h")]
 # -fno-slp-vectorize: v_pk_fma_f32 runs at ~0.4x the flop rate of v_fma_f32 on gfx950 (tools/ubench/valu_rates.hip).
 # -ffp-contract=off: the arithmetic contract (include/p3d_numerics.h) names every fma explicitly.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared"]
+# -pragma-unroll-threshold: k_render<96,...>'s twelve inverse-CDF batches must unroll completely (their results live in a
+#   register array); the default 16 k-instruction cap refuses and the array lands in scratch memory.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+               "-mllvm", "-pragma-unroll-threshold=200000", "-fPIC", "-shared"]
 
 
 def _hipcc():

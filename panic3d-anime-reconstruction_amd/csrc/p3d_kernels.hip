@@ -398,6 +398,43 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
     }
 }
 
+// The same with the coarse depths behind a functor tc(index) instead of an LDS column (k_render's TCG instantiations recompute
+// them from the jitter tensor).  Identical arithmetic.
+template <int B, typename TCF>
+P3D_DEV void p3d_inverse_cdf_batch_f(const float* cdfA, TCF tc, int Ns, int j, const float (&ui)[B], float (&out)[B], int (&k_out)[B]) {
+    const int n = Ns + 1;
+    int pos[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) pos[q] = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        if (step <= n) {  // wave-uniform
+            float c[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) c[q] = cdfA[((pos[q] + step <= n) ? pos[q] + step - 1 : 0) * 32 + j];
+#pragma unroll
+            for (int q = 0; q < B; ++q) pos[q] = ((pos[q] + step <= n) && (c[q] <= ui[q])) ? pos[q] + step : pos[q];
+        }
+    }
+    float cb[B], ca[B], t0[B], t1[B], t2[B], t3[B];
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+        const int k = pos[q], below = k - 1 > 0 ? k - 1 : 0, above = k < Ns ? k : Ns;
+        k_out[q] = k;
+        cb[q] = cdfA[below * 32 + j]; ca[q] = cdfA[above * 32 + j];
+        t0[q] = tc(below); t1[q] = tc(below + 1);
+        t2[q] = tc(above); t3[q] = tc(above + 1);
+    }
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+        float den = ca[q] - cb[q];
+        if (den < 1e-5f) den = 1.0f;
+        const float bb = 0.5f * (t0[q] + t1[q]), ba = 0.5f * (t2[q] + t3[q]);
+        out[q] = bb + ((ui[q] - cb[q]) / den) * (ba - bb);
+        asm volatile("" : "+v"(out[q]));  // (see p3d_inverse_cdf_batch)
+    }
+}
+
 // NF: register capacity for the fine depths (sorted by a network); NF == 0: generic path, fine depths sorted in LDS.
 //   NF = 48 / 96: Sf == NF exactly (the trainer's 48+48 and the eval-faithful 96+96 of eg3dc_v0.py:30-31): no padding keys, no
 //   `i < Sf` predicates (64 uniform predicates held in SGPR pairs were the 102-107 SGPR spills of round 2's NF = 64 kernels);
@@ -419,11 +456,23 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
 // FAST (P3D_FLAG_FAST_COLOR): the FINAL pass decodes in tolerance mode (p3d_decode_wave_fast); the coarse pass, and with it
 // the importance resampling (inverse-CDF indices, fine depths, merged depth order), stays on the exact contract.
 // EARLY: the exact early-outs (compile-time, so that the measurement / dump variant is the plain uniform loop).
+// TCG ("coarse depths from global"): the production (EARLY) 96-key kernel keeps NO coarse-depth rows in LDS — Sc + Sf = 192 depth
+// rows are 24.5 KB per wave, which capped a CU at 4 waves = ONE per SIMD (round 3: 512^2 x (96+96) every sample decoded took 1.39x
+// twice the 48+48 time).  A coarse depth is a pure function of (index, jitter value): t_i = lin_i + jitter[ray][i] * delta, so it is
+// recomputed wherever it is needed — streamed in index order in the coarse pass and the merge pre-pass (the jitter row is read
+// like the stratified phase reads it), fetched per lane (one 4-byte load from the L2-resident jitter tensor, or the in-kernel
+// generator) in the inverse-CDF lerp and in the final walk, where the NEXT coarse depth of every lane is prefetched under the
+// current decode.  Rows per wave: max(Sc, Sf) + 12 bit rows = 108 -> 13.8 KB -> 8 waves per CU, two per SIMD, also with the
+// tolerance-mode LDS image; the known-masked bits of the coarse samples live in three registers.  With jitter in [0, 1), as
+// torch.rand_like produces it, the stratified depths can be out of order only between NEIGHBOURS (rounding), which the sorted
+// accessor resolves with two more reads; any other disorder takes an exact O(Sc^2) selection (tc_sorted below).
 #define P3D_NF_EXACT(NF) ((NF) == 48 || (NF) == 96)
-#define P3D_NF_OCC(NF) ((NF) >= 96 ? 1 : P3D_RENDER_OCC)
+#define P3D_TCG(NF, DUMP, EARLY) ((NF) == 96 && (EARLY) && !(DUMP))
+#define P3D_NF_OCC(NF, DUMP, EARLY) (((NF) >= 96 && !P3D_TCG(NF, DUMP, EARLY)) ? 1 : P3D_RENDER_OCC)
 template <int NF, bool DUMP, bool FAST, bool EARLY>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_render(RenderParams p) {
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, DUMP, EARLY)) void k_render(RenderParams p) {
     static_assert(!(DUMP && EARLY), "dumps need every sample decoded");
+    constexpr bool TCG = P3D_TCG(NF, DUMP, EARLY);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
     if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
@@ -477,19 +526,58 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
     const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
 
     // LDS rows of this wave: row(i)[j]
-    float* tcA = wl;             // [Sc]            coarse depths
-    float* wcA = tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
+    float* tcA = wl;             // [Sc]            coarse depths (TCG: no such rows)
+    float* wcA = TCG ? wl : tcA + Sc * 32;  // [max(Sc,Sf)]    coarse weights -> pdf/cdf (row 0 = cdf[0]) -> (NF path) sorted fine depths
     float* tfA = (NF > 0) ? wcA : wcA + Sc * 32;  // [Sf] sorted fine depths
     uint32_t* mkA = (uint32_t*)(wl + (size_t)(p.lds_rows - ((Sc + 31) >> 5)) * 32);  // [ceil(Sc/32)] known-masked bits of the coarse samples
     const int nmw = (S + 31) >> 5;                         // words of a bit row over the merged list
-    uint32_t* knA = mkA - (size_t)2 * nmw * 32;            // [ceil(S/32)] merged sample q: sigma = -1000 known without a decode
+    uint32_t* knA = TCG ? (uint32_t*)(wl + (size_t)(Sc > Sf ? Sc : Sf) * 32) : mkA - (size_t)2 * nmw * 32;  // [ceil(S/32)] merged sample q: sigma = -1000 known without a decode
     uint32_t* slA = knA + (size_t)nmw * 32;                // [ceil(S/32)] merged sample q comes from the coarse list
+    // ---- the stratified depth of coarse sample i from its jitter value (renderer.py:324-326): the plain branch of the loop
+    // below as a function (the host launches a TCG instantiation only for it: fixed ray_start / ray_end, no disparity spacing)
+    const float sd_step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
+    auto depth_of = [&](int i, float jv) -> float {
+        const float lin = (i < Sc / 2) ? p3d_fma(sd_step, (float)i, p.ray_start) : p3d_fma(-sd_step, (float)(Sc - 1 - i), p.ray_end);
+        return lin + jv * p.depth_delta;
+    };
+    const float* jitp = p.jitter + ray * Sc;  // (not dereferenced with the in-kernel generator)
+    auto jit_at = [&](int i) -> float { return p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 0u, ray, i) : jitp[i]; };
+    auto tc_raw = [&](int i) -> float { return depth_of(i, jit_at(i)); };  // coarse depth i in DRAW order (bins of the pdf)
+    bool wave_unsorted = false;  // TCG: some ray of this wave has two neighbouring stratified depths out of order
+    bool bad_order = false;      // TCG: disorder beyond neighbours somewhere in this RAY (jitter outside [0, 1))
+    bool wave_bad = false;       //      ... somewhere in this wave
+    // coarse depth of sorted RANK i (what the stable sort of renderer.py:289-301 puts there): the draw-order value itself unless
+    // the wave saw a reversed pair — then the neighbour that rounding swapped in, or (jitter outside [0, 1): never from
+    // torch.rand_like) the rank-i element of the row by counting, O(Sc^2) jitter reads per access: slow, exact, and not a
+    // path any renderer.py call reaches
+    auto tc_sorted = [&](int i) -> float {
+        float a = tc_raw(i);
+        if (wave_unsorted) {  // wave-uniform
+            if (!wave_bad) {
+                const float lo = i > 0 ? tc_raw(i - 1) : -__builtin_inff(), hi = i < Sc - 1 ? tc_raw(i + 1) : __builtin_inff();
+                a = lo > a ? lo : (a > hi ? hi : a);
+            } else {
+                for (int c = 0; c < Sc; ++c) {
+                    const float tv = tc_raw(c);
+                    int r = 0;
+                    for (int x = 0; x < Sc; ++x) {
+                        const float tx = tc_raw(x);
+                        r += (tx < tv || (tx == tv && x < c)) ? 1 : 0;
+                    }
+                    a = (r == i) ? tv : a;
+                }
+            }
+        }
+        return a;
+    };
+    uint32_t mw0 = 0u, mw1 = 0u, mw2 = 0u;  // TCG: known-masked bits of coarse samples 0-31 / 32-63 / 64-95 (registers, not LDS rows)
+    uint32_t fw0 = 0u, fw1 = 0u, fw2 = 0u;  // TCG: sorted fine sample k is cropped (sigma = -1000 by position)
     const bool dump = DUMP && active && h == 0;
 
     // ---- sample_stratified: renderer.py:320-324
     bool unsorted = false;
     float tcmin = __builtin_inff(), tcmax = -__builtin_inff();  // extrema of the coarse depths
-    {
+    if constexpr (!TCG) {
         const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
         const float* jit = p.jitter + ray * Sc;
         // per-ray limits (ray_start = ray_end = 'auto'): math_utils.linspace + per-ray depth_delta (renderer.py:317-319)
@@ -536,6 +624,48 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
         MarchState st;
         st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
         uint32_t mword = 0;  // bit i & 31: coarse sample i is KNOWN to carry sigma = -1000 (cropped, or really decoded and masked)
+        if constexpr (TCG) {
+            // stratified depths and coarse pass in one loop: the jitter row is read eight values at a time, the depths never
+            // reach LDS
+            float prev = -__builtin_inff(), pmax = -__builtin_inff();  // previous depth; maximum of all depths before it
+            for (int i0 = 0; i0 < Sc; i0 += 8) {
+                float jv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) jv[q] = jit_at(i0 + q < Sc ? i0 + q : Sc - 1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q;
+                    if (i >= Sc) break;  // wave-uniform
+                    const float t = depth_of(i, jv[q]);
+                    unsorted |= (t < prev);
+                    bad_order |= (t < pmax);
+                    pmax = __builtin_fmaxf(pmax, prev);
+                    prev = t;
+                    tcmin = __builtin_fminf(tcmin, t);
+                    tcmax = __builtin_fmaxf(tcmax, t);
+                    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
+                    float sigma = P3D_SIGMA_MASKED;
+                    const bool cropped = f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+                    const bool live = !(cropped || st.Td < 1e-60);
+                    const bool skip = __builtin_amdgcn_ballot_w64(live) == 0;
+                    if (!skip) {
+                        f32x16 dummy;
+                        p3d_decode_wave<false, (FAST || P3D_QUAD_EXACT != 0) && (P3D_QUAD_COARSE != 0)>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                    }
+                    mword |= (cropped || (live && sigma == P3D_SIGMA_MASKED)) ? (1u << (i & 31)) : 0u;
+                    if ((i & 31) == 31 || i == Sc - 1) {  // wave-uniform
+                        if ((i >> 5) == 0) mw0 = mword; else if ((i >> 5) == 1) mw1 = mword; else mw2 = mword;
+                        mword = 0;
+                    }
+                    if (i > 0) {
+                        float tm;
+                        wcA[(i - 1) * 32 + j] = p3d_march_weight(st, t, sigma, tm);
+                    }
+                    st.prev_t = t; st.prev_sigma = sigma;
+                    ndec += skip ? 0 : 1;
+                }
+            }
+        } else
         for (int i = 0; i < Sc; ++i) {
             float t = tcA[i * 32 + j];
             float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;  // renderer.py:179
@@ -601,7 +731,8 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
                     int kb[DB];
 #pragma unroll
                     for (int q = 0; q < DB; ++q) ub[q] = tf[i0 + q];
-                    p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, j, ub, vb, kb);
+                    if constexpr (TCG) p3d_inverse_cdf_batch_f<DB>(wcA, tc_raw, Ns, j, ub, vb, kb);
+                    else p3d_inverse_cdf_batch<DB>(wcA, tcA, Ns, j, ub, vb, kb);
 #pragma unroll
                     for (int q = 0; q < DB; ++q) {
                         tf[i0 + q] = (i0 + q < Sf) ? vb[q] : __builtin_inff();
@@ -618,7 +749,14 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
             p3d_sort_network<NF>(tf);
 #pragma unroll
             for (int i = 0; i < NF; ++i)
-                if (i < Sf) tfA[i * 32 + j] = tf[i];  // over the cdf rows: every search is done
+                if (i < Sf) {
+                    tfA[i * 32 + j] = tf[i];  // over the cdf rows: every search is done
+                    if constexpr (TCG) {
+                        const float px = ox + tf[i] * dx, pz = oz + tf[i] * dz;
+                        const uint32_t b = (f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit)) ? (1u << (i & 31)) : 0u;
+                        if (i < 32) fw0 |= b; else if (i < 64) fw1 |= b; else fw2 |= b;
+                    }
+                }
         } else {
             for (int i0 = 0; i0 < Sf; i0 += DB) {
                 float ub[DB], vb[DB];
@@ -644,6 +782,11 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
         }
         // unify_samples (renderer.py:289-301) merges two sorted lists; the stratified list is sorted unless rounding
         // reversed two neighbours (practically never) — then sort it too.
+        if constexpr (TCG) {
+            wave_unsorted = __builtin_amdgcn_ballot_w64(unsorted) != 0;  // from here on tc_sorted() looks at the neighbours
+            wave_bad = __builtin_amdgcn_ballot_w64(bad_order) != 0;
+            if (wave_unsorted) { mw0 = 0u; mw1 = 0u; mw2 = 0u; }         // (bits indexed by draw order: forget them, as below)
+        } else
         if (__builtin_amdgcn_ballot_w64(unsorted) != 0) {
             p3d_lds_insertion_sort(tcA, Sc, j);
             if (early) {  // the known-masked bits are indexed by ORIGINAL coarse index: forget them (practically never taken)
@@ -672,7 +815,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
     for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
     {
         int ci = 0, fi = 0;
-        float ta = tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
+        float ta = TCG ? 0.0f : tcA[j], tb = (Sf > 0) ? tfA[j] : __builtin_inff();
         // the extrema of all depths of the ray (the global clamp range, ray_marcher.py:50); the fine list is sorted
         tmin = __builtin_fminf(tcmin, tb);
         tmax = __builtin_fmaxf(tcmax, (Sf > 0) ? tfA[(Sf - 1) * 32 + j] : -__builtin_inff());
@@ -692,6 +835,64 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
             ta = take_c ? nv : ta;
             tb = take_c ? tb : nv;
         };
+        float tcn = 0.0f;  // TCG: the head of the coarse list, tc_sorted(min(ci, Sc - 1)), fetched ahead of its use
+        if constexpr (TCG) {
+            // the merge without a coarse column: coarse rank i lands at merged position i + #{fine < t_i} (ties: coarse first),
+            // found by a search in the sorted fine column, eight ranks in flight; the two bit rows are built in registers (six
+            // words each: Sc + Sf <= 192) and stored once
+            uint32_t slw[6], knw[6];
+#pragma unroll
+            for (int w = 0; w < 6; ++w) { slw[w] = 0u; knw[w] = 0u; }
+            for (int i0 = 0; i0 < Sc; i0 += 8) {
+                float tv[8];
+                int pos[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { tv[q] = tc_sorted(i0 + q < Sc ? i0 + q : Sc - 1); pos[q] = 0; }
+#pragma unroll
+                for (int step = 64; step >= 1; step >>= 1) {
+                    float c[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) c[q] = tfA[((pos[q] + step <= Sf) ? pos[q] + step - 1 : 0) * 32 + j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) pos[q] = ((pos[q] + step <= Sf) && (c[q] < tv[q])) ? pos[q] + step : pos[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q;
+                    if (i >= Sc) break;  // wave-uniform
+                    const uint32_t mwv = (i < 32) ? mw0 : (i < 64 ? mw1 : mw2);  // (i is uniform)
+                    const bool known = is_cropped(tv[q]) || ((mwv >> (i & 31)) & 1u);
+                    const int P = i + pos[q], pw = P >> 5;
+                    const uint32_t b = 1u << (P & 31);
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) {
+                        slw[w] |= (pw == w) ? b : 0u;
+                        knw[w] |= (pw == w && known) ? b : 0u;
+                    }
+                }
+            }
+            // cropped fine samples: fine k sits at the k-th zero of the is-coarse row
+            if (__builtin_amdgcn_ballot_w64((fw0 | fw1 | fw2) != 0u) != 0) {
+                int fk = 0;
+#pragma unroll
+                for (int w = 0; w < 6; ++w) {
+                    if (w * 32 < S) {  // wave-uniform
+                        uint32_t kk = 0u;
+                        for (int b = 0; b < 32; ++b) {
+                            const bool isf = !((slw[w] >> b) & 1u) && (w * 32 + b < S);
+                            const uint32_t fwv = (fk < 32) ? fw0 : (fk < 64 ? fw1 : fw2);
+                            kk |= (isf && ((fwv >> (fk & 31)) & 1u)) ? (1u << b) : 0u;
+                            fk += isf ? 1 : 0;
+                        }
+                        knw[w] |= kk;
+                    }
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 6; ++w)
+                if (w < nmw) { knA[w * 32 + j] = knw[w]; slA[w * 32 + j] = slw[w]; }
+            tcn = tc_sorted(0);
+        } else
         if constexpr (EARLY) {
             // the merge, once: bit q of slA = merged sample q is the head of the coarse list, bit q of knA = its sigma is known
             uint32_t kw = 0u, sw = 0u;
@@ -740,6 +941,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
                         if (run < left) break;  // stopped in front of a sample that has to be decoded
                     }
                     if (any) {
+                        if constexpr (TCG) {
+                            // the two coarse depths a jump needs, requested together: the last consumed one and the new head
+                            const float pc = tc_sorted(ci > 0 ? ci - 1 : 0);
+                            tcn = tc_sorted(ci < Sc ? ci : Sc - 1);
+                            st.prev_t = last_c ? pc : tfA[(m - ci - 1 > 0 ? m - ci - 1 : 0) * 32 + j];
+                        } else
                         st.prev_t = last_c ? tcA[(ci - 1) * 32 + j] : tfA[(m - ci - 1) * 32 + j];
                         st.prev_sigma = P3D_SIGMA_MASKED;
                         prev_skipped = true; first = false;
@@ -752,8 +959,12 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF)) void k_rende
                 take_c = (sb & 1u) != 0u;
                 known = !done && (kb & 1u) != 0u;
                 const int cq = ci < Sc ? ci : Sc - 1, fq = (m - ci < Sf) ? m - ci : (Sf > 0 ? Sf - 1 : 0);
-                t = (take_c || Sf == 0) ? tcA[cq * 32 + j] : tfA[fq * 32 + j];
+                if constexpr (TCG) t = take_c ? tcn : tfA[fq * 32 + j];
+                else t = (take_c || Sf == 0) ? tcA[cq * 32 + j] : tfA[fq * 32 + j];
                 if (!done) { ++m; ci += take_c ? 1 : 0; }
+                if constexpr (TCG) {
+                    if (!done && take_c) tcn = tc_sorted(ci < Sc ? ci : Sc - 1);  // used one step later at the earliest: under the decode
+                }
             }
             const bool have = EARLY ? !done : true;
             const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
@@ -1569,10 +1780,16 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     // per-wave LDS rows: tc (Sc) + wc/cdf/sorted-fine (max(Sc,Sf)) [+ tf (Sf) on the generic path]
     // register-resident fine depths: 48 / 96 exactly (the trainer's and the eval-faithful rates), any other Sf <= 64 padded to 64;
     // the rest sorts in LDS
-    const int nf = (Sf == 48) ? 48 : (Sf == 96) ? 96 : (Sf <= 64 ? 64 : 0);
-    const int occ = (nf >= 96) ? 1 : P3D_RENDER_OCC;  // waves per SIMD the instantiation is compiled for (P3D_NF_OCC)
+    const int nf = (Sf == 48) ? 48 : (Sf == 96 && Sc <= 96) ? 96 : (Sf <= 64 ? 64 : 0);
+    const bool dmp = dumps != nullptr;
+    const bool pair = !dmp && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512;  // (the small-launch kernel, below)
+    // the production 96-key kernel keeps no coarse-depth rows (P3D_TCG) and runs two waves per SIMD like the others
+    // (for the plain stratified spacing: per-ray limits and disparity spacing keep the LDS-resident 96-key kernel)
+    const bool tcg = nf == 96 && !dmp && !pair && !(opts->flags & P3D_FLAG_NO_EARLY_OUT) && !ray_start && !p.disparity;
+    const int occ = (nf >= 96 && !tcg) ? 1 : P3D_RENDER_OCC;  // waves per SIMD the instantiation is compiled for (P3D_NF_OCC)
     // + two bit rows over the merged list (is-coarse / known-masked) + the known-masked bits of the coarse samples
     p.lds_rows = Sc + (Sc > Sf ? Sc : Sf) + (nf == 0 ? Sf : 0) + 2 * ((Sc + Sf + 31) >> 5) + ((Sc + 31) >> 5);
+    if (tcg) p.lds_rows = (Sc > Sf ? Sc : Sf) + 2 * ((Sc + Sf + 31) >> 5);
     int nwaves = P3D_RENDER_WAVES;
     // small ray counts (e.g. the pipeline's 128^2 rays = 512 tiles): shrink the workgroup so that every CU gets work
     while (nwaves > 1 && p.ntiles / nwaves < 2 * 256) nwaves >>= 1;
@@ -1600,12 +1817,11 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
         if (nwaves == 1) return P3D_E_RANGE;
     }
     hipLaunchKernelGGL(k_minmax_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, p.gminmax, p.per_view_clamp ? N : 0);
-    const bool dmp = dumps != nullptr;
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
     // (P3D_FLAG_FAST_COLOR is a permission, not an obligation: this kernel has no tolerance variant and its exact results are
     // trivially within any tolerance)
-    if (!dmp && !(opts->flags & P3D_FLAG_NO_PAIR) && p.ntiles <= 512) {
+    if (pair) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
         else p.tiles_per_img = (R + 15) / 16;
         p.ntiles = p.tiles_per_img * N;

@@ -561,3 +561,42 @@ def test_in_kernel_draws_match_the_restated_generator(hip, oracle, Sc, Sf, res):
             assert float(np.abs(a.cpu().numpy() - b).max()) <= FAST_MAX[nm], nm
     other = hip.ops.render(nhwc, o.cuda(), d.cuda(), None, None, mlp, hip.ops.make_opts(ro, **kw), ray_tile_w=res, rng_seed=seed + 1)
     assert not torch.equal(other[0], out[0])
+
+
+@pytest.mark.parametrize("Sc,Sf", [(96, 96), (64, 96), (48, 48)])
+def test_stratified_depths_out_of_order_are_sorted_like_the_reference(hip, oracle, Sc, Sf):
+    """unify_samples sorts the concatenated depths (renderer.py:289-301), so a stratified row that is NOT ascending still has a
+    defined result.  With jitter from torch.rand_like only rounding can swap two neighbours; this test forces both kinds of
+    disorder with doctored jitter — neighbour swaps (jitter 1.5 next to 0.1) and far moves (3.7, -2.2: outside anything the
+    reference draws) — on the large-launch kernels.  The 96-key production kernel holds no coarse-depth column at all and
+    resolves sorted ranks on the fly (csrc/p3d_kernels.hip, P3D_TCG): its three access paths must all match the oracle bit
+    for bit, in both precision modes' depth handling."""
+    res = 24
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    planes = T.make_planes(71, 1, 64, 64, scale=4.0, smooth=8)
+    raw = T.make_decoder_params(72, 1.0, 30.0)
+    o, d = hip.cameras.rays_from_label(hip.cameras.camera_label(5.0, 30.0, 1.0, 30.0)[None], res)
+    kw = dict(triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+    jit, u = T.make_random_draws(73, 1, res * res, Sc, Sf)
+    jit = jit.copy()
+    rng = np.random.default_rng(74)
+    rays = rng.permutation(res * res)
+    for r in rays[:120]:  # neighbour swaps, some rays twice, also at both ends of the row
+        for i in rng.choice(Sc - 1, size=rng.integers(1, 3), replace=False):
+            jit.reshape(res * res, Sc)[r, i] = 1.5
+            jit.reshape(res * res, Sc)[r, i + 1] = 0.1
+    for r in rays[120:150]:  # far moves: the general selection
+        jit.reshape(res * res, Sc)[r, rng.integers(0, Sc)] = 3.7
+        jit.reshape(res * res, Sc)[r, rng.integers(0, Sc)] = -2.2
+    ref = oracle.render(planes, o.numpy(), d.numpy(), jit, u, oracle.prescale_mlp(*raw), oracle.make_opts(ro, **kw))
+    mlp = hip_mlp(hip, raw, 1.0)
+    nhwc = hip.ops.planes_to_nhwc(dev(planes))
+    for flags in (dict(), dict(early_out=False)):
+        out = hip.ops.render(nhwc, o.cuda(), d.cuda(), dev(jit), dev(u), mlp,
+                             hip.ops.make_opts(ro, small_launch_kernel=False, **flags, **kw), ray_tile_w=res)
+        for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
+            assert np.array_equal(a.cpu().numpy(), b), (nm, flags)
+    fast = hip.ops.render(nhwc, o.cuda(), d.cuda(), dev(jit), dev(u), mlp,
+                          hip.ops.make_opts(ro, small_launch_kernel=False, fast_color=True, **kw), ray_tile_w=res)
+    for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), fast, ref):
+        assert float(np.abs(a.cpu().numpy() - b).max()) <= FAST_MAX[nm], nm
