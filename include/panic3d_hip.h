@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 5  /* 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
+#define P3D_ABI_VERSION 6  /* 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -254,11 +254,25 @@ typedef struct p3d_conv_args {
     float* y;                  /* [N][O][H*up][W*up] */
     void* workspace;           /* p3d_modconv2d_workspace_bytes(N, I, O, H, W, up) */
     uint32_t* saturated;       /* see p3d_modconv2d_f16x2mma_f32, or null */
+    const void* x_img;         /* the input as an activation image (already modulated by its producer), or null: then x + styles */
+    void* y_img;               /* up = 2: the output as an activation image for the layer that follows (instead of y), or null */
+    const float* y_img_styles; /* with y_img: that layer's styles [N][O] */
     size_t workspace_bytes;
     int32_t N, I, H, W, O, ks, up, demodulate, noise_per_sample, act, mma;
     float alpha, gain, clamp;
 } p3d_conv_args;
 int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
+
+/* The activation IMAGE of the two-term convolution path (csrc/p3d_synthesis.hip, "activation IMAGE"): the operand of a plain 3x3
+ * layer prepared by the layer in front of it — 16-byte pieces of f16 hi parts and of lo parts of 16 * s[n][c] * x[n][c][y][x], laid out
+ * [hi | lo][N][C/8][H][W][8]: p3d_act_image_bytes(N, C, H, W) = N*C*H*W*4 bytes, 16-byte aligned, C % 8 == 0.  An up-sampling layer
+ * writes it from its FIR + bias_act pass when p3d_conv_args.y_img / y_img_styles (the NEXT layer's styles) are set and y is null; the
+ * next layer (3x3, up = 1, two-term operands, W >= 32, demod_coefs given) reads it through x_img (x and styles are then unused) with
+ * buffer_load ... lds alone.  The pieces are bit for bit what that layer computes itself from the fp32 tensor, so results do not
+ * change.  p3d_act_to_image_f32 builds one from an fp32 tensor (styles may be null = 1).  |16 s x| > 65504: clamped,
+ * *saturated |= 1, as in p3d_modconv2d_f16x2mma_f32. */
+size_t p3d_act_image_bytes(int N, int C, int H, int W);
+int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int H, int W, void* img, uint32_t* saturated, void* stream);
 
 /* ToRGBLayer.forward (networks_stylegan2.py:366-380: 1x1 modulated convolution without demodulation + bias [+ clamp]) fused with
  * the skip connection of SynthesisBlock.forward (:476-478: img = upsample2d(img) + y) — ONE launch that reads the activation

@@ -11,7 +11,7 @@ SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D
 P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP, P3D_FLAG_NO_STAGING, P3D_FLAG_FORCE_STAGING = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192
 P3D_FLAG_DISPARITY = 4096
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 5  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 6  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -39,7 +39,7 @@ class PasteArgs(C.Structure):
 class ConvArgs(C.Structure):
     """p3d_conv_args"""
     _fields_ = [(n, C.c_void_p) for n in ("x", "w", "w_f16", "styles", "demod_coefs", "noise", "bias", "fir", "y", "workspace",
-                                          "saturated")] + [("workspace_bytes", C.c_size_t)] + \
+                                          "saturated", "x_img", "y_img", "y_img_styles")] + [("workspace_bytes", C.c_size_t)] + \
                [(n, C.c_int32) for n in ("N", "I", "H", "W", "O", "ks", "up", "demodulate", "noise_per_sample", "act", "mma")] + \
                [(n, C.c_float) for n in ("alpha", "gain", "clamp")]
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P]),
     "p3d_modconv2d_ex_f32": (_I, [C.POINTER(ConvArgs), _P]),
+    "p3d_act_image_bytes": (_Z, [_I, _I, _I, _I]),
+    "p3d_act_to_image_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "p3d_torgb_weights_f32": (_I, [_P, _I, _I, _P, _P]),
     "p3d_torgb_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -1799,7 +1799,8 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     if (nwaves == P3D_RENDER_WAVES) {
         // large launch: the workgroup shape (4, 2 or 1 waves, as many workgroups as fit) that puts most waves on a CU, at
         // most 8 (two per SIMD: the register cap); ties go to the LARGER workgroup.  48+48: 2 x 4 waves; 64+64: 3 x 2 instead of
-        // 1 x 4 (measured 6.85 -> 6.53 ms at 512^2); 96+96 stays 1 x 4 (measured: 2 x 2 waves 13.3 ms, 1 x 5 12.6, 1 x 4 11.2)
+        // 1 x 4 (measured 6.85 -> 6.53 ms at 512^2); 96+96: 2 x 4 with the production kernel (no coarse-depth rows: P3D_TCG), 1 x 4
+        // with the LDS-resident instantiations (measured there: 2 x 2 waves 13.3 ms, 1 x 5 12.6, 1 x 4 11.2)
         int best = 0, best_waves = 0;
         for (int w = 4; w >= 1; w >>= 1) {
             const size_t per_wg = lds_fixed + w * lds_wave;

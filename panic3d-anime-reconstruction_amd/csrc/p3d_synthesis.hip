@@ -56,6 +56,9 @@ struct ConvParams {
     int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
     int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
     unsigned int* sat;    // caller-owned device word, OR-ed with 1 when a two-term operand left its domain (or null: not reported)
+    // ---- the activation IMAGE path (the producer prepares the consumer's operand; see "activation IMAGE" below)
+    const void* ximg;     // input as an image [hi | lo][N][I/8][H][W] of 16-byte pieces, or null (then x + styles are used)
+    long long ximg_lo;    // byte offset of the lo half of ximg (= N*I*H*W*2)
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
@@ -674,6 +677,38 @@ DEV void conv_glds_wh(const ConvParams& p, const ConvStagePlanW& pl, char* ws, i
     }
 }
 
+// =====================================================================================================================
+// The activation IMAGE (round 3).  Between an up-sampling layer (conv0) and the plain 3x3 layer that follows it
+// (conv1) the activation travels as what the two-term MFMA kernel consumes: per (sample, group of 8 channels, pixel) one 16-byte
+// piece of f16 hi parts and one of lo parts of 16 * s[n][c] * x — the CONSUMER's modulation, applied by the producer
+// (k_fir4x4_img: the FIR + bias_act pass that ends conv0) — laid out [hi | lo][N][C/8][H][W][8], 4 bytes per value like the
+// fp32 tensor it replaces.  The values are exactly the ones k_modconv_w2 computes when it stages an fp32 tensor (the same
+// multiply, scale, clamp, split), so results are bit-identical; what goes away is the work: the consumer stages a K chunk's patch
+// with buffer_load ... lds only (the patch's LDS order (k half, row, column) IS ascending item order, so every wave writes 64
+// consecutive pieces; padding / channel tail arrive as zeros through the buffer's range check): no staging registers, no
+// conversion VALU, and the O/64 channel-tile workgroups no longer each repeat the fp32 -> hi/lo split of the same patch.
+// Measured (profiles/r03_notes.txt): k_modconv_w2 -4 % .. -16 % per layer, the image-writing FIR pass +2 .. +5 us.
+// Variants built on the way and dropped: an UNMODULATED image for every consumer (3x3, transposed 3x3, ToRGB) with the modulation
+// on per-sample weights — the weight preparation (30 us per backbone pass, x N) and the slower ToRGB ate the convolutions' gain.
+// =====================================================================================================================
+DEV void conv_glds_ximg(const ConvParams& p, char* xs_hi, char* xs_lo, const int (&xoff)[WX_ROUNDS], int tid, int n, int ic0, int ic_end) {
+    const int HW = p.H * p.W;
+    const int left = ic_end > ic0 ? ic_end - ic0 : 0;
+    const char* base = (const char*)p.ximg + ((size_t)n * (p.I >> 3) + (ic0 >> 3)) * HW * 16;
+    auto rh = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (left >> 3) * HW * 16, CONV_RSRC_FLAGS);
+    auto rl = __builtin_amdgcn_make_buffer_rsrc((void*)(base + p.ximg_lo), 0, (left >> 3) * HW * 16, CONV_RSRC_FLAGS);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int u = 0; u < WX_ROUNDS; ++u) {
+        if (tid + u * 256 < WX_ITEMS) {
+            const int slot = ((tid & ~63) + u * 256) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr)(xs_hi + slot), 16, xoff[u], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr)(xs_lo + slot), 16, xoff[u], 0, 0, 0);
+        }
+    }
+}
+
+template <bool IMG>
 __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
     using T = ConvTaps<0>;
     constexpr int WBYTES = 9 * 128 * 16;
@@ -702,18 +737,34 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
     const int xlane = half * WX_HALF + ((prow + 1) * WX_ROW + pcol + 1) * 16;  // row b adds one row pitch
     const int wlane = (half * 64 + j) * 16;                                     // channel tile a adds 32 o
 
-    const ConvStagePlanW pl = conv_plan_w(p, tid, gy0, gx0, o0);
+    ConvStagePlanW pl = conv_plan_w(p, tid, gy0, gx0, o0);
+    if constexpr (IMG) {  // piece offsets inside the chunk-relative image slice
+#pragma unroll
+        for (int u = 0; u < WX_ROUNDS; ++u) {
+            const int it = tid + u * 256;
+            const int h = it / ((CONV_TH + 2) * WX_ROW), px = it - h * ((CONV_TH + 2) * WX_ROW);
+            const int r = px / WX_ROW, c = px - r * WX_ROW;
+            const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+            const bool ok = it < WX_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            pl.xoff[u] = ok ? ((h * p.H + iy) * p.W + ix) * 16 : CONV_OOB;
+        }
+    }
     ConvStageRegsW rg;
-    conv_gload_w(p, pl, xn, sn, ic_beg, ic_end, rg);
+    if constexpr (IMG) conv_glds_ximg(p, xs[0][0], xs[1][0], pl.xoff, tid, n, ic_beg, ic_end);
+    else conv_gload_w(p, pl, xn, sn, ic_beg, ic_end, rg);
     conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 0);
     conv_glds_wh(p, pl, ws, tid, ic_beg, ic_end, 1);
-    conv_lstore_w(xs[0][0], pl, rg, p.sat);
+    if constexpr (!IMG) conv_lstore_w(xs[0][0], pl, rg, p.sat);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     int buf = 0;
     for (int ic0 = ic_beg; ic0 < ic_end; ic0 += 16) {
         const bool more = ic0 + 16 < ic_end;
-        if (more) conv_gload_w(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        if constexpr (IMG) {
+            if (more) conv_glds_ximg(p, xs[0][buf ^ 1], xs[1][buf ^ 1], pl.xoff, tid, n, ic0 + 16, ic_end);  // lands under this chunk's MFMAs
+        } else {
+            if (more) conv_gload_w(p, pl, xn, sn, ic0 + 16, ic_end, rg);
+        }
         const char* xh = xs[0][buf] + xlane;
         const char* xl = xs[1][buf] + xlane;
         const char* wb = ws + wlane;
@@ -738,7 +789,9 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) conv_lstore_w(xs[0][buf ^ 1], pl, rg, p.sat);   // (waits for this chunk's a_lo too: it was requested before phase 1)
+        if constexpr (!IMG) {
+            if (more) conv_lstore_w(xs[0][buf ^ 1], pl, rg, p.sat);   // (waits for this chunk's a_lo too: it was requested before phase 1)
+        }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();                                    // a_hi is free, a_lo has landed everywhere
         if (more) conv_glds_wh(p, pl, ws, tid, ic0 + 16, ic_end, 0);
@@ -1120,6 +1173,30 @@ __global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int 
     if (split) wh[total + idx] = (_Float16)(v - (float)hi);
 }
 
+// fp32 activation [N][C][H][W] -> image for a consumer with styles s [N][C] (null: 1): split(16 * s * x); C % 8 == 0.  One thread
+// per piece.  (Tests, and callers whose producer is not one of ours.)
+__global__ void k_act_to_image(const float* __restrict__ x, const float* __restrict__ s, int N, int C, int HW, char* __restrict__ img,
+                               long long lo_off, unsigned int* sat) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)N * (C >> 3) * HW;
+    if (idx >= total) return;
+    const long long g = idx / HW;  // (n, c8)
+    const int pix = (int)(idx - g * HW);
+    const float* xp = x + g * 8 * HW + pix;
+    f16x8 v, l;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float m = (s ? s[g * 8 + i] : 1.0f) * xp[(size_t)i * HW] * HX_SPLIT_SCALE_X;
+        bad = bad || !(__builtin_fabsf(m) <= 65504.0f);
+        m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+        v[i] = (_Float16)m;
+        l[i] = (_Float16)(m - (float)v[i]);
+    }
+    *reinterpret_cast<f16x8*>(img + idx * 16) = v;
+    *reinterpret_cast<f16x8*>(img + lo_off + idx * 16) = l;
+    if (bad && sat) atomicOr(sat, 1u);
+}
+
 // sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
 struct ReduceParams {
     const float* part; float* y; const float* dcoef; const float* noise; const float* bias;
@@ -1205,6 +1282,7 @@ struct FirParams {
     int C, H, W, OH, OW, fh, fw, up, down, padx0, pady0;
     int noise_per_sample, act, epilogue;
     float alpha, gain, clamp;
+    const float* nstyles; // k_fir4x4_img: the consuming layer's styles [N][C] (the image holds split(16 * s * y))
     int ksplit;           // k_fir4x4_tiled: x holds ksplit split-K partial tensors, `slice` elements apart, summed in slice order
     long long slice;      // while the tile is loaded (shallow splits only: see modconv_impl); 1 / 0 otherwise
 };
@@ -1380,6 +1458,134 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
     }
 }
 
+// k_fir4x4_tiled writing an activation IMAGE for the layer that follows (FirParams::nstyles): a workgroup = a 32 x 32 output tile of EIGHT consecutive channels (blockIdx.y = (n, c8)),
+// in two halves of four channels through one LDS image (pitch 40: 22 KB, seven workgroups per CU): the second half's loads are in
+// flight while the first is filtered.  A thread's 4 pixels x 8 channels leave as 4 pieces of hi parts + 4 of lo parts, 512
+// contiguous bytes per 8 threads.  Always applies the epilogue.  (Measured at 512^2 x 128 channels, whole up-convolution: channel
+// by channel through two buffers 381 us, all eight tiles resident (45 KB, 3 workgroups per CU) 342 us, fp32 output 303 us.)
+#define FIRI_PITCH 40
+__global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restrict__ yimg, long long lo_off, unsigned int* sat) {
+    __shared__ __attribute__((aligned(16))) float tile[4][35 * FIRI_PITCH];
+    __shared__ float fs[16];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.OW + 31) / 32;
+    const int X0 = (blockIdx.x % tiles_x) * 32, Y0 = (blockIdx.x / tiles_x) * 32;
+    const long long g = blockIdx.y;  // (n, c8)
+    const long long n = g / (p.C >> 3);
+    const int c0 = (int)(g - n * (p.C >> 3)) * 8;
+    if (tid < 16) fs[tid] = p.f[tid];
+    const int r0 = tid / 36, c = tid - r0 * 36;
+    const int vcol = X0 + c - p.padx0;
+    const bool cv = tid < 252 && vcol >= 0 && vcol < p.W;
+    const float* xg = p.x + (n * p.C + c0) * (long long)p.H * p.W;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 8 * p.H * p.W * 4, CONV_RSRC_FLAGS);
+    int off[5];
+#pragma unroll
+    for (int ps = 0; ps < 5; ++ps) {
+        const int u = Y0 + ps * 7 + r0 - p.pady0;
+        off[ps] = (cv && u >= 0 && u < p.H) ? (u * p.W + vcol) * 4 : CONV_OOB;
+    }
+    auto fetch = [&](int half, float (&val)[4][5]) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int ps = 0; ps < 5; ++ps)
+                val[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[ps], (half * 4 + ch) * p.H * p.W * 4, 0));
+        for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce); 20 independent loads per slice
+            auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * p.H * p.W * 4, CONV_RSRC_FLAGS);
+            float t[4][5];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int ps = 0; ps < 5; ++ps)
+                    t[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[ps], (half * 4 + ch) * p.H * p.W * 4, 0));
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int ps = 0; ps < 5; ++ps) val[ch][ps] += t[ch][ps];
+        }
+    };
+    auto put = [&](const float (&val)[4][5]) {
+        if (tid < 252) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int ps = 0; ps < 5; ++ps) tile[ch][(ps * 7 + r0) * FIRI_PITCH + c] = val[ch][ps];
+        }
+    };
+    const int lx = (tid & 7) * 4, ly = tid >> 3;
+    const int Y = Y0 + ly, Xb = X0 + lx;
+    float out[8][4];
+    auto filter = [&](int half) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float win[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&tile[ch][(ly + r) * FIRI_PITCH + lx]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&tile[ch][(ly + r) * FIRI_PITCH + lx + 4]);
+                win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
+                win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+                    for (int fx = 0; fx < 4; ++fx) acc = __builtin_fmaf(fs[fy * 4 + fx], win[fy][j + fx], acc);
+                out[half * 4 + ch][j] = acc;
+            }
+        }
+    };
+    float va[4][5], vb[4][5];
+    fetch(0, va);
+    fetch(1, vb);
+    put(va);
+    __syncthreads();
+    filter(0);
+    __syncthreads();
+    put(vb);
+    __syncthreads();
+    filter(1);
+    if (Y >= p.OH || Xb >= p.OW) return;
+    float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.noise) {
+        const float* nz = p.noise + (p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + Xb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nv[j] = (Xb + j < p.OW) ? nz[j] : 0.0f;
+    }
+    float dco[8], bs[8], ns[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        dco[ch] = p.dcoef ? p.dcoef[n * p.C + c0 + ch] : 1.0f;
+        bs[ch] = p.bias ? p.bias[c0 + ch] : 0.0f;
+        ns[ch] = p.nstyles[n * p.C + c0 + ch];
+    }
+    bool bad = false;
+    const size_t piece0 = ((size_t)g * p.OH + Y) * p.OW + Xb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f16x8 hv, lv;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            float a = out[ch][j] * dco[ch];
+            if (p.noise) a = a + nv[j];
+            a = a + bs[ch];
+            a = ns[ch] * act_apply(a, p.act, p.alpha, p.gain, p.clamp) * HX_SPLIT_SCALE_X;  // = conv_lstore_w's s * x * 16, bit for bit
+            bad = bad || !(__builtin_fabsf(a) <= 65504.0f);
+            a = __builtin_fminf(__builtin_fmaxf(a, -65504.0f), 65504.0f);
+            hv[ch] = (_Float16)a;
+            lv[ch] = (_Float16)(a - (float)hv[ch]);
+        }
+        if (Xb + j < p.OW) {
+            *reinterpret_cast<f16x8*>(yimg + (piece0 + j) * 16) = hv;
+            *reinterpret_cast<f16x8*>(yimg + lo_off + (piece0 + j) * 16) = lv;
+        }
+    }
+    if (bad && sat) atomicOr(sat, 1u);
+}
+
 // x viewed as [outer][C][inner]
 __global__ void k_bias_act(const float* __restrict__ x, const float* __restrict__ b, long long total, int C, long long inner,
                            int act, float alpha, float gain, float clamp, float* __restrict__ y) {
@@ -1402,7 +1608,8 @@ static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
     if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
         dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        hipLaunchKernelGGL(k_modconv_w2, gw, dim3(256), 0, st, p);
+        if (p.ximg) hipLaunchKernelGGL(k_modconv_w2<true>, gw, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_modconv_w2<false>, gw, dim3(256), 0, st, p);
         return;
     }
     if (p.wh && p.wsplit) hipLaunchKernelGGL((k_modconv_h<MODE, true>), grid, dim3(256), 0, st, p);
@@ -1441,8 +1648,17 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
 static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int wsplit, int O, int ks,
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
-                        size_t workspace_bytes, void* stream, unsigned int* sat = nullptr) {
-    if (!x || !w || !styles || !y || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+                        size_t workspace_bytes, void* stream, unsigned int* sat = nullptr, const void* ximg = nullptr,
+                        void* yimg = nullptr, const float* ystyles = nullptr) {
+    if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg) || (y && yimg) || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if (ximg) {  // an image input (already modulated by its producer): the wide two-term kernel; demodulation must be precomputed
+        if (!wh || !wsplit || (demodulate && !dcoef_in)) return P3D_E_ARG;
+        if (ks != 3 || up != 1 || I % 16 != 0 || W < WX_TW || ((uintptr_t)ximg & 15)) return P3D_E_RANGE;
+    }
+    if (yimg) {      // an image output: written by the FIR pass of an up-sampling layer, for a consumer with styles ystyles [N][O]
+        if (!ystyles) return P3D_E_ARG;
+        if (up != 2 || O % 8 != 0 || ((uintptr_t)yimg & 15)) return P3D_E_RANGE;
+    }
     // 32-bit byte offsets inside one image / the weight tensor (raw buffer addressing)
     if ((long long)I * H * W * 4 >= (1ll << 31) || (long long)O * I * ks * ks * 4 >= (1ll << 31)) return P3D_E_RANGE;
     if (!((ks == 3 && (up == 1 || up == 2)) || (ks == 1 && up == 1))) return P3D_E_RANGE;
@@ -1465,6 +1681,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
+    p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
     float* conv_dst = (ksplit > 1) ? part : (up == 2 ? tmp : y);
     p.y = conv_dst;
@@ -1499,9 +1716,12 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
     q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
     q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
-    q.alpha = alpha; q.gain = gain; q.clamp = clamp;
+    q.alpha = alpha; q.gain = gain; q.clamp = clamp; q.nstyles = ystyles;
     dim3 grid(((q.OW + 31) / 32) * ((q.OH + 31) / 32), (unsigned)q.NC);
-    hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
+    if (yimg) {
+        dim3 gi(grid.x, (unsigned)(q.NC / 8));
+        hipLaunchKernelGGL(k_fir4x4_img, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
+    } else hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
     return chk();
 }
 
@@ -1557,9 +1777,21 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* a, void* stream) {
         if (a->I % 16 != 0 || ((uintptr_t)a->w_f16 & 15) || (wsplit && ((size_t)a->O * a->I * a->ks * a->ks * 2) % 16 != 0)) return P3D_E_RANGE;
         wh = a->w_f16;
     }
+    if (a->x_img && !wsplit) return P3D_E_RANGE;
     return modconv_impl(a->x, a->N, a->I, a->H, a->W, a->w, wh, wsplit, a->O, a->ks, a->styles, a->demodulate, a->demod_coefs, a->noise,
                         a->noise_per_sample, a->bias, a->up, a->act, a->alpha, a->gain, a->clamp, a->fir, a->y, a->workspace, a->workspace_bytes,
-                        stream, wsplit ? (unsigned int*)a->saturated : nullptr);
+                        stream, (wsplit || a->y_img) ? (unsigned int*)a->saturated : nullptr, a->x_img, a->y_img, a->y_img_styles);
+}
+
+size_t p3d_act_image_bytes(int N, int C, int H, int W) { return (size_t)N * C * H * W * 4; }
+
+int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int H, int W, void* img, uint32_t* saturated, void* stream) {
+    if (!x || !img || N <= 0 || C <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
+    if (C % 8 != 0 || ((uintptr_t)img & 15)) return P3D_E_RANGE;
+    const long long total = (long long)N * (C / 8) * H * W;
+    hipLaunchKernelGGL(k_act_to_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, styles, N, C, H * W,
+                       (char*)img, (long long)N * C * H * W * 2, (unsigned int*)saturated);
+    return chk();
 }
 
 int p3d_modconv2d_f16x2mma_f32(const float* x, int N, int I, int H, int W, const float* w, const void* w_f16x2, int O, int ks,
@@ -1619,7 +1851,7 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
     q.OW = (W * up + padx0 + padx1 - fw) / down + 1;
     if (q.OH <= 0 || q.OW <= 0) return P3D_E_RANGE;
     q.fh = fh; q.fw = fw; q.up = up; q.down = down; q.padx0 = padx0; q.pady0 = pady0;
-    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1; q.ksplit = 1; q.slice = 0;
+    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1; q.ksplit = 1; q.slice = 0; q.nstyles = nullptr;
     long long total = q.NC * q.OH * q.OW;
     hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
     return chk();

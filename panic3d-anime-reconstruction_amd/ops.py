@@ -635,20 +635,72 @@ def _conv_scratch(device, nbytes):
     return ws
 
 
+class ActImage:
+    """The operand of a plain 3x3 two-term layer prepared by the layer in front of it (include/panic3d_hip.h, "activation IMAGE"):
+    data = float16 [2 (hi | lo), N, C/8, H, W, 8] holding split(16 * styles * x) for the CONSUMER's styles.  Produced by an
+    up-sampling modulated_conv2d called with next_styles=... (or act_to_image); consumed by modulated_conv2d in place of x."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @staticmethod
+    def empty(N, C, H, W, device):
+        if C % 8:
+            raise RuntimeError("ActImage: C % 8 != 0")
+        return ActImage(torch.empty((2, N, C // 8, H, W, 8), dtype=torch.float16, device=device), (N, C, H, W))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def float(self):
+        """(hi + lo) / 16 as fp32 [N,C,H,W]: the MODULATED activation styles * x (tests)."""
+        N, C, H, W = self.shape
+        v = (self.data[0].float() + self.data[1].float()) * (1.0 / 16.0)
+        return v.permute(0, 1, 4, 2, 3).reshape(N, C, H, W).contiguous()
+
+
+def act_to_image(x, styles=None, saturated=None):
+    """p3d_act_to_image_f32: fp32 [N,C,H,W] (* styles [N,C]) -> ActImage."""
+    x = _chk(x, "x")
+    N, C, H, W = x.shape
+    if styles is not None:
+        styles = _chk(styles, "styles")
+        if tuple(styles.shape) != (N, C):
+            raise RuntimeError("act_to_image: styles [N,C]")
+    img = ActImage.empty(N, C, H, W, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().p3d_act_to_image_f32(_p(x), _p(styles), N, C, H, W, _p(img.data), _p(saturated), _stream()), "p3d_act_to_image_f32")
+    return img
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
-                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None):
+                     bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None,
+                     next_styles=None):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
     noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
     weight_f16 (from conv_weights_to_f16): run the matrix cores on f16 operands (fp32 accumulate, fp32 in/out) — what the
     reference's fp16 super-resolution blocks do on the GPU, with less rounding; needs I % 16 == 0.  A [2,O,k*k,I] tensor
     (conv_weights_to_f16(split=True)) selects the two-term variant: fp32-class results on the f16 matrix cores; `saturated`: an
-    int32 [1] device tensor of the caller (conv_domain_flag) that the two-term kernels OR with 1 when |s*x| > 4094."""
-    x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
-    N, I, H, W = x.shape
+    int32 [1] device tensor of the caller (conv_domain_flag) that the two-term kernels OR with 1 when |s*x| > 4094.
+    x may be an ActImage (3x3, up 1, two-term weights, dcoef given: styles are already in it).  next_styles [N,O] (up 2 only):
+    return the result as the ActImage of a following layer with those styles instead of an fp32 tensor."""
+    ximg = x if isinstance(x, ActImage) else None
+    if ximg is not None:
+        if weight_f16 is None or weight_f16.ndim != 4 or (demodulate and dcoef is None):
+            raise RuntimeError("modulated_conv2d: an ActImage input needs two-term weights (conv_weights_to_f16(split=True)) and precomputed dcoef")
+        x = None
+        weight = _chk(weight, "weight")
+        N, I, H, W = ximg.shape
+    else:
+        x, weight, styles = _chk(x, "x"), _chk(weight, "weight"), _chk(styles, "styles")
+        N, I, H, W = x.shape
     O, I2, kh, kw = weight.shape
-    if I2 != I or tuple(styles.shape) != (N, I):
+    if I2 != I or (ximg is None and tuple(styles.shape) != (N, I)):
         raise RuntimeError("modulated_conv2d: x [N,I,H,W], weight [O,I,k,k], styles [N,I]")
+    dev_ = ximg.device if ximg is not None else x.device
     if not ((kh == kw == 3 and padding == 1 and up in (1, 2)) or (kh == kw == 1 and padding == 0 and up == 1)):
         raise NotImplementedError("modulated_conv2d: only 3x3/pad 1/up 1|2 and 1x1 are on the hot path")
     idx, da, dg = _ACTS[act]
@@ -662,7 +714,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
             raise RuntimeError("noise must be [H*up, W*up] or [N,1,H*up,W*up]")
     fir = None
     if up == 2:
-        fir = prepared_filter(resample_filter, x.device, 4.0, False)  # upfirdn2d.py:193-196, gain = up^2
+        fir = prepared_filter(resample_filter, dev_, 4.0, False)  # upfirdn2d.py:193-196, gain = up^2
         if tuple(fir.shape) != (4, 4):
             raise NotImplementedError("resample_filter must be the 4x4 [1,3,3,1] filter")
     if bias is not None:
@@ -671,7 +723,13 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
         dcoef = _chk(dcoef, "dcoef")
         if dcoef.numel() != N * O:
             raise RuntimeError("dcoef must hold N*O demodulation coefficients")
-    y = torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=x.device)
+    out_image = next_styles is not None
+    if out_image:
+        next_styles = _chk(next_styles, "next_styles")
+        if up != 2 or tuple(next_styles.shape) != (N, O):
+            raise RuntimeError("next_styles [N,O] goes with an up-sampling layer")
+    y = None if out_image else torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=dev_)
+    yimg = ActImage.empty(N, O, H * up, W * up, dev_) if out_image else None
     L = _lib.lib()
     mma = _lib.P3D_CONV_MMA_F32
     if weight_f16 is not None:
@@ -680,16 +738,17 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
                 or (split and weight_f16.shape[0] != 2):
             raise RuntimeError("weight_f16 must be the contiguous [O,k*k,I] / [2,O,k*k,I] float16 tensor of conv_weights_to_f16")
         mma = _lib.P3D_CONV_MMA_F16X2 if split else _lib.P3D_CONV_MMA_F16
-        if split and saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != x.device):
+        if split and saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != dev_):
             raise RuntimeError("saturated must be an int32 [1] tensor on x's device (ops.conv_domain_flag)")
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(dev_):
         wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
-        ws = _conv_scratch(x.device, wsb)
-        a = _lib.ConvArgs(x.data_ptr(), weight.data_ptr(), weight_f16.data_ptr() if weight_f16 is not None else None,
-                          styles.data_ptr(), dcoef.data_ptr() if dcoef is not None else None,
+        ws = _conv_scratch(dev_, wsb)
+        a = _lib.ConvArgs(x.data_ptr() if x is not None else None, weight.data_ptr(), weight_f16.data_ptr() if weight_f16 is not None else None,
+                          styles.data_ptr() if styles is not None else None, dcoef.data_ptr() if dcoef is not None else None,
                           noise.data_ptr() if noise is not None else None, bias.data_ptr() if bias is not None else None,
-                          fir.data_ptr() if fir is not None else None, y.data_ptr(), ws.data_ptr(),
-                          saturated.data_ptr() if (saturated is not None and mma == _lib.P3D_CONV_MMA_F16X2) else None,
-                          ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv)
+                          fir.data_ptr() if fir is not None else None, y.data_ptr() if y is not None else None, ws.data_ptr(),
+                          saturated.data_ptr() if (saturated is not None and (mma == _lib.P3D_CONV_MMA_F16X2 or yimg is not None)) else None,
+                          ximg.data.data_ptr() if ximg is not None else None, yimg.data.data_ptr() if yimg is not None else None,
+                          next_styles.data_ptr() if yimg is not None else None, ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv)
         _lib.check(L.p3d_modconv2d_ex_f32(C.byref(a), _stream()), "p3d_modconv2d_ex_f32")
-    return y
+    return yimg if out_image else y

@@ -117,6 +117,22 @@ DEFAULT_CONV_MMA = os.environ.get("P3D_CONV_MMA", "x2")
 DEFAULT_CONV_MMA_1X1 = os.environ.get("P3D_CONV_MMA_1X1", "f32")  # the 1x1 ToRGB layers (A/B knob, measured in round 3)
 
 
+# The activation IMAGE (ops.ActImage; csrc/p3d_synthesis.hip "activation IMAGE"): in a block whose map is >= IMG_MIN_RES^2, conv0's
+# last pass writes conv1's two-term operand directly (conv1's styles applied, hi / lo split done) instead of an fp32 tensor that
+# conv1 would modulate and split again in each of its channel-tile workgroups.  Bit-identical results; P3D_CONV_IMG=0 for A/B runs.
+CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
+IMG_MIN_RES = 32
+
+
+def _takes_image(layer, res):
+    """A plain 3x3 layer that can stage its input from an activation image: two-term operands, 16-channel K chunks, a map of at
+    least IMG_MIN_RES columns (the wide-tile kernel)."""
+    mode = getattr(layer, "mma_f16", None)
+    if mode is None:
+        mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
+    return CONV_IMG and mode == "x2" and layer.up == 1 and layer.weight.shape[-1] == 3 and layer.in_channels % 16 == 0 and res >= IMG_MIN_RES
+
+
 def _f16_operand(layer):
     """The cached f16 operand copy of layer.weight when the layer runs on f16 MFMA operands, else None.  `layer.mma_f16`:
     False = fp32 operands, True = one f16 term ([O,k*k,I]; TriPlaneGenerator.set_sr_mma_f16), "x2" = two-term operands
@@ -158,8 +174,10 @@ class SynthesisLayer(_CacheFree):
             self._noise_cache = hit
         return hit[1]
 
-    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None):
-        """pre: (styles [N,I], demodulation coefficients [N,O]) already computed by a StylePlan for this layer, or None."""
+    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None, next_styles=None):
+        """pre: (styles [N,I], demodulation coefficients [N,O]) already computed by a StylePlan for this layer, or None.
+        x: fp32 [N,I,H,W], or the ops.ActImage the previous layer prepared for this one (its styles are in it).
+        next_styles (up-sampling layers): return the ops.ActImage of the following layer, whose styles these are."""
         assert noise_mode in ["random", "const", "none"]
         styles, dcoef = pre if pre is not None else (self.affine(w), None)
         noise = None
@@ -171,7 +189,7 @@ class SynthesisLayer(_CacheFree):
         return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
                                     act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None),
-                                    dcoef=dcoef)
+                                    dcoef=dcoef, next_styles=next_styles)
 
 
 class ToRGBLayer(_CacheFree):
@@ -332,8 +350,12 @@ class SynthesisBlock(torch.nn.Module):
             x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
             x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
         else:
-            x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), **layer_kwargs)
-            x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
+            # conv0 hands conv1 its operand (activation image) when conv1 can stage from one and its styles / demodulation
+            # coefficients are known up front (a StylePlan)
+            p1 = pre.get("conv1")
+            img_ok = p1 is not None and p1[1] is not None and _takes_image(self.conv1, self.resolution) and self.conv1.in_channels % 8 == 0
+            x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), next_styles=p1[0] if img_ok else None, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), pre=p1, **layer_kwargs)
         # y = torgb(x); img = upsample2d(img, resample_filter); img = img.add_(y)  (networks_stylegan2.py:476-478): one launch
         img = self.torgb(x, next(w_iter), pre=pre.get("torgb"), skip=None if img is None else img.to(torch.float32),
                          skip_filter=self.resample_filter)

@@ -595,3 +595,65 @@ def test_torgb_gemm_kernel_vs_the_three_launch_form(hip, N, I, O, H):
         else:
             assert float((new_noskip - y_old).abs().max()) < 3e-6 * np.sqrt(I) * scale and float((new - old).abs().max()) < 3e-6 * np.sqrt(I) * scale
         assert torch.equal(new - 0, ops.torgb(x, wt, O, s, bias=b, clamp=clamp, skip=prev, skip_filter=filt))  # deterministic
+
+
+@pytest.mark.parametrize("N,I,O,H", [(1, 256, 128, 128), (2, 512, 512, 16), (1, 32, 256, 64), (3, 64, 48, 32), (1, 128, 64, 20), (1, 64, 32, 8)])
+def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O, H):
+    """Round 3: an up-sampling layer called with next_styles writes the following layer's two-term operand
+    (ops.ActImage: split(16 * s1 * y), the pieces k_modconv_w2 would build itself) from its FIR pass instead of the fp32 tensor.
+    conv1 on the image must equal conv1 on the fp32 tensor BIT FOR BIT — all split-K depths of conv0 (FIR sums / separate reduce),
+    batch > 1, clamp, per-sample noise, a map that is not a multiple of the tile (40^2), channel counts with a tail in the 64-wide
+    output tile (O = 48) — and the image itself must be what act_to_image makes of the fp32 result.  Also: the generator's blocks
+    really take this path (P3D_CONV_IMG default), and the domain flag trips through the image writer."""
+    ops = hip.ops
+    g = torch.Generator().manual_seed(N * 7 + I + O + H)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    filt = ops.setup_filter([1, 3, 3, 1]).cuda()
+    x, w0, w1 = rn(N, I, H, H), rn(O, I, 3, 3), rn(O, O, 3, 3)
+    s0, s1 = rn(N, I) * 0.4 + 1.0, rn(N, O) * 0.4 + 1.0
+    d0 = ((w0[None] * s0[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    d1 = ((w1[None] * s1[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    wf0 = ops.conv_weights_to_f16(w0, split=True) if I % 16 == 0 else None
+    wf1 = ops.conv_weights_to_f16(w1, split=True)
+    for clamp, per_sample_noise in ((None, False), (1.5, True)):
+        nz0 = rn(N, 1, 2 * H, 2 * H) * 0.1 if (per_sample_noise and N > 1) else rn(2 * H, 2 * H) * 0.1
+        k0 = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz0, weight_f16=wf0, clamp=clamp)
+        k1 = dict(up=1, padding=1, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d1, noise=rn(2 * H, 2 * H) * 0.1, weight_f16=wf1)
+        mid = ops.modulated_conv2d(x, w0, s0, **k0)
+        img = ops.modulated_conv2d(x, w0, s0, next_styles=s1, **k0)
+        assert isinstance(img, ops.ActImage) and img.shape == (N, O, 2 * H, 2 * H)
+        assert torch.equal(img.data, ops.act_to_image(mid, s1).data)
+        if 2 * H >= 32:
+            assert torch.equal(ops.modulated_conv2d(img, w1, None, **k1), ops.modulated_conv2d(mid, w1, s1, **k1))
+        else:
+            with pytest.raises(RuntimeError):  # maps narrower than the wide tile do not stage from images
+                ops.modulated_conv2d(img, w1, None, **k1)
+    flag = ops.conv_domain_flag(x.device)
+    ops.modulated_conv2d(x * 3e4, w0, s0, next_styles=s1, saturated=flag, **k0)
+    assert ops.conv_domain_violated(flag)
+    with pytest.raises(RuntimeError):  # next_styles is for up-sampling layers
+        ops.modulated_conv2d(mid, w1, s1, next_styles=s1, **k1)
+
+
+def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
+    """SynthesisBlock hands conv1 an ops.ActImage from res 32 on (StylePlan styles), and the planes do not change by a bit when
+    the path is switched off."""
+    sg = hip.stylegan2
+    torch.manual_seed(5)
+    net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="none", channel_base=8192, channel_max=128, num_fp16_res=0).cuda()
+    ws = torch.randn(2, net.num_ws, 512, device="cuda")
+    seen = []
+    orig = hip.ops.modulated_conv2d
+
+    def spy(x, *a, **k):
+        seen.append(isinstance(x, hip.ops.ActImage))
+        return orig(x, *a, **k)
+
+    monkeypatch.setattr(hip.ops, "modulated_conv2d", spy)
+    with torch.no_grad():
+        a = net(ws, {}, noise_mode="const")
+        assert sum(seen) == 2  # conv1 of b32 and b64
+        monkeypatch.setattr(sg, "CONV_IMG", False)
+        seen.clear()
+        b = net(ws, {}, noise_mode="const")
+    assert sum(seen) == 0 and torch.equal(a, b)
