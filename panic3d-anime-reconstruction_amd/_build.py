@@ -35,15 +35,16 @@ def source_hash():
 
 
 def built_hash(so=SO):
-    """The source hash a library was compiled from (embedded by build() as -DP3D_SRC_HASH, returned by p3d_build_info), or None."""
-    import ctypes
+    """The source hash a library was compiled from (embedded by build() as -DP3D_SRC_HASH in p3d_build_info's string), or None.
+    Read from the FILE, not through dlopen: a library loaded here to ask it would stay mapped under its path, and the dlopen that
+    follows a rebuild in the same process would get that stale image back (the loader matches loaded objects by name first)."""
+    import re
     try:
-        L = ctypes.CDLL(so)
-        L.p3d_build_info.restype = ctypes.c_char_p
-        info = L.p3d_build_info().decode()
-    except (OSError, AttributeError):
+        with open(so, "rb") as f:
+            m = re.search(rb"libpanic3d_hip gfx950[^\0]{0,64}src=([0-9a-f]{16})", f.read())
+    except OSError:
         return None
-    return info.rsplit("src=", 1)[1].strip() if "src=" in info else None
+    return m.group(1).decode() if m else None
 
 
 def sources_present():
