@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/r03m
-timeout 600 python bench.py > gpurun_out/r03m/bench.json 2> gpurun_out/r03m/bench.err; echo "bench rc $?"
-timeout 600 python bench.py --fast > gpurun_out/r03m/bench_fast.json 2> gpurun_out/r03m/bench_fast.err; echo "bench fast rc $?"
-timeout 600 python bench.py --scene surface > gpurun_out/r03m/bench_surface.json 2> gpurun_out/r03m/bench_surface.err; echo "bench surface rc $?"
+for i in 1 2 3; do timeout 300 python tools/profile_f.py 2>/dev/null | tail -1; done
+timeout 300 python tools/generate_subject.py 2>/dev/null | tail -1
