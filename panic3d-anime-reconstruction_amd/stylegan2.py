@@ -18,7 +18,7 @@ from . import ops
 SQRT2 = float(np.sqrt(2))
 
 # derived tensors the modules keep as plain attributes (never part of the state_dict, dropped when pickled / deep-copied)
-_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan")
+_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan", "_cond_cache")
 
 
 class _CacheFree(torch.nn.Module):
@@ -388,45 +388,77 @@ class SynthesisNetwork(_CacheFree):
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
             setattr(self, f"b{res}", block)
 
-    # ---- PAniC-3D conditioning between blocks (networks_stylegan2.py:551-694): cheap element-wise glue on x / img
+    # ---- PAniC-3D conditioning between blocks (networks_stylegan2.py:551-694): element-wise glue on x / img.  What is added /
+    # multiplied / concatenated depends only on the conditioning images and the level — not on x — so it is prepared once per
+    # set of conditioning tensors (the 16 views of a subject share them: _util/eg3d_metrics3d.py / generate.py) and applied IN PLACE on
+    # the block's fresh output: one launch per level instead of seven (flip, scale, resize, repeat, add, two-part cat), which at
+    # batch 1 were ~40 launches the host could not issue as fast as the GPU ran them.  Same values: x[:, -k:] + t either way.
+    def _cond_prepared(self, key, tensors, make):
+        """make() cached under `key` for exactly these tensor OBJECTS at their current versions (strong references are kept, so
+        a hit can never be another tensor that reused an address)."""
+        cache = self.__dict__.setdefault("_cond_cache", {})
+        hit = cache.get(key)
+        if hit is not None and len(hit[0]) == len(tensors) and all(a is b and v == b._version for (a, v), b in zip(hit[0], tensors)):
+            return hit[1]
+        val = make()
+        cache[key] = ([(t, t._version) for t in tensors], val)
+        return val
+
     def _condition(self, lvl, res, x, img, cond, cm, chonkadd):
         if self.cond_mode == "none":
             return x, img
         if res == 8 and chonkadd > 0:  # resnet "chonk" added to the first channels of the 8x8 activations (:554-560)
             k = chonkadd
-            return torch.cat([x[:, :k] + cond["resnet_chonk"][:, :k], x[:, k:]], dim=1), img
+            x[:, :k].add_(cond["resnet_chonk"][:, :k])
+            return x, img
         interp = torch.nn.functional.interpolate
         if self.cond_mode.startswith("ortho_front."):
-            cimg = cond["image_ortho_front"].flip(dims=(-2,))
+            names = ["image_ortho_front"]
             if "gt_sides" in cm:
-                cimg = torch.cat([cimg, cond["image_ortho_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
-                                  cond["image_ortho_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
+                names += ["image_ortho_left", "image_ortho_right"]
             if "dorthoA" in cm:
-                cimg = torch.cat([cimg, cond["image_dorthoA_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
-                                  cond["image_dorthoA_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
-            cimg = cimg * 2 - 1
-            if "cond_img_norm_4" in cm:
-                cimg = 4 * cimg
+                names += ["image_dorthoA_left", "image_dorthoA_right"]
+            srcs = [cond[n] for n in names]
+
+            def make_cimg():
+                cimg = cond["image_ortho_front"].flip(dims=(-2,))
+                if "gt_sides" in cm:
+                    cimg = torch.cat([cimg, cond["image_ortho_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
+                                      cond["image_ortho_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
+                if "dorthoA" in cm:
+                    cimg = torch.cat([cimg, cond["image_dorthoA_left"].permute(0, 1, 3, 2).flip(dims=(-1, -2)),
+                                      cond["image_dorthoA_right"].permute(0, 1, 3, 2).flip(dims=(-1,))], dim=1)
+                cimg = cimg * 2 - 1
+                if "cond_img_norm_4" in cm:
+                    cimg = 4 * cimg
+                return cimg
+
+            def resized(tag, unshuffle=False):
+                """cimg at x's size, repeated to x.shape[1] / 4 channels ('add_4' / 'add_shuffle2_4'), prepared once"""
+                def make():
+                    cimg = self._cond_prepared("cimg", srcs, make_cimg)
+                    t = _pixel_unshuffle(cimg, cimg.shape[-1] // x.shape[-1]) if unshuffle else interp(cimg, size=x.shape[-2:], mode="bilinear")
+                    return t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1).contiguous()
+                return self._cond_prepared((tag, lvl, tuple(x.shape[1:]), unshuffle), srcs, make)
+
             if "add_4" in cm:
-                t = interp(cimg, size=x.shape[-2:], mode="bilinear")
-                t = t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1)
-                k = t.shape[1]
-                x = torch.cat([x[:, :-k], x[:, -k:] + t], dim=1)
+                t = resized("add_4")
+                x[:, -t.shape[1]:].add_(t)
             if "concatfront" in cm:
-                t = interp(cimg, size=x.shape[-2:], mode="bilinear")
-                x = torch.cat([x[:, :-t.shape[1]], t], dim=1)
+                t = self._cond_prepared(("concatfront", lvl, tuple(x.shape[2:])), srcs,
+                                        lambda: interp(self._cond_prepared("cimg", srcs, make_cimg), size=x.shape[-2:], mode="bilinear"))
+                x[:, -t.shape[1]:].copy_(t)
             if "add_shuffle2_4" in cm or "mult_shuffle2_4" in cm:
-                if lvl < len(self.block_resolutions) - 2:
-                    t = interp(cimg, size=x.shape[-2:], mode="bilinear")
+                t = resized("shuffle2_4", unshuffle=not (lvl < len(self.block_resolutions) - 2))
+                if "add_shuffle2_4" in cm:
+                    x[:, -t.shape[1]:].add_(t)
                 else:
-                    t = _pixel_unshuffle(cimg, cimg.shape[-1] // x.shape[-1])
-                t = t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1)
-                k = t.shape[1]
-                x = torch.cat([x[:, :-k], (x[:, -k:] + t) if "add_shuffle2_4" in cm else (x[:, -k:] * t)], dim=1)
+                    x[:, -t.shape[1]:].mul_(t)
             if "inj_6b_4" in cm and res == self.block_resolutions[-1]:
-                t = (cond["image_ortho_front"].flip(dims=(-2,)) * 2 - 1) * 4
-                t = interp(t, size=img.shape[-2:], mode="bilinear")
-                img = torch.cat([img[:, :t.shape[1]] + t, img[:, t.shape[1]:]], dim=1)
+                front = cond["image_ortho_front"]
+                t = self._cond_prepared(("inj_6b_4", tuple(img.shape[2:])), [front],
+                                        lambda: interp((front.flip(dims=(-2,)) * 2 - 1) * 4, size=img.shape[-2:], mode="bilinear"))
+                img[:, :t.shape[1]].add_(t)
         if "crossavg_4" in cm:
             k = int(x.shape[1] // 8)
             h, v = x[:, 0:k], x[:, k:2 * k]
