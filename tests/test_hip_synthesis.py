@@ -657,3 +657,31 @@ def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
         seen.clear()
         b = net(ws, {}, noise_mode="const")
     assert sum(seen) == 0 and torch.equal(a, b)
+
+
+def test_prepared_conditioning_follows_the_conditioning_tensors(hip):
+    """SynthesisNetwork prepares what each level adds from the conditioning images once per set of tensor OBJECTS (and versions) and
+    applies it in place.  A second call with the same tensors reuses it; other tensors of the same shape — also ones that could
+    reuse a freed address — and in-place edits of the same tensors must be noticed: every result equals a network that has never
+    seen another conditioning image."""
+    import copy
+    sg = hip.stylegan2
+    torch.manual_seed(11)
+    net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.reschonk_add_16",
+                              channel_base=4096, channel_max=64, num_fp16_res=0).cuda()
+    ws = torch.randn(1, net.num_ws, 512, device="cuda")
+    mk = lambda: {"image_ortho_front": torch.rand(1, 3, 64, 64, device="cuda"), "resnet_chonk": torch.randn(1, 16, 8, 8, device="cuda")}
+    fresh = lambda cond: copy.deepcopy(net)(ws, cond, noise_mode="const")
+    with torch.no_grad():
+        assert "_cond_cache" not in copy.deepcopy(net).__dict__ or not copy.deepcopy(net).__dict__["_cond_cache"]
+        a = mk()
+        y1 = net(ws, a, noise_mode="const")
+        assert net.__dict__["_cond_cache"]  # something was prepared
+        assert torch.equal(net(ws, a, noise_mode="const"), y1) and torch.equal(fresh(a), y1)
+        for _ in range(3):  # new tensors, the old ones freed in between: addresses may repeat, objects do not
+            del a
+            a = mk()
+            assert torch.equal(net(ws, a, noise_mode="const"), fresh(a))
+        a["image_ortho_front"].mul_(0.5)  # same object, new version
+        y2 = net(ws, a, noise_mode="const")
+        assert torch.equal(y2, fresh(a)) and not torch.equal(y2, y1)

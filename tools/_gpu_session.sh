@@ -1,5 +1,1 @@
-mkdir -p gpurun_out/r03n
-timeout 900 python -m pytest tests/test_hip_synthesis.py tests/test_dropin_reference.py -x -q -m gpu > gpurun_out/r03n/pytest_syn.log 2>&1; echo "pytest rc $?"
-tail -4 gpurun_out/r03n/pytest_syn.log
-for i in 1 2; do timeout 300 python tools/profile_f.py 2>/dev/null | tail -1; done
-timeout 300 python tools/generate_subject.py 2>/dev/null | tail -1
+timeout 600 python -m pytest tests/test_hip_synthesis.py -x -q -m gpu -k "prepared_conditioning" 2>&1 | grep -v "^$" | tail -30
