@@ -1,1 +1,2 @@
-timeout 600 python -m pytest tests/test_hip_synthesis.py -x -q -m gpu -k "prepared_conditioning" 2>&1 | grep -v "^$" | tail -30
+mkdir -p gpurun_out/r03n
+bash tools/secondary_benchmarks.sh > gpurun_out/r03n/secondary.txt 2>&1; echo "secondary rc $?"
