@@ -1,2 +1,1 @@
-mkdir -p gpurun_out/r03n
-bash tools/secondary_benchmarks.sh > gpurun_out/r03n/secondary.txt 2>&1; echo "secondary rc $?"
+timeout 300 python tools/experiments/f_sync_check.py 2>&1 | tail -2
