@@ -45,7 +45,7 @@ extern "C" {
                                      out_sigma = -1000 (get_eg3d_volume overwrites their density anyway, eg3d_metrics3d.py:155-159) */
 #define P3D_FLAG_FAST_COLOR 512 /* p3d_render_f32: the caller ACCEPTS fp32-tolerance colours, so the final pass may run in its
                                    tolerance mode: both decoder layers on f16 MFMA with two-term operand splits (~2^-21 per
-                                   product) and hardware exp2 / log2 / rcp activations (small launches stay on the exact kernel).  The
+                                   product) and hardware exp2 / log2 / rcp activations (both render kernels have the variant).  The
                                    coarse pass — hence the inverse-CDF indices, the fine depths and the merged depth order —
                                    stays on the exact contract; feat / depth / wsum / xyz agree with it to fp32 tolerance
                                    (tests/test_hip_parity.py::test_fast_color_*). */

@@ -1078,17 +1078,21 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, DUMP, EARLY))
 // it the two slots exchange sigma / skipped flag / their 16 colour channels (ds_bpermute), then both consume sample A and
 // sample B in order.  Slot 0 writes the outputs.  No dumps on this path (the host falls back to k_render for them).
 // =====================================================================================================================
-template <int NF>
+// FAST (P3D_FLAG_FAST_COLOR): the final pass decodes in tolerance mode exactly as k_render<…, FAST = true> does (two-term f16 MLP
+// operands, hardware transcendentals, the exact mask guard, rays dropped below a transmittance of 2e-6); the coarse pass, and
+// with it every importance draw, stays on the exact contract.
+template <int NF, bool FAST>
 __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(RenderParams p) {  // 1 workgroup per CU is all a small launch has: up to 512 VGPRs
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
+    if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const int jr = j & 15, slot = j >> 4;
     const int nwaves = blockDim.x >> 6;
     long long tile = (long long)blockIdx.x * nwaves + wave;  // 16-ray tiles
     if (tile >= p.ntiles) return;  // no workgroup barrier below this line
-    float* wl = lds + P3D_LDS_MLP_FLOATS + 4 + (size_t)wave * p.lds_rows * 32;
+    float* wl = lds + (FAST ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4 + (size_t)wave * p.lds_rows * 32;
 
     const int Sc = p.Sc, Sf = P3D_NF_EXACT(NF) ? NF : p.Sf, S = Sc + Sf;
     long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
@@ -1284,13 +1288,15 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
                     if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
                         float s2;
                         f32x16 c2;
-                        p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        else p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
                         if (prev_skipped) prev_rgb = c2;
                         prev_skipped = false;
                     }
                     if (__builtin_amdgcn_ballot_w64(skipped && w != 0.0f) != 0) {
                         float s2;
-                        p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
                         skipped = false;
                     }
                 }
@@ -1320,11 +1326,14 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
             for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
             bool skipped = false, live = true;
             if (early) {
-                live = !(is_cropped(px, pz) || st.Td < 1e-60);
+                // exact mode: below 1e-60 every later weight is exactly 0.  Tolerance mode: the transmittance bounds what the rest
+                // of the ray can still add — stop at 2e-6, inside the 2e-5 budget (as in k_render)
+                live = !(is_cropped(px, pz) || st.Td < (FAST ? 2e-6 : 1e-60));
                 skipped = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skipped) {
-                p3d_decode_wave<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0, false, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                else p3d_decode_wave<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 ndec += 1;
                 skipped = !live;
             }
@@ -1820,25 +1829,24 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     hipLaunchKernelGGL(k_minmax_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, p.gminmax, p.per_view_clamp ? N : 0);
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
-    // (P3D_FLAG_FAST_COLOR is a permission, not an obligation: this kernel has no tolerance variant and its exact results are
-    // trivially within any tolerance)
     if (pair) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
         else p.tiles_per_img = (R + 15) / 16;
         p.ntiles = p.tiles_per_img * N;
         nwaves = P3D_RENDER_WAVES;
-        for (;; nwaves >>= 1) {  // (always the exact kernel's LDS image)
-            lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4 + (size_t)nwaves * p.lds_rows * 128;
+        for (;; nwaves >>= 1) {
+            lds_bytes = lds_fixed + (size_t)nwaves * p.lds_rows * 128;
             if (lds_bytes <= 160 * 1024) break;
             if (nwaves == 1) return P3D_E_RANGE;
         }
         dim3 grid2((unsigned)((p.ntiles + nwaves - 1) / nwaves)), blk2(64 * nwaves);
         hipError_t e2 = hipSuccess;
-#define P3D_LAUNCH2(NFV)                                                                                             \
+#define P3D_LAUNCH2F(NFV, FV)                                                                                        \
     do {                                                                                                             \
-        e2 = p3d_ensure_dynamic_lds(k_render_pair<NFV>, lds_bytes);                                                  \
-        if (e2 == hipSuccess) hipLaunchKernelGGL((k_render_pair<NFV>), grid2, blk2, lds_bytes, st, p);              \
+        e2 = p3d_ensure_dynamic_lds(k_render_pair<NFV, FV>, lds_bytes);                                              \
+        if (e2 == hipSuccess) hipLaunchKernelGGL((k_render_pair<NFV, FV>), grid2, blk2, lds_bytes, st, p);          \
     } while (0)
+#define P3D_LAUNCH2(NFV) do { if (fast) P3D_LAUNCH2F(NFV, true); else P3D_LAUNCH2F(NFV, false); } while (0)
 #ifdef P3D_ONLY_NF
         P3D_LAUNCH2(P3D_ONLY_NF);
 #else

@@ -19,8 +19,9 @@ R = res * res
 jit = torch.rand((1, R, S, 1), device=dev); u = torch.rand((R, S), device=dev)
 out = {}
 ref = None
-for name, pair in (("pair_16rays_x2samples", True), ("classic_32rays", False)):
-    opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True, small_launch_kernel=pair)
+for name, pair, fast in (("pair_16rays_x2samples", True, False), ("classic_32rays", False, False), ("pair_tolerance", True, True),
+                         ("classic_32rays_tolerance", False, True)):
+    opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True, small_launch_kernel=pair, fast_color=fast)
     for _ in range(3):
         r = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
     ts = []
@@ -31,6 +32,8 @@ for name, pair in (("pair_16rays_x2samples", True), ("classic_32rays", False)):
     out[name + "_ms"] = float(np.median(ts))
     if ref is None:
         ref = r
-    else:
+    elif not fast:
         out["identical"] = all(torch.equal(x, y) for x, y in zip(ref, r))
+    else:
+        out[name + "_max_abs_vs_exact"] = max(float((x - y).abs().max()) for x, y in zip(ref, r))
 print(json.dumps(dict(res=res, samples=[S, S], **out)))
