@@ -243,12 +243,19 @@ class TriPlaneGenerator(torch.nn.Module):
         force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
         res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
         if "camera_params" not in x:
+            # one device -> host copy for the view parameters the caller gave (the defaults — distance 1, fov 30, triplane.py:360-363 —
+            # are known on the host), then labels and rays memoised per view (cameras.cached_view).  Every launch saved here is a
+            # launch the GPU does not wait for: a call starts with an empty queue.
+            given = [k for k in ("elevations", "azimuths", "distances", "fovs") if k in x]
+            host = dict(zip(given, torch.stack([torch.as_tensor(x[k]).reshape(-1) for k in given]).cpu().double().tolist()))
+            nv = len(host["elevations"])
             if "distances" not in x:
                 x["distances"] = torch.ones_like(x["elevations"])
+                host["distances"] = [1.0] * nv
             if "fovs" not in x:
-                x["fovs"] = 30 * torch.ones_like(x["elevations"])
-            # one device -> host copy for all view parameters, then labels and rays memoised per view (cameras.cached_view)
-            vals = torch.stack([torch.as_tensor(x[k]).reshape(-1).double() for k in ("elevations", "azimuths", "distances", "fovs")]).cpu().tolist()
+                x["fovs"] = torch.full_like(x["elevations"], 30)
+                host["fovs"] = [30.0] * nv
+            vals = [host[k] for k in ("elevations", "azimuths", "distances", "fovs")]
             views = [cameras.cached_view(e, a, d, fv, res, self.rendering_kwargs["box_warp"], device, dtype) for e, a, d, fv in zip(*vals)]
             x["camera_params"] = torch.stack([v[0] for v in views])
             if force_rays is None:

@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r03p
-timeout 600 python bench.py > gpurun_out/r03p/bench.json 2> gpurun_out/r03p/bench.err; echo "bench rc $?"
-timeout 600 python bench.py --fast > gpurun_out/r03p/bench_fast.json 2> gpurun_out/r03p/bench_fast.err; echo "bench fast rc $?"
-timeout 600 python bench.py --scene surface > gpurun_out/r03p/bench_surface.json 2> gpurun_out/r03p/bench_surface.err; echo "bench surface rc $?"
+timeout 900 python -m pytest tests/test_hip_synthesis.py tests/test_dropin_reference.py -x -q -m gpu 2>&1 | tail -3
+for i in 1 2; do timeout 300 python tools/profile_f.py 2>/dev/null | tail -1; done
+timeout 300 python tools/experiments/f_sync_check.py 2>&1 | tail -1
