@@ -928,18 +928,27 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
         buf ^= 1;
     }
     float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0);
+    // a lane owns both column phases (ox = 2 gx, 2 gx + 1) of its grid point: one 8-byte store per (row phase, channel) — 16 lanes
+    // cover 128 contiguous bytes of an output row — instead of two 4-byte stores 8 bytes apart (the last grid column has only
+    // px = 0; rows of the odd-width intermediate are 4-byte aligned, which global stores allow)
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int gy = gy0 + prow0 + 2 * t, gx = gx0 + pcol;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const int py = ph >> 1, px = ph & 1;
-            if (gy > p.H - py || gx > p.W - px) continue;
-            const int oy = 2 * gy + py, ox = 2 * gx + px;
+        for (int py = 0; py < 2; ++py) {
+            if (gy > p.H - py || gx > p.W) continue;
+            const int oy = 2 * gy + py, ox = 2 * gx;
+            const bool both = gx < p.W;  // px = 1 exists
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = SPLIT ? acc[ph][t][r] * HX_SPLIT_UNSCALE : acc[ph][t][r];
+                if (ch >= p.O) continue;
+                const float v0 = SPLIT ? acc[2 * py][t][r] * HX_SPLIT_UNSCALE : acc[2 * py][t][r];
+                const float v1 = SPLIT ? acc[2 * py + 1][t][r] * HX_SPLIT_UNSCALE : acc[2 * py + 1][t][r];
+                float* dst = yout + (((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox;
+                if (both) *reinterpret_cast<f32x2u*>(dst) = (f32x2u){v0, v1};
+                else dst[0] = v0;
             }
         }
     }

@@ -1,3 +1,4 @@
-timeout 600 python tools/experiments/img_conv_check.py 2>&1 | tail -7
-echo "== w4 off"
-P3D_CONV_W4=0 timeout 600 python tools/experiments/img_conv_check.py 2>&1 | tail -7 | cut -c1-200
+mkdir -p gpurun_out/r03r
+timeout 600 python bench.py > gpurun_out/r03r/bench.json 2> gpurun_out/r03r/bench.err; echo "bench rc $?"
+timeout 600 python bench.py --fast > gpurun_out/r03r/bench_fast.json 2> gpurun_out/r03r/bench_fast.err; echo "bench fast rc $?"
+timeout 600 python bench.py --scene surface > gpurun_out/r03r/bench_surface.json 2> gpurun_out/r03r/bench_surface.err; echo "bench surface rc $?"
