@@ -23,15 +23,20 @@ def flops_backbone():
     return f
 
 
-def timeit(fn, n=10):
-    for _ in range(2):
+def timeit(fn, n=10, groups=5):
+    """Median over `groups` back-to-back groups of n calls (a mean over one group carried the occasional one-off — a first
+    allocation of a 134 MB activation, a lazily set kernel attribute — into the number: 7 ms 'super-resolution' lines)."""
+    for _ in range(3):
         fn()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n
+    ts = []
+    for _ in range(groups):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) / n)
+    return float(np.median(ts))
 
 
 G = sg.Generator(z_dim=512, c_dim=25, w_dim=512, img_resolution=256, img_channels=96, cond_mode="none",
@@ -54,6 +59,6 @@ with torch.no_grad():
     dt = timeit(lambda: sr(rgb, x, ws, noise_mode="none"))
     out["superres_N1_f16_operands"] = {"ms": dt * 1e3, "TFLOP/s": fl / dt / 1e12, "frac_of_2500_f16": fl / dt / 2.5e15}
     x16 = x.expand(16, -1, -1, -1).contiguous(); rgb16 = x16[:, :3].contiguous(); ws16 = ws.expand(16, -1, -1).contiguous()
-    dt = timeit(lambda: sr(rgb16, x16, ws16, noise_mode="none"), n=3)
+    dt = timeit(lambda: sr(rgb16, x16, ws16, noise_mode="none"), n=3, groups=3)
     out["superres_N16_f16_operands"] = {"ms_per_image": dt * 1e3 / 16, "TFLOP/s": 16 * fl / dt / 1e12}
 print(json.dumps(out))
