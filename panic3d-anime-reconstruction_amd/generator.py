@@ -105,7 +105,7 @@ class TriPlaneGenerator(torch.nn.Module):
     def __getstate__(self):
         """Pickling / deep copies (the reference snapshots G): derived tensors and per-call state stay out."""
         state = dict(self.__dict__)
-        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan"):
+        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo"):
             if k in state:
                 state[k] = None
         return state
@@ -235,10 +235,31 @@ class TriPlaneGenerator(torch.nn.Module):
                 break
         if "latent_injection" in x:
             latent_injection = {**(latent_injection or {}), **x["latent_injection"]}
+        ws_key = None
         if "zs" not in x and "ws" not in x:
             if "z" not in x:
-                x["z"] = torch.tensor(np.stack([np.random.RandomState(s).randn(self.z_dim) for s in x["seeds"]]),
-                                      device=device, dtype=dtype)
+                # generate.py renders its 16 views of a subject with the same seeds, conditioning tensors and (PAniC-3D's default,
+                # c_gen_conditioning_zero) a mapping that does not see the camera: the latents and the ws of the previous call are
+                # then the ws of this one.  Memoised on everything the mapping reads — seeds, truncation, the mapping network's
+                # parameter versions, the conditioning tensors it uses (object + version, strong references) — one entry deep.
+                rc = self.backbone.mapping.resnet_cond
+                pose_free = bool(self.rendering_kwargs.get("c_gen_conditioning_zero", False)) or self.c_dim == 0
+                if pose_free and latent_injection is None:
+                    ct = [x["cond"]["resnet_feats"]] if rc > 0 else []
+                    ws_key = (tuple(int(s) for s in x["seeds"]), float(truncation_psi), truncation_cutoff, str(device), dtype,
+                              tuple((id(t), t._version) for t in ct),
+                              tuple((q.data_ptr(), q._version) for q in self.backbone.mapping.parameters()),
+                              tuple((q.data_ptr(), q._version) for q in self.backbone.mapping.buffers()))
+                    hit = self.__dict__.get("_ws_memo")
+                    if hit is not None and hit[0] == ws_key and all(a is b for a, b in zip(hit[1], ct)) \
+                            and hit[2]._version == hit[4][0] and hit[3]._version == hit[4][1]:  # (nobody wrote into the memoised tensors)
+                        x["z"], x["ws"] = hit[2], hit[3]
+                        ws_key = None
+                    else:
+                        ws_key = (ws_key, ct)
+                if "z" not in x:
+                    x["z"] = torch.tensor(np.stack([np.random.RandomState(s).randn(self.z_dim) for s in x["seeds"]]),
+                                          device=device, dtype=dtype)
             x["zs"] = x["z"][:, None, :].expand(-1, self.backbone.num_ws, -1)
         force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
         res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
@@ -283,6 +304,8 @@ class TriPlaneGenerator(torch.nn.Module):
                 cpm = cpm[:1]
             x["ws"] = self.mapping_zplus(x["zs"], cpm, x["cond"], truncation_psi=truncation_psi,
                                          truncation_cutoff=truncation_cutoff)
+            if ws_key is not None:
+                self.__dict__["_ws_memo"] = (ws_key[0], ws_key[1], x["z"], x["ws"], (x["z"]._version, x["ws"]._version))
         _ws = x["ws"]
         if latent_injection is not None:
             for k in ("dw", "dws"):

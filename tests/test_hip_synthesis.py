@@ -685,3 +685,45 @@ def test_prepared_conditioning_follows_the_conditioning_tensors(hip):
         a["image_ortho_front"].mul_(0.5)  # same object, new version
         y2 = net(ws, a, noise_mode="const")
         assert torch.equal(y2, fresh(a)) and not torch.equal(y2, y1)
+
+
+def test_f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed(hip):
+    """generate.py calls f() once per view with the same seeds and conditioning tensors; with a mapping that does not see the
+    camera (c_gen_conditioning_zero, PAniC-3D's default) the second call reuses the first call's ws.  Anything the mapping reads
+    invalidates it: other seeds, truncation, edited / replaced conditioning features, edited mapping weights, a write into the
+    memoised tensors.  A pose-conditioned generator never memoises."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    torch.manual_seed(3)
+    kw = dict(TRI_KW, rendering_kwargs={**TRI_KW["rendering_kwargs"], "c_gen_conditioning_zero": True}, cond_mode="resnetcond_8")
+    G = TriPlaneGenerator(**kw).cuda().eval()
+    G.set_force_sigmoid(True)
+    feats = torch.randn(1, 16, device="cuda")
+    mk = lambda **o: dict(dict(seeds=[4], cond={"resnet_feats": feats}, elevations=torch.zeros(1).cuda(), azimuths=torch.zeros(1).cuda(),
+                               neural_rendering_resolution=16, noise_mode="const", triplane_crop=0.1, cull_clouds=0.5), **o)
+    direct = lambda x: G.mapping_zplus(x["zs"], x["camera_params"], x["cond"])
+    with torch.no_grad():
+        a = mk(); G.f(a)
+        b = mk(azimuths=torch.full((1,), 40.0).cuda()); G.f(b)
+        assert b["ws"] is a["ws"] and torch.equal(b["ws"], direct(b))  # another view of the same subject: reused, and right
+        c = mk(seeds=[5]); G.f(c)
+        assert c["ws"] is not a["ws"] and not torch.equal(c["ws"], a["ws"]) and torch.equal(c["ws"], direct(c))
+        d = mk(seeds=[5]); G.f(d, truncation_psi=0.7)
+        assert d["ws"] is not c["ws"]
+        e = mk(); G.f(e); e2 = mk(); G.f(e2)
+        assert e2["ws"] is e["ws"]
+        feats.add_(torch.randn_like(feats))  # same object, new version (not a pure rescale: the embedding is normalised)
+        f_ = mk(); G.f(f_)
+        assert f_["ws"] is not e["ws"] and torch.equal(f_["ws"], direct(f_)) and not torch.equal(f_["ws"], e["ws"])
+        G.backbone.mapping.fc1.weight.data.mul_(1.01)  # (a .data write does not bump the version: the memo must be dropped by hand ...)
+        G.__dict__.pop("_ws_memo", None)
+        g1 = mk(); G.f(g1)
+        G.backbone.mapping.fc1.weight.mul_(1.01)  # ... an in-place write does
+        g2 = mk(); G.f(g2)
+        assert g2["ws"] is not g1["ws"] and torch.equal(g2["ws"], direct(g2))
+        g2["ws"].add_(1.0)  # a caller scribbles on its ws
+        g3 = mk(); G.f(g3)
+        assert g3["ws"] is not g2["ws"] and torch.equal(g3["ws"], direct(g3))
+    Gp = TriPlaneGenerator(**dict(TRI_KW, cond_mode="resnetcond_8")).cuda().eval()  # pose-conditioned (the fixture's default)
+    with torch.no_grad():
+        p1 = mk(); Gp.f(p1); p2 = mk(); Gp.f(p2)
+    assert p2["ws"] is not p1["ws"] and "_ws_memo" not in Gp.__dict__

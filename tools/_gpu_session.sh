@@ -1,3 +1,1 @@
-mkdir -p gpurun_out/r03r
-bash tools/secondary_benchmarks.sh > gpurun_out/r03r/secondary.txt 2>&1; echo "secondary rc $?"
-timeout 300 python tools/graph_backbone.py 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_hip_synthesis.py -x -q -m gpu -k memoises 2>&1 | tail -3
