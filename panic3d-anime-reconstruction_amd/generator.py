@@ -49,6 +49,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
                                                img_channels=3, is_last=True, conv_clamp=clamp, **block_kwargs)
 
     def forward(self, rgb, x, ws, **block_kwargs):
+        ws_in = ws
         ws = ws[:, -1:, :].repeat(1, 3, 1)
         if x.shape[-1] != self.input_resolution:
             size = (self.input_resolution, self.input_resolution)
@@ -60,7 +61,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
         if plan is None:
             plan = stylegan2.StylePlan(stylegan2.plan_entries([("block0", self.block0), ("block1", self.block1)], [0, 0]))
             self.__dict__["_style_plan"] = plan
-        pre = plan(ws)
+        pre = plan(ws, memo_of=ws_in)
         x, rgb = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], **block_kwargs)
         x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], **block_kwargs)
         return rgb

@@ -727,3 +727,29 @@ def test_f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed(hip):
     with torch.no_grad():
         p1 = mk(); Gp.f(p1); p2 = mk(); Gp.f(p2)
     assert p2["ws"] is not p1["ws"] and "_ws_memo" not in Gp.__dict__
+
+
+def test_style_plan_memo_follows_ws_and_parameters(hip):
+    """StylePlan returns the previous call's styles / demodulation coefficients only for the same ws OBJECT at the same version
+    with unchanged parameters; the planes always equal those of a network that has never seen another ws."""
+    import copy
+    sg = hip.stylegan2
+    torch.manual_seed(21)
+    net = sg.SynthesisNetwork(w_dim=512, img_resolution=32, img_channels=96, cond_mode="none", channel_base=2048, channel_max=64, num_fp16_res=0).cuda()
+    fresh = lambda w: copy.deepcopy(net)(w, {}, noise_mode="const")
+    with torch.no_grad():
+        ws = torch.randn(1, net.num_ws, 512, device="cuda")
+        a = net(ws, {}, noise_mode="const")
+        plan = net.__dict__["_style_plan"]
+        m0 = plan._memo
+        assert m0 is not None and m0[0] is ws
+        assert torch.equal(net(ws, {}, noise_mode="const"), a) and plan._memo is m0  # reused
+        ws.mul_(0.5)  # same object, new version
+        b = net(ws, {}, noise_mode="const")
+        assert plan._memo is not m0 and torch.equal(b, fresh(ws)) and not torch.equal(a, b)
+        w2 = ws.clone()  # another object, same values
+        assert torch.equal(net(w2, {}, noise_mode="const"), b) and plan._memo[0] is w2
+        net.b16.conv1.affine.bias.add_(0.25)  # a parameter the plan reads
+        c = net(w2, {}, noise_mode="const")
+        assert torch.equal(c, fresh(w2)) and not torch.equal(c, b)
+        assert "_style_plan" not in copy.deepcopy(net).__dict__  # derived state stays out of copies / pickles
