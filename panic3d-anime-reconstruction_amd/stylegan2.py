@@ -121,6 +121,9 @@ DEFAULT_CONV_MMA_1X1 = os.environ.get("P3D_CONV_MMA_1X1", "f32")  # the 1x1 ToRG
 # last pass writes conv1's two-term operand directly (conv1's styles applied, hi / lo split done) instead of an fp32 tensor that
 # conv1 would modulate and split again in each of its channel-tile workgroups.  Bit-identical results; P3D_CONV_IMG=0 for A/B runs.
 CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
+# StylePlan returns the previous call's result for the same ws object (views of one subject).  Off: every pass computes its styles
+# (the pass timings of tools/bench_backbone.py, graph_backbone.py, profile_backbone.py are taken that way).
+STYLE_MEMO = os.environ.get("P3D_STYLE_MEMO", "1") != "0"
 IMG_MIN_RES = 32
 
 
@@ -296,6 +299,8 @@ class StylePlan:
             self._key = key
             self._memo = None
         memo = getattr(self, "_memo", None)
+        if not STYLE_MEMO:
+            memo_of = None
         if memo_of is not None and memo is not None and memo[0] is memo_of and memo[1] == memo_of._version and memo[2] == tuple(ws.shape):
             return memo[3]
         out = self._compute(ws, dev)

@@ -5,6 +5,7 @@ import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import panic3d_amd as P
+P.stylegan2.STYLE_MEMO = False  # every timed pass computes its styles (a new batch of subjects per pass)
 from panic3d_amd import ops, cameras, stylegan2 as sg
 
 torch.manual_seed(0)

@@ -5,6 +5,7 @@ import argparse, os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import panic3d_amd as P
+P.stylegan2.STYLE_MEMO = False  # a pass includes its style computation (a new subject per pass)
 from panic3d_amd import stylegan2 as sg
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
