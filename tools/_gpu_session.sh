@@ -1,5 +1,2 @@
-mkdir -p gpurun_out/r03t
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03t/pytest.log 2>&1; echo "pytest rc $?"
-tail -3 gpurun_out/r03t/pytest.log
-bash tools/secondary_benchmarks.sh > gpurun_out/r03t/secondary.txt 2>&1; echo "secondary rc $?"
-timeout 300 python tools/graph_backbone.py 2>&1 | tail -1
+timeout 120 python tools/experiments/fir_img_time.py 2>/dev/null | tail -1
+for p in 44 48 52 56; do P3D_LIB=$PWD/build/lib_fir$p.so timeout 120 python tools/experiments/fir_img_time.py 2>/dev/null | tail -1; done
