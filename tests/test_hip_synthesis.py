@@ -597,7 +597,8 @@ def test_torgb_gemm_kernel_vs_the_three_launch_form(hip, N, I, O, H):
         assert torch.equal(new - 0, ops.torgb(x, wt, O, s, bias=b, clamp=clamp, skip=prev, skip_filter=filt))  # deterministic
 
 
-@pytest.mark.parametrize("N,I,O,H", [(1, 256, 128, 128), (2, 512, 512, 16), (1, 32, 256, 64), (3, 64, 48, 32), (1, 128, 64, 20), (1, 64, 32, 8)])
+@pytest.mark.parametrize("N,I,O,H", [(1, 256, 128, 128), (2, 512, 512, 16), (1, 32, 256, 64), (3, 64, 48, 32), (1, 128, 64, 20), (1, 64, 32, 8),
+                                     (2, 24, 32, 32)])  # (I = 24: conv0 itself runs on fp32 operands, its FIR pass still writes the image)
 def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O, H):
     """Round 3: an up-sampling layer called with next_styles writes the following layer's two-term operand
     (ops.ActImage: split(16 * s1 * y), the pieces k_modconv_w2 would build itself) from its FIR pass instead of the fp32 tensor.
@@ -628,8 +629,13 @@ def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O,
         else:
             with pytest.raises(RuntimeError):  # maps narrower than the wide tile do not stage from images
                 ops.modulated_conv2d(img, w1, None, **k1)
+    # the domain flag trips through the image WRITER too: conv0 on fp32 operands (it raises nothing itself), no clamp, a result whose
+    # 16 * s1 * y leaves the f16 range
     flag = ops.conv_domain_flag(x.device)
-    ops.modulated_conv2d(x * 3e4, w0, s0, next_styles=s1, saturated=flag, **k0)
+    kz = dict(k0, clamp=None, weight_f16=None)
+    ops.modulated_conv2d(x, w0, s0, next_styles=s1, saturated=flag, **kz)
+    assert not ops.conv_domain_violated(flag)
+    ops.modulated_conv2d(x * 3e4, w0, s0, next_styles=s1, saturated=flag, **kz)
     assert ops.conv_domain_violated(flag)
     with pytest.raises(RuntimeError):  # next_styles is for up-sampling layers
         ops.modulated_conv2d(mid, w1, s1, next_styles=s1, **k1)
