@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 6  /* 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
+#define P3D_ABI_VERSION 7  /* 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -100,6 +100,13 @@ typedef struct {
  * (training/triplane.py:200-206) and lets grid_sample gather 32 lines per tap (renderer.py:80); every kernel below
  * wants one 128-byte line per tap. */
 int p3d_planes_to_nhwc_f32(const float* planes_nchw, int n3, int C, int H, int W, float* planes_nhwc, void* stream);
+
+/* OSGDecoder.forward (training/triplane.py:528-544) on already sampled features — the decoder module's own call surface:
+ * feats [N][3][M][32] (`sampled_features`, renderer.py:271-273), mean over the three planes, FC 32 -> 64, Softplus, FC 64 -> 33;
+ * out_sigma [N][M] = row 0, out_rgb [N][M][32] = sigmoid(rows 1..32) (force_sigmoid != 0) or sigmoid * 1.002 - 0.001.  Weights
+ * pre-scaled as for p3d_triplane_decode_f32; feats / out_rgb 16-byte aligned.  Same arithmetic contract as the fused kernels. */
+int p3d_decode_features_f32(const float* feats, int N, int64_t M, const float* w0, const float* b0, const float* w1, const float* b1,
+                            int force_sigmoid, float* out_sigma, float* out_rgb, void* stream);
 
 /* ImportanceRenderer.run_model (renderer.py:266-280) = sample_from_planes (:68-81) + OSGDecoder.forward
  * (training/triplane.py:528-544) + crop/cull masks (renderer.py:138-153,187-198) on a point cloud.
@@ -193,7 +200,9 @@ int p3d_unify_perm_f32(const float* depths_coarse, const float* depths_fine, int
  * transposed conv + 4x4 FIR `fir` = setup_filter([1,3,3,1]) flipped and multiplied by up^2, conv2d_resample.py:114-128);
  * act 0 linear / 1 lrelu(alpha); then *gain and clamp (< 0: none) as bias_act.py:93-122.  y [N][O][H*up][W*up].
  * demod_coefs: NULL, or the [N][O] coefficients already computed by p3d_demod_coefs_f32 (then no per-call reduction over the
- * weights is launched); ignored unless demodulate. */
+ * weights is launched); ignored unless demodulate.
+ * Alignment: x, w, styles, noise, bias and y need only their natural 4-byte alignment (an offset view is fine); when up = 2 and
+ * y / noise happen to be 16-byte aligned the FIR pass stores four outputs at a time, otherwise one by one — same values. */
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up);
 int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
                       int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias,
@@ -351,6 +360,18 @@ int p3d_mc_emit_f32(const float* vol, int n, int flip0, float level, void* works
 /* Library / build identification ("gfx950"), and the ABI version this library was built with (P3D_ABI_VERSION). */
 const char* p3d_build_info(void);
 int p3d_abi_version(void);
+
+/* The layout of the four POD structs above AS THIS LIBRARY WAS COMPILED, for bindings that restate them in another language
+ * (ctypes, cgo, JNA ...): which = P3D_STRUCT_OPTS / _DUMPS / _PASTE_ARGS / _CONV_ARGS; out[0] = sizeof, out[1 + i] = offsetof
+ * field i in declaration order; returns the number of entries (1 + #fields) or P3D_E_ARG / P3D_E_RANGE (cap too small, unknown
+ * struct).  A binding compares them with its own mirror once at load time (the in-tree one does: _lib.py) — the plugin seam of the
+ * reference validates its arguments with TORCH_CHECK (torch_utils/ops/bias_act.cpp:36-101); a struct passed through a foreign
+ * FFI has no such check unless the library offers one. */
+#define P3D_STRUCT_OPTS 0
+#define P3D_STRUCT_DUMPS 1
+#define P3D_STRUCT_PASTE_ARGS 2
+#define P3D_STRUCT_CONV_ARGS 3
+int p3d_struct_layout(int which, size_t* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,19 @@ def decode(planes, coords, mlp, box_warp, plane_mode=1, flags=FLAG_FORCE_SIGMOID
     return sigma, rgb
 
 
+def decode_features(feats, mlp, force_sigmoid=True):
+    """OSGDecoder.forward (triplane.py:528-544) on sampled features [N,3,M,32] -> sigma [N,M,1], rgb [N,M,32]."""
+    feats, pf = _f(feats)
+    N, three, M, Cc = feats.shape
+    assert three == 3 and Cc == 32
+    (w0, p0), (b0, q0), (w1, p1), (b1, q1) = map(_f, mlp)
+    sigma = np.empty((N, M, 1), np.float32)
+    rgb = np.empty((N, M, 32), np.float32)
+    lib().p3d_oracle_decode_features(pf, N, C.c_long(M), p0, q0, p1, q1, FLAG_FORCE_SIGMOID if force_sigmoid else 0,
+                                     sigma.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
+    return sigma, rgb
+
+
 def sample_stratified(start, end, S, jitter):
     jitter, pj = _f(jitter)
     NR = jitter.size // S

@@ -130,21 +130,11 @@ typedef struct {
     const float *w0, *b0, *w1, *b1; /* pre-scaled: [64][32], [64], [33][64], [33] (networks_stylegan2.py:121-127) */
 } or_mlp;
 
-/* run_model for ONE point: sample_from_planes (renderer.py:68-81) + OSGDecoder.forward (triplane.py:528-544)
- * + crop/cull masks (renderer.py:138-153,187-198).  planes_n: this image's [3][C][H][W].
- * rgb may be NULL (density only). */
-static void or_decode_point(const float* planes_n, int H, int W, float px, float py, float pz, const or_mlp* m,
-                            float coord_scale, int plane_mode, int flags, float crop_limit, float cull_thresh,
-                            float* sigma_out, float* rgb) {
-    const long plane_sz = (long)OR_C * H * W;
-    float qx = px * coord_scale, qy = py * coord_scale, qz = pz * coord_scale; /* renderer.py:77 */
-    float f0[OR_C], f1[OR_C], f2[OR_C], X[OR_C], h[OR_HID];
-    or_sample_plane(planes_n + 0 * plane_sz, H, W, qx, qy, f0); /* generate_planes: renderer.py:26-50 */
-    or_sample_plane(planes_n + 1 * plane_sz, H, W, qx, qz, f1);
-    if (plane_mode)
-        or_sample_plane(planes_n + 2 * plane_sz, H, W, qy, qz, f2);
-    else
-        or_sample_plane(planes_n + 2 * plane_sz, H, W, qz, qx, f2);
+/* OSGDecoder.forward (triplane.py:528-544) on the three sampled feature vectors of ONE point + the crop / cull masks
+ * (renderer.py:138-153,187-198; px, pz: the point's position for the crop mask).  rgb may be NULL (density only). */
+static void or_decode_features(const float* f0, const float* f1, const float* f2, float px, float pz, const or_mlp* m, int flags,
+                               float crop_limit, float cull_thresh, float* sigma_out, float* rgb) {
+    float X[OR_C], h[OR_HID];
     for (int c = 0; c < OR_C; ++c) X[c] = ((f0[c] + f1[c]) + f2[c]) * P3D_THIRD; /* triplane.py:530 mean(1) */
     for (int n = 0; n < OR_HID; ++n) { /* net[0] + Softplus: triplane.py:522-524 */
         float a = m->b0[n];
@@ -188,6 +178,38 @@ static void or_decode_point(const float* planes_n, int H, int W, float px, float
             sigma = P3D_SIGMA_MASKED; /* renderer.py:194-196 */
     }
     *sigma_out = sigma;
+}
+
+/* run_model for ONE point: sample_from_planes (renderer.py:68-81) + OSGDecoder.forward (triplane.py:528-544)
+ * + crop/cull masks (renderer.py:138-153,187-198).  planes_n: this image's [3][C][H][W].
+ * rgb may be NULL (density only). */
+static void or_decode_point(const float* planes_n, int H, int W, float px, float py, float pz, const or_mlp* m,
+                            float coord_scale, int plane_mode, int flags, float crop_limit, float cull_thresh,
+                            float* sigma_out, float* rgb) {
+    const long plane_sz = (long)OR_C * H * W;
+    float qx = px * coord_scale, qy = py * coord_scale, qz = pz * coord_scale; /* renderer.py:77 */
+    float f0[OR_C], f1[OR_C], f2[OR_C];
+    or_sample_plane(planes_n + 0 * plane_sz, H, W, qx, qy, f0); /* generate_planes: renderer.py:26-50 */
+    or_sample_plane(planes_n + 1 * plane_sz, H, W, qx, qz, f1);
+    if (plane_mode)
+        or_sample_plane(planes_n + 2 * plane_sz, H, W, qy, qz, f2);
+    else
+        or_sample_plane(planes_n + 2 * plane_sz, H, W, qz, qx, f2);
+    or_decode_features(f0, f1, f2, px, pz, m, flags, crop_limit, cull_thresh, sigma_out, rgb);
+}
+
+/* OSGDecoder.forward over already sampled features (triplane.py:528-544): feats [N][3][M][32] -> sigma [N][M], rgb [N][M][32].
+ * No masks (the decoder knows no positions). */
+void p3d_oracle_decode_features(const float* feats, int N, long M, const float* w0, const float* b0, const float* w1,
+                                const float* b1, int flags, float* out_sigma, float* out_rgb) {
+    or_mlp m = {w0, b0, w1, b1};
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)N * M; ++i) {
+        const long n = i / M, q = i - n * M;
+        const float* base = feats + (n * 3 * M + q) * OR_C;
+        or_decode_features(base, base + M * OR_C, base + 2 * M * OR_C, 0.0f, 0.0f, &m, flags & OR_FLAG_FORCE_SIGMOID, 0.0f, 0.0f,
+                           out_sigma + i, out_rgb ? out_rgb + 32 * i : NULL);
+    }
 }
 
 /* ImportanceRenderer.run_model over a point cloud (renderer.py:266-280), used by sample_mixed (triplane.py:273-298)

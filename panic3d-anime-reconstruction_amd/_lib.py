@@ -11,7 +11,7 @@ SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D
 P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP, P3D_FLAG_NO_STAGING, P3D_FLAG_FORCE_STAGING = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192
 P3D_FLAG_DISPARITY = 4096
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 6  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 7  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -50,6 +50,8 @@ P3D_CONV_MMA_F32, P3D_CONV_MMA_F16, P3D_CONV_MMA_F16X2 = 0, 1, 2
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "p3d_planes_to_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "p3d_decode_features_f32": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "p3d_struct_layout": (_I, [_I, C.POINTER(C.c_size_t), _I]),
     "p3d_triplane_decode_f32": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _P]),
     "p3d_grid_density_f32": (_I, [_P, _I, _I, _I, _L, _L, _F, _F, _F, _F, _P, _P, _P, _P, C.POINTER(Opts), _P, _P, _F, _P]),
     "p3d_render_workspace_bytes": (_Z, [_I, _L, _I, _I]),
@@ -112,8 +114,28 @@ def lib():
         got = L.p3d_abi_version()
         if got != P3D_ABI_VERSION:
             raise RuntimeError(f"{SO} was built for ABI version {got}, this binding is written for {P3D_ABI_VERSION}: rebuild the library")
+        check_struct_layouts(L)
         _LIB = L
     return _LIB
+
+
+STRUCT_MIRRORS = {0: Opts, 1: Dumps, 2: PasteArgs, 3: ConvArgs}  # P3D_STRUCT_* -> the ctypes restatement above
+
+
+def check_struct_layouts(L):
+    """Compare every ctypes mirror with the layout the library was compiled with (p3d_struct_layout: sizeof + the offset of
+    each field in declaration order).  The mirrors are written by hand; p3d_abi_version() alone would not notice a field that
+    was added to one side only, or a padding difference."""
+    buf = (C.c_size_t * 64)()
+    for which, cls in STRUCT_MIRRORS.items():
+        n = L.p3d_struct_layout(which, buf, 64)
+        if n <= 0:
+            raise RuntimeError(f"p3d_struct_layout({which}) failed: {n}")
+        mine = [C.sizeof(cls)] + [getattr(cls, name).offset for name, _ in cls._fields_]
+        theirs = list(buf[:n])
+        if mine != theirs:
+            raise RuntimeError(f"{cls.__name__}: the ctypes mirror in _lib.py (size, offsets {mine}) does not match the struct "
+                               f"{SO} was compiled with ({theirs}): include/panic3d_hip.h and _lib.py have diverged")
 
 
 def check(rc, what):

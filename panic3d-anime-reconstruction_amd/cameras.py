@@ -123,8 +123,9 @@ import functools
 # entries are device tensors (2 x [3,res,res] fp32: 6 MB per view at 512^2), so the cache is kept SMALL — a 360-degree sweep or
 # random evaluation poses would otherwise pin one entry per unique pose (3 GB at 512^2 with the old 512 entries) — and is
 # dropped by cached_view_clear() (e.g. after moving a generator to another device).
-@functools.lru_cache(maxsize=32)
-def _cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype):
+def make_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.float32):
+    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res]) of one view, computed now."""
+    elev, azim, dist, fov, resolution, boxwarp = float(elev), float(azim), float(dist), float(fov), int(resolution), float(boxwarp)
     label = camera_label(elev, azim, dist, fov).to(dtype).to(device)
     if fov < 0:  # negative fov = orthographic view (training/triplane.py:402-414)
         r = ortho_rays(elev, azim, dist, boxwarp, resolution, device=device)
@@ -132,6 +133,9 @@ def _cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype):
     ro, rd = perspective_rays(label[:16].view(1, 4, 4), label[16:25].view(1, 3, 3), resolution)
     chw = lambda t: t.reshape(resolution, resolution, 3).permute(2, 0, 1).contiguous()
     return label, chw(ro), chw(rd)
+
+
+_cached_view = functools.lru_cache(maxsize=32)(make_view)
 
 
 def cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.float32):

@@ -13,6 +13,7 @@
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see panic3d-anime-reconstruction_amd/_build.py).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -224,6 +225,53 @@ __global__ __launch_bounds__(P3D_WG, 2) void k_decode_points(DecodeParams p) {
             tile = next;
             cur = nxt;
             cur_staged = nxt_staged;
+        }
+    }
+}
+
+// OSGDecoder.forward (training/triplane.py:528-544) on ALREADY SAMPLED features — the module's own call surface, for callers that
+// hold `sampled_features` [N][3][M][32] (the reference's renderer hands the decoder exactly that, renderer.py:271-273).  The plane
+// mean in the contract's order ((f0 + f1) + f2) * (1/3), then the same MFMA decoder as every other kernel here.  No masks: the
+// decoder knows no positions.  HBM-bound: 384 B in, 132 B out per sample.
+struct DecodeFeatParams {
+    const float* feats;  // [N][3][M][32]
+    const float *w0, *b0, *w1, *b1;
+    float* out_sigma;    // [N][M]
+    float* out_rgb;      // [N][M][32]
+    long long M, tiles_per_img, ntiles;
+    P3dDecodeCfg cfg;    // flags: P3D_FLAG_FORCE_SIGMOID only
+};
+__global__ __launch_bounds__(P3D_WG, 2) void k_decode_features(DecodeFeatParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const long long stride = (long long)gridDim.x * P3D_WAVES_PER_WG;
+    for (long long tile = (long long)blockIdx.x * P3D_WAVES_PER_WG + wave; tile < p.ntiles; tile += stride) {
+        const long long n = tile / p.tiles_per_img, m = (tile - n * p.tiles_per_img) * 32 + j;
+        const bool active = m < p.M;
+        const long long mc = active ? m : p.M - 1;
+        f32x16 f[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const f32x4* src = (const f32x4*)(p.feats + (((size_t)n * 3 + pl) * p.M + mc) * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = src[q];
+                f[pl][4 * q] = v.x; f[pl][4 * q + 1] = v.y; f[pl][4 * q + 2] = v.z; f[pl][4 * q + 3] = v.w;
+            }
+        }
+        f32x16 X, rgb;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) X[c] = ((f[0][c] + f[1][c]) + f[2][c]) * P3D_THIRD;  // triplane.py:530 mean(1)
+        float sigma;
+        p3d_decode_features<true>(lds, p.cfg, X, 0.0f, 0.0f, sigma, rgb);
+        if (active) {
+            const size_t o = (size_t)n * p.M + m;
+            if (h == 0) p.out_sigma[o] = sigma;
+            float* dst = p.out_rgb + o * 32 + 4 * h;  // register r holds channel rowof(r) + 4h (p3d_decode.hpp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){rgb[4 * q], rgb[4 * q + 1], rgb[4 * q + 2], rgb[4 * q + 3]};
         }
     }
 }
@@ -468,11 +516,14 @@ P3D_DEV void p3d_inverse_cdf_batch_f(const float* cdfA, TCF tc, int Ns, int j, c
 // accessor resolves with two more reads; any other disorder takes an exact O(Sc^2) selection (tc_sorted below).
 #define P3D_NF_EXACT(NF) ((NF) == 48 || (NF) == 96)
 #define P3D_TCG(NF, DUMP, EARLY) ((NF) == 96 && (EARLY) && !(DUMP))
-#define P3D_NF_OCC(NF, DUMP, EARLY) (((NF) >= 96 && !P3D_TCG(NF, DUMP, EARLY)) ? 1 : P3D_RENDER_OCC)
-template <int NF, bool DUMP, bool FAST, bool EARLY>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, DUMP, EARLY)) void k_render(RenderParams p) {
+#define P3D_NF_OCC(NF, TCGV) (((NF) >= 96 && !(TCGV)) ? 1 : P3D_RENDER_OCC)
+// TCG is a template parameter of its own (default: on wherever it can be): the host turns it OFF for the launches whose coarse
+// depths are not the plain stratified spacing — per-ray limits (ray_start = 'auto') and disparity spacing — which depth_of() below
+// does not know (with TCG derived from (NF, DUMP, EARLY) alone those launches silently rendered the fixed spacing).
+template <int NF, bool DUMP, bool FAST, bool EARLY, bool TCG = P3D_TCG(NF, DUMP, EARLY)>
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, TCG)) void k_render(RenderParams p) {
     static_assert(!(DUMP && EARLY), "dumps need every sample decoded");
-    constexpr bool TCG = P3D_TCG(NF, DUMP, EARLY);
+    static_assert(!TCG || P3D_TCG(NF, DUMP, EARLY), "TCG exists only for the production 96-key kernel");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
     if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
@@ -1639,6 +1690,55 @@ extern "C" {
 const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1 src=" P3D_SRC_HASH; }
 int p3d_abi_version(void) { return P3D_ABI_VERSION; }
 
+int p3d_struct_layout(int which, size_t* out, int cap) {
+    if (!out || cap <= 0) return P3D_E_ARG;
+    int n = 0;
+#define P3D_PUT(v) do { if (n >= cap) return P3D_E_RANGE; out[n++] = (size_t)(v); } while (0)
+#define P3D_OFF(T, f) P3D_PUT(offsetof(T, f))
+    switch (which) {
+    case P3D_STRUCT_OPTS:
+        P3D_PUT(sizeof(p3d_opts));
+        P3D_OFF(p3d_opts, coord_scale); P3D_OFF(p3d_opts, ray_start); P3D_OFF(p3d_opts, ray_end); P3D_OFF(p3d_opts, depth_delta);
+        P3D_OFF(p3d_opts, crop_limit); P3D_OFF(p3d_opts, cull_thresh); P3D_OFF(p3d_opts, Sc); P3D_OFF(p3d_opts, Sf);
+        P3D_OFF(p3d_opts, plane_mode); P3D_OFF(p3d_opts, flags);
+        break;
+    case P3D_STRUCT_DUMPS:
+        P3D_PUT(sizeof(p3d_dumps));
+        P3D_OFF(p3d_dumps, depths_coarse); P3D_OFF(p3d_dumps, sigma_coarse); P3D_OFF(p3d_dumps, weights_coarse);
+        P3D_OFF(p3d_dumps, depths_fine); P3D_OFF(p3d_dumps, inds); P3D_OFF(p3d_dumps, depths_sorted); P3D_OFF(p3d_dumps, sigma_sorted);
+        P3D_OFF(p3d_dumps, depth_unclamped); P3D_OFF(p3d_dumps, tminmax);
+        break;
+    case P3D_STRUCT_PASTE_ARGS:
+        P3D_PUT(sizeof(p3d_paste_args));
+        P3D_OFF(p3d_paste_args, weights); P3D_OFF(p3d_paste_args, xyz); P3D_OFF(p3d_paste_args, occ); P3D_OFF(p3d_paste_args, rays_o);
+        P3D_OFF(p3d_paste_args, rays_d); P3D_OFF(p3d_paste_args, front); P3D_OFF(p3d_paste_args, image);
+        P3D_OFF(p3d_paste_args, out_image); P3D_OFF(p3d_paste_args, out_paste); P3D_OFF(p3d_paste_args, out_mask);
+        P3D_OFF(p3d_paste_args, out_mask_weights); P3D_OFF(p3d_paste_args, out_mask_edges); P3D_OFF(p3d_paste_args, out_mask_occ);
+        P3D_OFF(p3d_paste_args, out_mask_dxyz);
+        P3D_OFF(p3d_paste_args, N); P3D_OFF(p3d_paste_args, r); P3D_OFF(p3d_paste_args, S); P3D_OFF(p3d_paste_args, front_shared);
+        P3D_OFF(p3d_paste_args, normalize_images);
+        P3D_OFF(p3d_paste_args, thresh_weight); P3D_OFF(p3d_paste_args, thresh_edges); P3D_OFF(p3d_paste_args, thresh_occ);
+        P3D_OFF(p3d_paste_args, thresh_dxyz); P3D_OFF(p3d_paste_args, box_warp);
+        break;
+    case P3D_STRUCT_CONV_ARGS:
+        P3D_PUT(sizeof(p3d_conv_args));
+        P3D_OFF(p3d_conv_args, x); P3D_OFF(p3d_conv_args, w); P3D_OFF(p3d_conv_args, w_f16); P3D_OFF(p3d_conv_args, styles);
+        P3D_OFF(p3d_conv_args, demod_coefs); P3D_OFF(p3d_conv_args, noise); P3D_OFF(p3d_conv_args, bias); P3D_OFF(p3d_conv_args, fir);
+        P3D_OFF(p3d_conv_args, y); P3D_OFF(p3d_conv_args, workspace); P3D_OFF(p3d_conv_args, saturated); P3D_OFF(p3d_conv_args, x_img);
+        P3D_OFF(p3d_conv_args, y_img); P3D_OFF(p3d_conv_args, y_img_styles); P3D_OFF(p3d_conv_args, workspace_bytes);
+        P3D_OFF(p3d_conv_args, N); P3D_OFF(p3d_conv_args, I); P3D_OFF(p3d_conv_args, H); P3D_OFF(p3d_conv_args, W); P3D_OFF(p3d_conv_args, O);
+        P3D_OFF(p3d_conv_args, ks); P3D_OFF(p3d_conv_args, up); P3D_OFF(p3d_conv_args, demodulate); P3D_OFF(p3d_conv_args, noise_per_sample);
+        P3D_OFF(p3d_conv_args, act); P3D_OFF(p3d_conv_args, mma);
+        P3D_OFF(p3d_conv_args, alpha); P3D_OFF(p3d_conv_args, gain); P3D_OFF(p3d_conv_args, clamp);
+        break;
+    default:
+        return P3D_E_RANGE;
+    }
+#undef P3D_OFF
+#undef P3D_PUT
+    return n;
+}
+
 int p3d_planes_to_nhwc_f32(const float* src, int n3, int C, int H, int W, float* dst, void* stream) {
     if (!src || !dst || n3 <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
     if (C != P3D_C) return P3D_E_RANGE;
@@ -1706,6 +1806,24 @@ int p3d_grid_density_f32(const float* planes, int H, int W, int grid_n, int64_t 
     if (staged) { if (fastd) P3D_LAUNCH_GRID(true, true); else P3D_LAUNCH_GRID(true, false); }
     else { if (fastd) P3D_LAUNCH_GRID(false, true); else P3D_LAUNCH_GRID(false, false); }
     if (e != hipSuccess) return (int)e;
+    return p3d_check_launch();
+}
+
+int p3d_decode_features_f32(const float* feats, int N, int64_t M, const float* w0, const float* b0, const float* w1, const float* b1,
+                            int force_sigmoid, float* out_sigma, float* out_rgb, void* stream) {
+    if (!feats || !w0 || !b0 || !w1 || !b1 || !out_sigma || !out_rgb || N <= 0 || M <= 0) return P3D_E_ARG;
+    if ((((uintptr_t)feats | (uintptr_t)out_rgb) & 15) != 0) return P3D_E_RANGE;  // 16-byte rows of 32 floats
+    DecodeFeatParams p;
+    p.feats = feats; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.out_sigma = out_sigma; p.out_rgb = out_rgb;
+    p.M = M; p.tiles_per_img = (M + 31) / 32; p.ntiles = p.tiles_per_img * N;
+    memset(&p.cfg, 0, sizeof(p.cfg));
+    p.cfg.flags = force_sigmoid ? P3D_FLAG_FORCE_SIGMOID : 0;
+    const size_t lds_bytes = (size_t)(P3D_LDS_MLP_FLOATS + 4) * 4;
+    long long blocks = (p.ntiles + P3D_WAVES_PER_WG - 1) / P3D_WAVES_PER_WG;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: the weight image is loaded once per workgroup
+    hipError_t e = p3d_ensure_dynamic_lds(k_decode_features, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_decode_features, dim3((unsigned)blocks), dim3(P3D_WG), lds_bytes, (hipStream_t)stream, p);
     return p3d_check_launch();
 }
 
@@ -1872,11 +1990,17 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
         e = p3d_ensure_dynamic_lds(k_render<NFV, DV, FV, EV>, lds_bytes);                                            \
         if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, DV, FV, EV>), grid, blk, lds_bytes, st, p);          \
     } while (0)
+#define P3D_LAUNCH_NOTCG(NFV, FV)                                                                                   \
+    do {                                                                                                             \
+        e = p3d_ensure_dynamic_lds(k_render<NFV, false, FV, true, false>, lds_bytes);                                \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_render<NFV, false, FV, true, false>), grid, blk, lds_bytes, st, p); \
+    } while (0)
 #define P3D_LAUNCH_F(NFV, FV)                                                                                        \
     do {                                                                                                             \
         if (dmp) P3D_LAUNCH(NFV, true, FV, false);                                                                   \
         else if (opts->flags & P3D_FLAG_NO_EARLY_OUT) P3D_LAUNCH(NFV, false, FV, false);                             \
-        else P3D_LAUNCH(NFV, false, FV, true);                                                                       \
+        else if (tcg) P3D_LAUNCH(NFV, false, FV, true);  /* (NFV == 96 only: the default TCG of that instantiation) */ \
+        else P3D_LAUNCH_NOTCG(NFV, FV);  /* per-ray limits / disparity spacing at 96+96: the LDS-resident coarse column */ \
     } while (0)
 #define P3D_LAUNCH_P(NFV) do { if (fast) P3D_LAUNCH_F(NFV, true); else P3D_LAUNCH_F(NFV, false); } while (0)
 #ifdef P3D_ONLY_NF  // development builds (tools/resource_usage.py -D P3D_ONLY_NF=48): compile ONE fine-depth capacity

@@ -1441,7 +1441,9 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
     }
     const float* nz = (p.epilogue && p.noise) ? p.noise + (p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + Xb : nullptr;
     float* yo = p.y + (nc * p.OH + Y) * p.OW + Xb;
-    const bool vec = (p.OW & 3) == 0;  // a row of 4-aligned width: the four outputs are one 16-byte store (Xb is a multiple of 4)
+    // a row of 4-aligned width: the four outputs are one 16-byte store (Xb is a multiple of 4) — provided the caller's y (and noise)
+    // are 16-byte aligned, which the C ABI does not demand of them: an offset view takes the scalar path
+    const bool vec = (p.OW & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)((p.epilogue && p.noise) ? p.noise : nullptr)) & 15) == 0;
     float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (nz) {
         if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(nz); nv[0] = t.x; nv[1] = t.y; nv[2] = t.z; nv[3] = t.w; }
@@ -1836,16 +1838,10 @@ int p3d_torgb_f32(const float* x, int N, int I, int H, int W, const float* w_t, 
     const bool ks = (long long)N * ((HW + 127) / 128) < 512;
     const size_t lds = (size_t)(2 * TG_KC * 32 * MT + ((I + 63) / 64) * 64) * 4;
     dim3 grid((unsigned)(ks ? (HW + 31) / 32 : (HW + 127) / 128), (unsigned)N);
-    hipError_t e = hipSuccess;
-#define P3D_TORGB(MTV, KSV)                                                                                              \
-    do {                                                                                                                 \
-        static bool attr_##MTV##KSV = false;                                                                             \
-        if (!attr_##MTV##KSV) { e = hipFuncSetAttribute((const void*)k_torgb<MTV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / 2); attr_##MTV##KSV = (e == hipSuccess); } \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_torgb<MTV, KSV>), grid, dim3(256), lds, (hipStream_t)stream, p);     \
-    } while (0)
+    if (lds > 64 * 1024) return P3D_E_RANGE;  // (53 KB at I = 1024, O = 96: inside the default dynamic-LDS limit, no per-device attribute to set)
+#define P3D_TORGB(MTV, KSV) hipLaunchKernelGGL((k_torgb<MTV, KSV>), grid, dim3(256), lds, (hipStream_t)stream, p)
     if (MT == 1) { if (ks) P3D_TORGB(1, true); else P3D_TORGB(1, false); }
     else { if (ks) P3D_TORGB(3, true); else P3D_TORGB(3, false); }
-    if (e != hipSuccess) return (int)e;
     return chk();
 }
 

@@ -12,12 +12,13 @@ import os
 import numpy as np
 import torch
 
-from . import cameras, stylegan2
+from . import cameras, memo, stylegan2
 from .renderer import ImportanceRenderer
 
 
 class OSGDecoder(torch.nn.Module):
-    """Parameter container of the tiny decoder MLP (triplane.py:516-547); it is evaluated inside the fused HIP kernels."""
+    """The tiny decoder MLP (triplane.py:516-547).  The renderer evaluates it INSIDE the fused kernels (it reads the parameters
+    only); `forward` keeps the module callable like the reference's, on the same device arithmetic (p3d_decode_features_f32)."""
 
     def __init__(self, n_features, options):
         super().__init__()
@@ -27,6 +28,15 @@ class OSGDecoder(torch.nn.Module):
         self.net = torch.nn.Sequential(stylegan2.FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr),
                                        torch.nn.Softplus(),
                                        stylegan2.FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=lr))
+
+    def forward(self, sampled_features, ray_directions, force_sigmoid=None):
+        """triplane.py:528-544: sampled_features [N,3,M,C] -> {'rgb': [N,M,32], 'sigma': [N,M,1]}; ray_directions are ignored, as
+        the reference's decoder ignores them."""
+        from . import ops
+        from .renderer import decoder_params
+        force_sigmoid = force_sigmoid or self.force_sigmoid
+        sigma, rgb = ops.decode_features(sampled_features.float().contiguous(), decoder_params(self), force_sigmoid=force_sigmoid)
+        return {"rgb": rgb, "sigma": sigma}
 
     def set_force_sigmoid(self, state):
         self.force_sigmoid = state
@@ -106,7 +116,7 @@ class TriPlaneGenerator(torch.nn.Module):
     def __getstate__(self):
         """Pickling / deep copies (the reference snapshots G): derived tensors and per-call state stay out."""
         state = dict(self.__dict__)
-        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo"):
+        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo", "_conv_domain_flag"):
             if k in state:
                 state[k] = None
         return state
@@ -245,7 +255,7 @@ class TriPlaneGenerator(torch.nn.Module):
                 # parameter versions, the conditioning tensors it uses (object + version, strong references) — one entry deep.
                 rc = self.backbone.mapping.resnet_cond
                 pose_free = bool(self.rendering_kwargs.get("c_gen_conditioning_zero", False)) or self.c_dim == 0
-                if pose_free and latent_injection is None:
+                if pose_free and latent_injection is None and memo.enabled():
                     ct = [x["cond"]["resnet_feats"]] if rc > 0 else []
                     ws_key = (tuple(int(s) for s in x["seeds"]), float(truncation_psi), truncation_cutoff, str(device), dtype,
                               tuple((id(t), t._version) for t in ct),
@@ -278,7 +288,8 @@ class TriPlaneGenerator(torch.nn.Module):
                 x["fovs"] = torch.full_like(x["elevations"], 30)
                 host["fovs"] = [30.0] * nv
             vals = [host[k] for k in ("elevations", "azimuths", "distances", "fovs")]
-            views = [cameras.cached_view(e, a, d, fv, res, self.rendering_kwargs["box_warp"], device, dtype) for e, a, d, fv in zip(*vals)]
+            view_of = cameras.cached_view if memo.enabled() else cameras.make_view
+            views = [view_of(e, a, d, fv, res, self.rendering_kwargs["box_warp"], device, dtype) for e, a, d, fv in zip(*vals)]
             x["camera_params"] = torch.stack([v[0] for v in views])
             if force_rays is None:
                 x["force_rays"] = force_rays = {"ray_origins": torch.stack([v[1] for v in views]),
@@ -340,24 +351,38 @@ class TriPlaneGenerator(torch.nn.Module):
         """Give every modulated 3x3 layer of THIS generator one flag word (owned by the generator, on its device) that the two-term
         f16 convolutions raise when a modulated activation leaves their domain |s*x| <= 4094.  Per generator, not per process:
         two generators on two streams do not share it (the C ABI keeps no such state, include/panic3d_hip.h ABI 5)."""
-        from . import ops
         device = device if device is not None else next(self.parameters()).device
-        flag = ops.conv_domain_flag(device)
+        flags = stylegan2.DomainFlags()  # one word per device, created where a layer runs (the generator may be moved later)
         for m in list(self.backbone.modules()) + list(self.superresolution.modules()):
-            if isinstance(m, stylegan2.SynthesisLayer):
-                m.conv_domain_flag = flag
-        self._conv_domain_flag = flag
-        return flag
+            if isinstance(m, (stylegan2.SynthesisLayer, stylegan2.ToRGBLayer)):
+                m.conv_domain_flag = flags
+        self.__dict__["_conv_domain_flag"] = flags
+        return flags.get(device)
 
     def conv_domain_violated(self, reset=True):
         """True if a two-term convolution of this generator saturated an operand since the last reset (synchronises).  The flag is
         created on first use: convolutions that ran before `watch_conv_domain()` were not watched."""
         from . import ops
-        flag = getattr(self, "_conv_domain_flag", None)
-        if flag is None or flag.device != next(self.parameters()).device:
+        flags = self.__dict__.get("_conv_domain_flag")
+        if flags is None:
             self.watch_conv_domain()
             return False
-        return ops.conv_domain_violated(flag, reset)
+        return any([ops.conv_domain_violated(w, reset) for w in list(flags.words.values())])  # (a list: every device's word is read and reset)
+
+    def clear_memo(self):
+        """Drop everything this generator remembers between calls — the memoised latents, both StylePlans (styles and the
+        parameter-derived tables), the prepared conditioning, the cached planes and their channels-last copy, every layer's derived
+        weights — and the process-wide view cache.  For callers that wrote into parameters or conditioning tensors behind the
+        version counter (`.data`, DLPack aliases; memo.py), and for servers that want the last subject's tensors released."""
+        self.__dict__["_ws_memo"] = None
+        self._last_planes = None
+        self.renderer._planes_cache = (None, None, None)
+        for m in self.modules():
+            for k in stylegan2._CACHE_ATTRS:
+                if k != "conv_domain_flag":
+                    m.__dict__.pop(k, None)
+            m.__dict__.pop("_style_plan", None)
+        cameras.cached_view_clear()
 
     def set_force_sigmoid(self, state):
         return self.decoder.set_force_sigmoid(state)

@@ -10,7 +10,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, memo
 from ._lib import Opts, Dumps
 
 __all__ = ["make_opts", "prescale_mlp", "planes_to_nhwc", "triplane_decode", "render", "sample_stratified", "composite",
@@ -138,6 +138,22 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
         rc = _lib.lib().p3d_triplane_decode_f32(_p(planes_nhwc), N, H, W, _p(coords), M, _p(w0), _p(b0), _p(w1), _p(b1),
                                                 C.byref(opts), _p(sigma), _p(rgb), _stream())
     _lib.check(rc, "p3d_triplane_decode_f32")
+    return sigma, rgb
+
+
+def decode_features(feats, mlp, force_sigmoid=True):
+    """OSGDecoder.forward (training/triplane.py:528-544) on sampled features [N,3,M,32] -> sigma [N,M,1], rgb [N,M,32]."""
+    feats = _chk(feats, "sampled_features")
+    if feats.dim() != 4 or feats.shape[1] != 3 or feats.shape[3] != 32:
+        raise RuntimeError("sampled_features must be [N,3,M,32]")
+    N, _, M, _ = feats.shape
+    w0, b0, w1, b1 = _chk_mlp(mlp)
+    sigma = torch.empty((N, M, 1), dtype=torch.float32, device=feats.device)
+    rgb = torch.empty((N, M, 32), dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        rc = _lib.lib().p3d_decode_features_f32(_p(feats), N, M, _p(w0), _p(b0), _p(w1), _p(b1), int(bool(force_sigmoid)), _p(sigma),
+                                                _p(rgb), _stream())
+    _lib.check(rc, "p3d_decode_features_f32")
     return sigma, rgb
 
 
@@ -487,7 +503,7 @@ def prepared_filter(f, device, gain=1.0, flip_filter=False):
     once per (filter tensor object, version, gain, flip): the reference rebuilds it on every call (three tiny launches)."""
     key = (id(f), str(device), float(gain), bool(flip_filter))
     hit = _FIR_CACHE.get(key)
-    if hit is not None and hit[0]() is f and hit[1] == f._version:
+    if memo.enabled() and hit is not None and hit[0]() is f and hit[1] == f._version:
         return hit[2]
     ff = f.detach().to(device, torch.float32) * float(gain)
     if not flip_filter:

@@ -17,7 +17,7 @@ import weakref
 
 import torch
 
-from . import ops
+from . import memo, ops
 
 
 # The final pass of the fused renderer may run in its tolerance mode (P3D_FLAG_FAST_COLOR: f16 two-term MFMA + hardware
@@ -48,7 +48,7 @@ class ImportanceRenderer(torch.nn.Module):
         # same tensor OBJECT (weak reference) at the same version is rendered again — generate.py renders 16 views per
         # subject.  (Keying on data_ptr would alias a freed tensor whose storage the caching allocator handed out again.)
         ref, version, cached = self._planes_cache
-        if ref is not None and ref() is planes and version == planes._version:
+        if memo.enabled() and ref is not None and ref() is planes and version == planes._version:
             return cached
         if planes.dim() == 5 and planes.shape[0] > 1 and planes.stride(0) == 0:
             planes_src = planes[:1]  # planes.expand(N, ...): one subject, N views -> one shared channels-last copy

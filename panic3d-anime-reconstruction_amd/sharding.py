@@ -10,6 +10,12 @@ import sys
 import torch
 import torch.distributed as dist
 
+# RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails with "invalid argument" otherwise), and the HSA
+# runtime reads the variable when it initialises — i.e. at the first HIP call of the process, long after this import.  Set here for
+# EVERY way a rank can come to life (an external torch.distributed.run, ensure_ranks' own re-exec, a test's subprocess); a value the
+# user exported wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def ensure_ranks(gpus, argv=None):
     """`--gpus N` of bench.py / tools/sweep360.py / tools/bench_c5.py: make sure N ranks exist, one process per GPU.
@@ -120,8 +126,10 @@ class FrameGather:
     every rank must push the same [lo, hi) sequence.  With 8 ranks at 512^2 x RGBA fp32 this hides 5.9 GB of inbound frames per 200-view sweep
     behind rendering instead of paying them after it."""
 
-    def __init__(self, local, per_rank, dst=0):
-        self.local, self.per_rank, self.dst = local, int(per_rank), int(dst)
+    def __init__(self, local, per_rank, dst=0, force=False):
+        """force: go through the collective also when the group has ONE rank (tests on a 1-GPU box: the communicator, the
+        asynchronous gather and the in-place receive buffers are exercised on RCCL; default: a plain copy)."""
+        self.local, self.per_rank, self.dst, self.force = local, int(per_rank), int(dst), bool(force)
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.active else 1
         self.rank = dist.get_rank() if self.active else 0
@@ -135,7 +143,7 @@ class FrameGather:
         # exception only dst sees — would leave the others inside gather()): P3D_GATHER_P2P=1 or a backend without gather(),
         # then the maximum over ranks, which is also the group-wide collective that has to precede the first P2P batch
         want = os.environ.get("P3D_GATHER_P2P", "0") == "1" or (self.active and dist.get_backend() not in ("nccl", "gloo"))
-        if self.active and self.world > 1:
+        if self.active and (self.world > 1 or self.force):
             flag = torch.tensor([1.0 if want else 0.0], device=local.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             want = bool(flag.item() > 0)
@@ -146,7 +154,7 @@ class FrameGather:
         """Frames [lo, hi) of every rank's stack are final: start moving them."""
         if not (0 <= lo < hi <= self.per_rank):
             raise ValueError(f"slice [{lo}, {hi}) outside [0, {self.per_rank})")
-        if not self.active or self.world == 1:
+        if not self.active or (self.world == 1 and not self.force):
             if self.out is not None:
                 self.out[lo:hi].copy_(self.local[lo:hi])
             return
@@ -159,7 +167,9 @@ class FrameGather:
         if self.rank != self.dst:
             self.pending += dist.batch_isend_irecv([dist.P2POp(dist.isend, self.local[lo:hi], self.dst)])
             return
-        self.pending += dist.batch_isend_irecv([dist.P2POp(dist.irecv, dests[r], r) for r in range(self.world) if r != self.dst])
+        recvs = [dist.P2POp(dist.irecv, dests[r], r) for r in range(self.world) if r != self.dst]
+        if recvs:  # (a one-rank group has nobody to receive from)
+            self.pending += dist.batch_isend_irecv(recvs)
         dests[self.dst].copy_(self.local[lo:hi])
 
     def finish(self):

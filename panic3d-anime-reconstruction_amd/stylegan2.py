@@ -13,12 +13,12 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import memo, ops
 
 SQRT2 = float(np.sqrt(2))
 
 # derived tensors the modules keep as plain attributes (never part of the state_dict, dropped when pickled / deep-copied)
-_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan", "_cond_cache")
+_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan", "_cond_cache", "conv_domain_flag")
 
 
 class _CacheFree(torch.nn.Module):
@@ -49,7 +49,7 @@ class FullyConnectedLayer(_CacheFree):
         the same two multiplications the reference does on every call (inference: the parameters do not change), so the
         values are bit-identical.  Plain attributes, not buffers: the state_dict stays the reference's."""
         key = (dtype, self.weight.data_ptr(), self.weight._version, None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
-        if getattr(self, "_scaled_key", None) != key:
+        if getattr(self, "_scaled_key", None) != key or not memo.enabled():
             w = self.weight.detach().to(dtype) * self.weight_gain
             b = self.bias
             if b is not None:
@@ -147,9 +147,31 @@ def _f16_operand(layer):
     if not mode or layer.in_channels % 16 != 0:
         return None
     key = (layer.weight.data_ptr(), layer.weight._version, mode)
-    if getattr(layer, "_wh_key", None) != key:
+    if getattr(layer, "_wh_key", None) != key or not memo.enabled():
         layer._wh, layer._wh_key = ops.conv_weights_to_f16(layer.weight.detach(), split=(mode == "x2")), key
     return layer._wh
+
+
+class DomainFlags:
+    """The out-of-domain flag words of one generator's two-term convolutions (TriPlaneGenerator.watch_conv_domain): one int32 word
+    PER DEVICE, created when a layer first runs there — a generator moved with .to(device) keeps being watched (one
+    tensor on the device of the moment made every forward after G.to(other) raise).  Shared by the generator's layers; never
+    pickled (the attribute is in _CACHE_ATTRS) — a copy of the generator is unwatched until it asks."""
+
+    def __init__(self):
+        self.words = {}
+
+    def get(self, device):
+        device = torch.device(device)
+        w = self.words.get(device)
+        if w is None:
+            w = self.words[device] = ops.conv_domain_flag(device)
+        return w
+
+
+def _domain_flag(layer, device):
+    f = getattr(layer, "conv_domain_flag", None)
+    return f.get(device) if isinstance(f, DomainFlags) else f  # (a bare int32 tensor set by hand is still honoured)
 
 
 class SynthesisLayer(_CacheFree):
@@ -172,7 +194,7 @@ class SynthesisLayer(_CacheFree):
         """`noise_const * noise_strength` (networks_stylegan2.py:346), once per parameter version instead of once per call."""
         key = (self.noise_const.data_ptr(), self.noise_const._version, self.noise_strength.data_ptr(), self.noise_strength._version)
         hit = getattr(self, "_noise_cache", None)
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != key or not memo.enabled():
             hit = (key, (self.noise_const * self.noise_strength.detach()).contiguous())
             self._noise_cache = hit
         return hit[1]
@@ -191,8 +213,8 @@ class SynthesisLayer(_CacheFree):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
-                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None),
-                                    dcoef=dcoef, next_styles=next_styles)
+                                    act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self),
+                                    saturated=_domain_flag(self, x.device), dcoef=dcoef, next_styles=next_styles)
 
 
 class ToRGBLayer(_CacheFree):
@@ -212,11 +234,11 @@ class ToRGBLayer(_CacheFree):
                 and x.shape[-2] % 2 == 0:
             # the dedicated GEMM kernel (p3d_torgb_f32): the activation is read once, the skip image is added in the same launch
             key = (self.weight.data_ptr(), self.weight._version)
-            if getattr(self, "_wt_key", None) != key:
+            if getattr(self, "_wt_key", None) != key or not memo.enabled():
                 self._wt, self._wt_key = ops.torgb_weights(self.weight.detach()), key
             return ops.torgb(x, self._wt, self.weight.shape[0], styles, bias=self.bias, clamp=self.conv_clamp, skip=skip, skip_filter=skip_filter)
         y = ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
-                                 clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=getattr(self, "conv_domain_flag", None))
+                                 clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=_domain_flag(self, x.device))
         return ops.upsample2d_add(skip, skip_filter, y) if skip is not None else y
 
 
@@ -294,12 +316,12 @@ class StylePlan:
         dev = ws.device
         key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias.data_ptr(), l.affine.bias._version,
                      l.weight.data_ptr(), l.weight._version) for _, _, l, _ in self.entries) + (str(dev),)
-        if key != self._key:
+        if key != self._key or not memo.enabled():
             self._build(dev)
             self._key = key
             self._memo = None
         memo = getattr(self, "_memo", None)
-        if not STYLE_MEMO:
+        if not (STYLE_MEMO and memo.enabled()):
             memo_of = None
         if memo_of is not None and memo is not None and memo[0] is memo_of and memo[1] == memo_of._version and memo[2] == tuple(ws.shape):
             return memo[3]
@@ -413,6 +435,8 @@ class SynthesisNetwork(_CacheFree):
     def _cond_prepared(self, key, tensors, make):
         """make() cached under `key` for exactly these tensor OBJECTS at their current versions (strong references are kept, so
         a hit can never be another tensor that reused an address)."""
+        if not memo.enabled():
+            return make()
         cache = self.__dict__.setdefault("_cond_cache", {})
         hit = cache.get(key)
         if hit is not None and len(hit[0]) == len(tensors) and all(a is b and v == b._version for (a, v), b in zip(hit[0], tensors)):
@@ -421,9 +445,22 @@ class SynthesisNetwork(_CacheFree):
         cache[key] = ([(t, t._version) for t in tensors], val)
         return val
 
+    def clear_cond_cache(self):
+        """Drop the prepared conditioning terms (they hold strong references to the last subject's conditioning images and their
+        resized copies: a long-running server calls this between subjects, or when it is done; G.to(device) does it too)."""
+        self.__dict__.pop("_cond_cache", None)
+
+    def _apply(self, fn):  # .to() / .cuda() / .float(): prepared terms live on the old device
+        self.clear_cond_cache()
+        self.__dict__.pop("_style_plan", None)
+        return super()._apply(fn)
+
     def _condition(self, lvl, res, x, img, cond, cm, chonkadd):
+        """x, img: the block's FRESH outputs — owned by this call, written in place below.  (Inference only: under autograd, or if a
+        caller ever aliased a block output, the in-place adds would be visible through the alias; the blocks return new tensors.)"""
         if self.cond_mode == "none":
             return x, img
+        assert not (torch.is_grad_enabled() and (x.requires_grad or img.requires_grad)), "inference only: the conditioning is applied in place"
         if res == 8 and chonkadd > 0:  # resnet "chonk" added to the first channels of the 8x8 activations (:554-560)
             k = chonkadd
             x[:, :k].add_(cond["resnet_chonk"][:, :k])

@@ -214,6 +214,19 @@ def decode_case():
              planes_checksum=np.array(T.checksum(planes)), pts_checksum=np.array(T.checksum(pts)))
 
 
+def decoder_forward_case():
+    """OSGDecoder.forward itself (training/triplane.py:528-544) on sampled features [N,3,M,32] — the module's own call surface,
+    which our OSGDecoder.forward / p3d_decode_features_f32 mirror: both sigmoid branches, lr_mul 1 and 0.5."""
+    seed = 40
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(2, 3, 777, 32, generator=g) * 2.0
+    for tag, lr_mul, fs in (("a", 1.0, True), ("b", 0.5, False)):
+        dec = ref_decoder(seed + 1, lr_mul, fs, sigma_gain=5.0)
+        out = dec(feats, None)
+        save(f"decoder_forward_{tag}.npz", sigma=out["sigma"].numpy(), rgb=out["rgb"].numpy(), meta_seed=np.array(seed),
+             meta_lr_mul=np.array(lr_mul), meta_force_sigmoid=np.array(int(fs)), feats_checksum=np.array(T.checksum(feats.numpy())))
+
+
 def stage_cases():
     g = torch.Generator().manual_seed(20)
     NR, S, K = 256, 24, 35
@@ -273,6 +286,7 @@ def main():
     render_case("render_variant_b.npz", res=16, Sc=20, Sf=8, seed=600, binarize=0.4, cull=None, crop=0.05, plane_scale=4.0, smooth=8, sigma_gain=20.0,
                 ray_start=0.6, ray_end=1.4)
     decode_case()
+    decoder_forward_case()
     stage_cases()
     ray_cases()
     auto_case()
@@ -294,5 +308,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "auto":  # only the fixture added in round 2 (the others are unchanged)
         torch.set_num_threads(8)
         auto_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "decoder":  # only the fixtures added in round 4
+        decoder_forward_case()
     else:
         main()

@@ -8,10 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "panic3d-anime-reconstruction_amd")
 
 
-def build_example(out):
+def build_example(out, src="render_c_abi.cpp"):
     import panic3d_amd
     panic3d_amd.build()
-    cmd = [panic3d_amd._build._hipcc(), "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "examples", "render_c_abi.cpp"),
+    cmd = [panic3d_amd._build._hipcc(), "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "examples", src),
            "-I", os.path.join(ROOT, "include"), "-L", PKG, "-lpanic3d_hip", f"-Wl,-rpath,{PKG}", "-o", out]
     subprocess.check_call(cmd)
     return out
@@ -22,6 +22,37 @@ def test_example_builds_against_the_header_only(tmp_path):
     assert os.path.getsize(exe) > 0
     src = open(os.path.join(ROOT, "examples", "render_c_abi.cpp")).read()
     assert "torch" not in src.replace("PyTorch", "") and '#include "panic3d_hip.h"' in src
+    exe2 = build_example(str(tmp_path / "synthesis_c_abi"), "synthesis_c_abi.cpp")
+    assert os.path.getsize(exe2) > 0
+    src2 = open(os.path.join(ROOT, "examples", "synthesis_c_abi.cpp")).read()
+    assert "torch" not in src2.replace("PyTorch", "").replace("torgb", "") and '#include "panic3d_hip.h"' in src2
+
+
+def test_struct_mirrors_match_the_library():
+    """The four POD structs of include/panic3d_hip.h are restated by hand in _lib.py (ctypes); p3d_struct_layout reports the
+    layout the library was compiled with — sizeof and every field offset in declaration order — and lib() refuses to load on any
+    difference.  No GPU needed: host code of the library."""
+    import ctypes as C
+    import panic3d_amd
+    L = panic3d_amd._lib.lib()  # (runs check_struct_layouts)
+    buf = (C.c_size_t * 64)()
+    for which, cls in panic3d_amd._lib.STRUCT_MIRRORS.items():
+        n = L.p3d_struct_layout(which, buf, 64)
+        assert n == 1 + len(cls._fields_), cls.__name__
+        assert buf[0] == C.sizeof(cls)
+        assert [buf[1 + i] for i in range(n - 1)] == [getattr(cls, f).offset for f, _ in cls._fields_]
+    assert L.p3d_struct_layout(0, buf, 2) == -2 and L.p3d_struct_layout(7, buf, 64) == -2 and L.p3d_struct_layout(0, None, 64) == -1
+
+    class Wrong(C.Structure):  # a mirror that lost a field is caught (what p3d_abi_version alone would not see)
+        _fields_ = [f for f in panic3d_amd._lib.ConvArgs._fields_ if f[0] != "x_img"]
+    saved = dict(panic3d_amd._lib.STRUCT_MIRRORS)
+    try:
+        panic3d_amd._lib.STRUCT_MIRRORS[3] = Wrong
+        with pytest.raises(RuntimeError, match="does not match"):
+            panic3d_amd._lib.check_struct_layouts(L)
+    finally:
+        panic3d_amd._lib.STRUCT_MIRRORS.clear()
+        panic3d_amd._lib.STRUCT_MIRRORS.update(saved)
 
 
 @pytest.mark.gpu
@@ -56,3 +87,57 @@ def test_cpp_host_renders_the_same_bytes(tmp_path, oracle):
     for name, a, b in zip(("feat", "depth", "wsum", "xyz"), ref, orc):
         got = np.fromfile(os.path.join(d, name + ".bin"), dtype=np.float32).reshape(b.shape)
         assert np.array_equal(got, a.cpu().numpy()) and np.array_equal(got, b), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("up", [1, 2])
+def test_cpp_host_runs_a_synthesis_layer_and_torgb(tmp_path, up):
+    """examples/synthesis_c_abi.cpp: p3d_conv_weights_to_f16x2 + p3d_modconv2d_ex_f32 (the struct entry) + p3d_torgb_weights_f32 +
+    p3d_torgb_f32 from C++, on the bytes the Python host (ops.modulated_conv2d / ops.torgb, i.e. stylegan2.SynthesisLayer / ToRGBLayer)
+    gets: identical outputs, and its own sizeof / offsetof of the four structs equal p3d_struct_layout."""
+    import torch
+    import panic3d_amd as P
+    g = torch.Generator().manual_seed(70 + up)
+    N, I, O, H, W, ORGB = 2, 64, 64, 32, 32, 96
+    OH, OW = H * up, W * up
+    x = torch.randn(N, I, H, W, generator=g)
+    w = torch.randn(O, I, 3, 3, generator=g)
+    styles = torch.randn(N, I, generator=g) * 0.5 + 1.0
+    noise = torch.randn(OH, OW, generator=g) * 0.1
+    bias = torch.randn(O, generator=g) * 0.2
+    wrgb = torch.randn(ORGB, O, 1, 1, generator=g)
+    srgb = (torch.randn(N, O, generator=g) * 0.5 + 1.0) / np.sqrt(O)
+    brgb = torch.randn(ORGB, generator=g) * 0.2
+    skip = torch.randn(N, ORGB, OH // 2, OW // 2, generator=g)
+    filt = P.ops.setup_filter((1, 3, 3, 1))
+    fir = P.ops.prepared_filter(filt.cuda(), torch.device("cuda"), 4.0, False).cpu()
+    d = str(tmp_path)
+    for name, a in (("x", x), ("w", w), ("styles", styles), ("noise", noise), ("bias", bias), ("fir", fir), ("wrgb", wrgb), ("srgb", srgb),
+                    ("brgb", brgb), ("skip", skip)):
+        a.contiguous().numpy().astype(np.float32).tofile(os.path.join(d, name + ".bin"))
+    with open(os.path.join(d, "meta.txt"), "w") as f:
+        f.write(f"{N} {I} {O} {H} {W} {up} {ORGB}")
+    exe = build_example(os.path.join(d, "synthesis_c_abi"), "synthesis_c_abi.cpp")
+    out = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "struct layouts agree" in out.stdout
+    c = lambda t: t.cuda().contiguous()
+    y = P.ops.modulated_conv2d(c(x), c(w), c(styles), noise=c(noise), up=up, padding=1, resample_filter=c(filt), demodulate=True, bias=c(bias),
+                               act="lrelu", gain=float(np.sqrt(2)), weight_f16=P.ops.conv_weights_to_f16(c(w), split=True))
+    img = P.ops.torgb(y, P.ops.torgb_weights(c(wrgb)), ORGB, c(srgb), bias=c(brgb), skip=c(skip), skip_filter=c(filt))
+    got_y = np.fromfile(os.path.join(d, "y.bin"), dtype=np.float32).reshape(N, O, OH, OW)
+    got_i = np.fromfile(os.path.join(d, "img.bin"), dtype=np.float32).reshape(N, ORGB, OH, OW)
+    assert np.array_equal(got_y, y.cpu().numpy())
+    assert np.array_equal(got_i, img.cpu().numpy())
+    # and the layer is the reference's modulated_conv2d (networks_stylegan2.py:40-97) + bias_act, restated in plain torch fp32
+    xs = c(x) * c(styles)[:, :, None, None]
+    dco = ((c(w)[None] * c(styles)[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt()
+    if up == 1:
+        ref = torch.nn.functional.conv2d(xs, c(w), padding=1)
+    else:
+        ref = torch.nn.functional.conv_transpose2d(xs, c(w).transpose(0, 1), stride=2)  # flip_weight = (up == 1): networks_stylegan2.py:346
+        f4 = c(fir)[None, None].repeat(O, 1, 1, 1)
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(ref, (1, 1, 1, 1)), f4, groups=O)
+    ref = ref * dco[:, :, None, None] + c(noise)[None, None] + c(bias)[None, :, None, None]
+    ref = torch.nn.functional.leaky_relu(ref, 0.2) * float(np.sqrt(2))
+    assert float((y - ref).abs().max()) <= 3e-6 * np.sqrt(9 * I) * float(ref.abs().max())

@@ -42,6 +42,15 @@ def _check_line(d, steps):
         assert r["peak"] == 8000.0 and abs(r["achieved"] - hbm_equiv) < 1e-6 * hbm_equiv
     else:  # the yardstick exceeded the HBM peak: relabelled to the L2-level gather fraction, contract figure kept beside it
         assert r["peak"] == 34500.0 and abs(r["hbm_algorithmic_equiv_frac"] - hbm_equiv / 8000.0) < 1e-6 and hbm_equiv > 8000.0
+    # the three readings that keep `frac` from being mistaken for a measured HBM fraction
+    assert abs(r["frac_timed"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert r["compulsory_bytes_per_launch"] == 3 * 32 * 256 * 256 * 4 + 512 * 512 * 172
+    if r["traffic"]:
+        assert abs(r["hbm_measured_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and r["hbm_measured_frac"] < 1.0
+        assert abs(r["traffic_over_compulsory"] - r["traffic"] / r["compulsory_bytes_per_launch"]) < 1e-9
+    else:
+        assert r["hbm_measured_frac"] is None and r["traffic_over_compulsory"] is None
+    assert "checkpoint ecrutileE_eclustrousC_n120" in d["config"]["workload"] and "absent" in d["config"]["workload"]
     ph = r["physical"]["l2_gather"]
     assert 0 < ph["frac_no_early_out"] <= 1.0 and 0 < ph["frac_timed"] <= 1.0
     v = d["verify"]
@@ -61,6 +70,12 @@ def test_bench_default_invocation_prints_the_contract_line():
     assert rows == {(s, m) for s in ("canonical", "surface") for m in ("exact", "tolerance")}
     assert all(r["kernel_ms"] > 0 and r["kernel_ms_no_early_out"] > 0 and 0 < r["decode_steps_executed_frac"] <= 1 for r in d["results"])
     assert len(d["eval_faithful"]["rows"]) == 4 and all(r["Sc"] == 96 and r["Sf"] == 96 for r in d["eval_faithful"]["rows"])
+    # the representative (surface-scene, exact) numbers sit at the top level, next to the 8(d) headline
+    rs = next(r for r in d["results"] if r["scene"] == "surface" and r["mode"] == "exact")
+    rf = next(r for r in d["eval_faithful"]["rows"] if r["scene"] == "surface" and r["mode"] == "exact")
+    assert d["value_surface"] == rs["rays_per_s"] and d["ms_per_step_surface"] == rs["ms_per_step"] and d["kernel_ms_surface"] == rs["kernel_ms"]
+    assert d["value_surface_96p96"] == rf["rays_per_s"] and d["ms_per_step_surface_96p96"] == rf["ms_per_step"]
+    assert rs["hit_fraction"] > 0.3 and d["hit_fraction"] == 0.0 and "empty volume" in d["surface_note"]
     assert d["sustained"]["seconds"] >= 2.0 and d["sustained"]["sustained_ms_per_step"] > 0
     assert d["device_rng"]["ms_per_step"] > 0 and d["device_rng"]["kernel_ms"] > 0  # the opt-in in-kernel draws, beside the contract step
     rec = d["roofline"]["recorded"]  # PMC numbers are builder-recorded and say so; absent capture -> nulls, never stale numbers
@@ -76,7 +91,10 @@ def test_bench_under_torch_distributed_run_streams_the_frames():
     assert len(d["per_rank"]["ms_per_step_render"]) == 1 and len(d["per_rank"]["gather_ms"]) == 1
     assert "slices sent while the next frames render" in d["config"]["workload"]
     assert d["n_ranks_seen"] == 1
+    g = d["gather"]
+    assert g["mode"].startswith("streamed") and g["bytes_into_rank0"] == 0 and g["frame_bytes"] == 512 * 512 * 16 and g["exposed_ms_max"] >= 0
+    assert g["backend"].startswith("nccl")
     e = _bench(SMALL + ["--no-cpu-baseline", "--no-table", "--gather", "end", "--fast"], launched=True)
     _check_line(e, 6)
     assert e["dtype"].startswith("f32 (final-pass MLP operands as two-term f16") and "ONE gather" in e["config"]["workload"]
-    assert "results" not in e
+    assert "results" not in e and "value_surface" not in e and e["gather"]["mode"].startswith("end")

@@ -173,3 +173,22 @@ def test_degenerate_triangles_are_dropped_like_skimage_allow_degenerate_false(hi
     assert key(tri[~deg0]) == key(tri1)
     out = hip.volume.marching_cubes(vol, None, 0.7, level=25.0)  # the mirror of eg3d_metrics3d.marching_cubes: drops them by default
     assert out["faces"].shape[0] == f1.shape[0] and out["verts"].shape[0] == v1.shape[0]
+
+
+def test_hip_mesh_scores_like_the_reference_evaluation(hip):
+    """parity with skimage's Lewiner triangulation stays unpinned (skimage is not installable here), so the
+    HIP extractor is held to what the reference's evaluation actually computes from a mesh — surface-sample chamfer distance and F1
+    at the thresholds of _scripts/eval/measure.py:187-201 — against an analytic sphere, through volume.marching_cubes (the
+    reference's vertex scaling, eg3d_metrics3d.py:201-202)."""
+    from test_mcubes_cpu import world_mesh_of_sphere, mesh_scores_against_sphere, F1_THRESHOLDS
+    n, r, bw = 96, 0.24, 0.7
+
+    def extract(vol):
+        m = hip.volume.marching_cubes(dev(vol), None, bw, level=0.0)
+        return (m["verts"] + bw / 2) / bw * n, m["faces"]  # back to index space: world_mesh_of_sphere applies the scaling itself
+    verts, faces, centre = world_mesh_of_sphere(n, r, extract, bw)
+    s = mesh_scores_against_sphere(verts.astype(np.float64), faces.astype(np.int64), centre.astype(np.float64), r, n_sample=1500)
+    assert s["cd"] < 0.05 * (bw / n), s
+    assert all(s[f"f1_{int(th * 1000):03d}"] == 1.0 for th in F1_THRESHOLDS), s
+    uniq, cnt, has_rev = edge_stats(faces.astype(np.int64))
+    assert (cnt == 1).all() and has_rev.all()  # closed, consistently oriented

@@ -383,6 +383,44 @@ def _random_config(seed):
                 tile_w=(side if side else 0), early_out=bool(rng.integers(0, 2)))
 
 
+@pytest.mark.parametrize("branch", ["auto_limits", "disparity", "plain"])
+@pytest.mark.parametrize("fast", [False, True])
+def test_96p96_large_launch_kernel_honours_ray_limits_and_disparity(hip, oracle, branch, fast):
+    """the production 96+96 kernel of LARGE launches keeps no coarse-depth column (TCG) and recomputes a
+    stratified depth from the fixed ray_start / ray_end spacing; with per-ray limits (ray_start = 'auto', renderer.py:165-171,
+    317-319) or disparity spacing (:309-316) it must therefore not be launched — until round 4 it was, silently.  The
+    32-rays-per-wave kernel forced on a small image (what a > 512-tile launch gets), early-outs on, no dumps: exact mode bit for
+    bit against the oracle, tolerance mode within its stated bound."""
+    seed, res, Sc, Sf = 4100, 16, 96, 96
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    limits = None
+    label = hip.cameras.camera_label(10.0, 35.0, 1.0, 30.0)
+    o, d = hip.cameras.rays_from_label(label[None], res)
+    if branch == "auto_limits":
+        ro["ray_start"] = ro["ray_end"] = "auto"
+        rs, re = hip.cameras.patch_ray_limits(*hip.cameras.ray_limits_box(o.cuda(), d.cuda(), ro["box_warp"]))
+        limits = (rs.reshape(1, -1).cpu().numpy(), re.reshape(1, -1).cpu().numpy())
+    elif branch == "disparity":
+        ro["disparity_space_sampling"] = True
+    planes = T.make_planes(seed, 1, 64, 64, scale=4.0, smooth=8)
+    raw = T.make_decoder_params(seed + 1, 1.0, 30.0)
+    jit, u = T.make_random_draws(seed + 2, 1, res * res, Sc, Sf, auto_limits=branch == "auto_limits")
+    kw = dict(triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+    ref = oracle.render(planes, o.numpy(), d.numpy(), jit, u, oracle.prescale_mlp(*raw), oracle.make_opts(ro, **kw), ray_limits=limits)
+    st = {}
+    out = hip.ops.render(hip.ops.planes_to_nhwc(dev(planes)), o.cuda(), d.cuda(), dev(jit), dev(u), hip_mlp(hip, raw, 1.0),
+                         hip.ops.make_opts(ro, small_launch_kernel=False, early_out=True, fast_color=fast, **kw), ray_tile_w=res,
+                         stats=st, ray_limits=None if limits is None else tuple(dev(x) for x in limits))
+    assert st["small_launch_kernel"] is False
+    for name, a, b, tol in zip(("feat", "depth", "wsum", "xyz"), out, ref, (1e-5, 2e-5, 1e-5, 1e-5)):
+        a = a.cpu().numpy()
+        if fast:
+            assert float(np.abs(a - b).max()) <= tol, (name, branch)
+        else:
+            assert np.array_equal(a, b), (name, branch, float(np.abs(a - b).max()))
+    assert float(ref[2].mean()) > 0.05  # the scene has surfaces: the depths matter
+
+
 @pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("seed", range(100, 124))
 def test_render_random_configs_bit_exact(hip, oracle, seed, pair):

@@ -336,3 +336,40 @@ def test_ray_limits_box_matches_the_reference(P):
     # no valid ray at all: nothing is patched (the reference's `if torch.any(is_ray_valid)`)
     a2, b2 = cameras.patch_ray_limits(torch.full((1, 4, 1), -1.0), torch.full((1, 4, 1), -2.0))
     assert torch.all(a2 == -1) and torch.all(b2 == -2)
+
+
+def test_no_memo_environment_variable_is_read_at_import():
+    import subprocess, sys
+    code = "import os, sys; sys.path.insert(0, %r); import panic3d_amd as P; print(int(P.memo.enabled()))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for val, want in (("1", "0"), ("0", "1"), (None, "1")):
+        env = {k: v for k, v in os.environ.items() if k != "P3D_NO_MEMO"}
+        if val is not None:
+            env["P3D_NO_MEMO"] = val
+        assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.strip() == want
+
+
+def test_sobel_restatement_against_a_dense_convolution_with_the_published_kernels():
+    """VERDICT r03 item 7 (f4).  kornia is not installable here, so `kornia.filters.sobel` (triplane.py:632,652) is restated — and until
+    round 4 the restatement (paste.sobel_magnitude, shifted slices; the HIP kernel is tested against it) was only ever compared with
+    itself.  This is an INDEPENDENT formulation of kornia 0.6.5's published definition: `spatial_gradient(mode='sobel', order=1,
+    normalized=True)` = a dense F.conv2d of the replicate-padded image with the 3x3 kernels
+        gx = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]] / 8,   gy = gx^T      (kornia.filters.kernels.get_sobel_kernel_3x3, normalize_kernel2d: / sum |k|)
+    per channel (groups = C), then sqrt(gx^2 + gy^2 + eps), eps = 1e-6.  Also checked: it is a CORRELATION (conv2d does not flip;
+    kornia flips the kernels once and F.conv3d un-flips them: the published gradient of a ramp rising to the right is positive)."""
+    import torch.nn.functional as F
+    from panic3d_amd import paste
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 37, 53, generator=g)
+    x[:, :, 10:20, 15:30] += 2.0  # edges
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+    k = torch.stack([kx, kx.t()])[:, None]  # [2,1,3,3]
+    C = x.shape[1]
+    xp = F.pad(x, [1, 1, 1, 1], mode="replicate")
+    gxy = F.conv2d(xp, k.repeat(C, 1, 1, 1), groups=C).reshape(2, C, 2, 37, 53)
+    dense = torch.sqrt(gxy[:, :, 0] ** 2 + gxy[:, :, 1] ** 2 + 1e-6)
+    mine = paste.sobel_magnitude(x)
+    assert mine.shape == dense.shape and float((mine - dense).abs().max()) < 1e-6
+    ramp = torch.arange(8.0)[None, None, None, :].repeat(1, 1, 8, 1)
+    r = F.conv2d(F.pad(ramp, [1, 1, 1, 1], mode="replicate"), k)
+    assert float(r[0, 0, 4, 4]) == 1.0 and float(r[0, 1, 4, 4]) == 0.0  # d/dx of a unit ramp = 1 after the /8 normalisation
+    assert abs(float(paste.sobel_magnitude(ramp)[0, 0, 4, 4]) - float(np.sqrt(1 + 1e-6))) < 1e-6

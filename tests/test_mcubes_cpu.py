@@ -100,3 +100,119 @@ def test_empty_and_full_volumes():
     for fill in (-1.0, 1.0):
         v, f, nrm, val = O.marching_cubes(np.full((6, 6, 6), fill, np.float32), 0.0)
         assert len(v) == 0 and len(f) == 0
+
+
+# ---- the downstream score the reference computes on a mesh: surface-sample chamfer distance and F1 at the
+# thresholds of _scripts/eval/measure.py:187-201, here between the extractor's mesh and an ANALYTIC surface (the triangulation is
+# this repo's own and unpinned against skimage; what the reference's evaluation sees of a mesh are these numbers) ---------------
+F1_THRESHOLDS = (0.005, 0.01, 0.05, 0.1, 0.5)  # measure.py:200
+
+
+def sample_mesh_surface(verts, faces, n, seed):
+    """n points uniformly on the mesh surface (area-weighted triangles, uniform barycentric coordinates)."""
+    rng = np.random.default_rng(seed)
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    tri = rng.choice(len(faces), size=n, p=area / area.sum())
+    r1, r2 = np.sqrt(rng.random(n))[:, None], rng.random(n)[:, None]
+    return (1 - r1) * a[tri] + r1 * (1 - r2) * b[tri] + r1 * r2 * c[tri]
+
+
+def point_triangle_distance(p, a, b, c):
+    """Exact distance from points p [P,3] to triangles (a, b, c) [F,3] -> [P,F] (Ericson, Real-Time Collision Detection 5.1.5:
+    closest point by Voronoi region), vectorised."""
+    ab, ac = (b - a)[None], (c - a)[None]
+    ap = p[:, None, :] - a[None]
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p[:, None, :] - b[None]
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p[:, None, :] - c[None]
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+    den = va + vb + vc
+    den = np.where(np.abs(den) < 1e-30, 1e-30, den)
+    v, w = vb / den, vc / den
+    q = a[None] + ab * v[..., None] + ac * w[..., None]  # interior
+    def put(mask, val):
+        nonlocal q
+        q = np.where(mask[..., None], val, q)
+    t_ab = np.clip(d1 / np.where(d1 - d3 == 0, 1, d1 - d3), 0, 1)
+    t_ac = np.clip(d2 / np.where(d2 - d6 == 0, 1, d2 - d6), 0, 1)
+    t_bc = np.clip((d4 - d3) / np.where((d4 - d3) + (d5 - d6) == 0, 1, (d4 - d3) + (d5 - d6)), 0, 1)
+    put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), b[None] + (c - b)[None] * t_bc[..., None])
+    put((vb <= 0) & (d2 >= 0) & (d6 <= 0), a[None] + ac * t_ac[..., None])
+    put((vc <= 0) & (d1 >= 0) & (d3 <= 0), a[None] + ab * t_ab[..., None])
+    put((d6 >= 0) & (d5 <= d6), np.broadcast_to(c[None], q.shape))
+    put((d3 >= 0) & (d4 <= d3), np.broadcast_to(b[None], q.shape))
+    put((d1 <= 0) & (d2 <= 0), np.broadcast_to(a[None], q.shape))
+    return np.linalg.norm(p[:, None, :] - q, axis=-1)
+
+
+def point_mesh_distance(p, verts, faces, k=24):
+    """Distance of every point to the mesh: exact point-triangle distance over the k triangles with the nearest centroids (scipy
+    cKDTree; on a fine, regular mesh the closest triangle is always among them)."""
+    from scipy.spatial import cKDTree
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    _, idx = cKDTree((a + b + c) / 3.0).query(p, k=min(k, len(faces)))
+    out = np.empty(len(p))
+    for i in range(0, len(p), 512):
+        ii = idx[i:i + 512]
+        pa, pb, pc = a[ii], b[ii], c[ii]  # [P,k,3]
+        d = np.stack([point_triangle_distance(p[i + j:i + j + 1], pa[j], pb[j], pc[j])[0] for j in range(len(ii))])
+        out[i:i + 512] = d.min(1)
+    return out
+
+
+def mesh_scores_against_sphere(verts, faces, centre, radius, n_sample=2000, seed=0):
+    """measure.py:187-201 with the ground-truth mesh replaced by an analytic sphere: p2s = distance of points sampled on the
+    predicted mesh to the sphere (closed form), s2p = distance of points sampled on the sphere to the predicted mesh."""
+    pred = sample_mesh_surface(verts, faces, n_sample, seed)
+    p2s = np.abs(np.linalg.norm(pred - centre, axis=1) - radius)
+    g = np.random.default_rng(seed + 1).standard_normal((n_sample, 3))
+    gt = centre + radius * g / np.linalg.norm(g, axis=1, keepdims=True)
+    s2p = point_mesh_distance(gt, verts, faces)
+    out = {"p2s": float(p2s.mean()), "s2p": float(s2p.mean()), "cd": float((p2s.mean() + s2p.mean()) / 2)}
+    for th in F1_THRESHOLDS:  # point_mesh_f1, measure.py:87-99
+        pre, rec = float((p2s <= th).mean()), float((s2p <= th).mean())
+        out[f"f1_{int(th * 1000):03d}"] = 0.0 if pre == rec == 0.0 else 2 * pre * rec / (pre + rec)
+    return out
+
+
+def world_mesh_of_sphere(n, radius_world, extract, bw=0.7):
+    """The extractor's mesh of a sphere's signed field sampled on the reference's n^3 lattice, scaled to world units the way
+    eg3d_metrics3d.py:201-202 scales skimage's vertices (/n * bw - bw/2, sic: n, not n - 1)."""
+    ax = (np.arange(n, dtype=np.float32) / n) * bw - bw / 2  # so that index i <-> world coordinate i / n * bw - bw / 2
+    x, y, z = np.meshgrid(ax, ax, ax, indexing="ij")
+    centre = np.array([0.013, -0.021, 0.008], np.float32)  # off-lattice
+    vol = (radius_world - np.sqrt((x - centre[0]) ** 2 + (y - centre[1]) ** 2 + (z - centre[2]) ** 2)).astype(np.float32)
+    verts, faces = extract(vol)
+    return verts / n * bw - bw / 2, faces, centre
+
+
+def test_point_triangle_distance_against_brute_force():
+    rng = np.random.default_rng(3)
+    tri = rng.standard_normal((5, 3, 3))
+    p = rng.standard_normal((40, 3)) * 2
+    d = point_triangle_distance(p, tri[:, 0], tri[:, 1], tri[:, 2])
+    # dense barycentric sampling of each triangle
+    u, v = np.meshgrid(np.linspace(0, 1, 201), np.linspace(0, 1, 201))
+    keep = u + v <= 1
+    u, v = u[keep], v[keep]
+    pts = tri[:, None, 0] + u[None, :, None] * (tri[:, None, 1] - tri[:, None, 0]) + v[None, :, None] * (tri[:, None, 2] - tri[:, None, 0])
+    brute = np.linalg.norm(p[:, None, None, :] - pts[None], axis=-1).min(-1)
+    assert np.all(d <= brute + 1e-9) and np.abs(d - brute).max() < 2e-2
+
+
+def test_mesh_scores_like_the_reference_evaluation_oracle_extractor():
+    """The C specification of the extractor (oracle/p3d_oracle_mc.c) scored the way _scripts/eval/measure.py:187-201 scores a
+    mesh, against an analytic sphere at the reference's grid scaling: chamfer distance a small fraction of a voxel, F1 = 1 at every
+    threshold of measure.py from 0.005 (0.7 % of the box) up."""
+    n, r = 64, 0.21
+    verts, faces, centre = world_mesh_of_sphere(n, r, lambda vol: O.marching_cubes(vol, level=0.0)[:2])
+    s = mesh_scores_against_sphere(verts.astype(np.float64), faces, centre.astype(np.float64), r)
+    voxel = 0.7 / n
+    assert s["cd"] < 0.05 * voxel, s
+    assert all(s[f"f1_{int(th * 1000):03d}"] == 1.0 for th in F1_THRESHOLDS), s
+    # the score is not vacuous: a mesh of the wrong radius fails the fine thresholds
+    bad = mesh_scores_against_sphere(verts.astype(np.float64), faces, centre.astype(np.float64), r + 0.02)
+    assert bad["f1_005"] < 0.05 and bad["f1_010"] < 0.05 and bad["f1_050"] == 1.0

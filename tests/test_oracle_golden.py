@@ -7,6 +7,7 @@ Indices (searchsorted bins, depth-sort permutation): exact-match counts, require
 """
 import numpy as np
 import pytest
+import torch
 
 import p3d_testing as T
 
@@ -74,6 +75,27 @@ def test_decode_points_matches_reference(oracle, ut):
     assert np.abs(rgb - g["rgb"]).max() <= 2e-6
     # the fixture must exercise the zeros-padding path (points outside the planes)
     assert (np.abs(pts * (2 / 0.7)) > 1).any()
+
+
+def decoder_forward_inputs(tag):
+    g = T.load_golden(f"decoder_forward_{tag}.npz")
+    seed = int(g["meta_seed"])
+    feats = (torch.randn(2, 3, 777, 32, generator=torch.Generator().manual_seed(seed)) * 2.0).numpy()
+    assert T.checksum(feats) == str(g["feats_checksum"])
+    raw = T.make_decoder_params(seed + 1, float(g["meta_lr_mul"]), 5.0)
+    return g, feats, raw, float(g["meta_lr_mul"]), bool(int(g["meta_force_sigmoid"]))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decoder_forward_matches_reference(oracle, tag):
+    """oracle.decode_features against the reference's OSGDecoder.forward on sampled features (triplane.py:528-544)."""
+    g, feats, raw, lr_mul, fs = decoder_forward_inputs(tag)
+    sigma, rgb = oracle.decode_features(feats, oracle.prescale_mlp(*raw, lr_mul=lr_mul), force_sigmoid=fs)
+    assert np.abs(sigma - g["sigma"]).max() <= 1e-5 * 5.0  # (sigma row scaled by 5)
+    assert np.abs(rgb - g["rgb"]).max() <= 2e-6
+    other, _ = None, None
+    _, rgb_other = oracle.decode_features(feats, oracle.prescale_mlp(*raw, lr_mul=lr_mul), force_sigmoid=not fs)
+    assert np.abs(rgb_other - g["rgb"]).max() > 1e-4  # the fixture tells the two sigmoid branches (triplane.py:539-542) apart
 
 
 @pytest.mark.parametrize("wb", [0, 1])
