@@ -320,11 +320,11 @@ class StylePlan:
             self._build(dev)
             self._key = key
             self._memo = None
-        memo = getattr(self, "_memo", None)
+        last = getattr(self, "_memo", None)
         if not (STYLE_MEMO and memo.enabled()):
             memo_of = None
-        if memo_of is not None and memo is not None and memo[0] is memo_of and memo[1] == memo_of._version and memo[2] == tuple(ws.shape):
-            return memo[3]
+        if memo_of is not None and last is not None and last[0] is memo_of and last[1] == memo_of._version and last[2] == tuple(ws.shape):
+            return last[3]
         out = self._compute(ws, dev)
         self._memo = (memo_of, memo_of._version, tuple(ws.shape), out) if memo_of is not None else None
         return out

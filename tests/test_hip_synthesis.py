@@ -765,7 +765,7 @@ def _memo_generator():
     from panic3d_amd.generator import TriPlaneGenerator
     torch.manual_seed(5)
     kw = dict(TRI_KW, rendering_kwargs={**TRI_KW["rendering_kwargs"], "c_gen_conditioning_zero": True},
-              cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.resnetcond_8")
+              cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.resnetcond_8", channel_base=2048, channel_max=64)
     G = TriPlaneGenerator(**kw).cuda().eval()
     G.set_force_sigmoid(True)
     G.set_render_exact(True)
