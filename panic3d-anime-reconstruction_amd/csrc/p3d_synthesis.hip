@@ -768,25 +768,35 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
         const char* xh = xs[0][buf] + xlane;
         const char* xl = xs[1][buf] + xlane;
         const char* wb = ws + wlane;
-        // phase 1: a_hi x (b_lo, b_hi)
+        // phase 1: a_hi x (b_lo, b_hi).  Round 4: the taps run column-major (dx outer, dy inner) and a B tile is a patch ROW — output row
+        // b under tap dy reads patch row b + dy, so the wave's two output rows and three dy share FOUR row tiles per dx instead of
+        // reading six — and the hi row tiles stay in registers (12 x 4 VGPRs) for phase 2, which then reads weights only:
+        // 42 + 18 = 60 ds_read_b128 per wave and chunk instead of 54 + 36 = 90 for the same 108 MFMAs (the LDS port was as busy as the
+        // matrix cores: profiles/r03_notes.txt).  Same products, another summation order (dx-major).
+        f16x8 bh[3][4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int off = (T::dy[t] * WX_ROW + T::dx[t]) * 16;
-            f16x8 ah[2], bh[2], bl[2];
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            f16x8 bl[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16 + a * 32 * 16);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * WX_ROW * 16);
-                bl[b] = *reinterpret_cast<const f16x8*>(xl + off + b * WX_ROW * 16);
+            for (int r = 0; r < 4; ++r) {
+                const int off = ((r - 1) * WX_ROW + (dxi - 1)) * 16;
+                bh[dxi][r] = *reinterpret_cast<const f16x8*>(xh + off);
+                bl[r] = *reinterpret_cast<const f16x8*>(xl + off);
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                const int t = dyi * 3 + dxi;
+                f16x8 ah[2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                }
+                for (int a = 0; a < 2; ++a) ah[a] = *reinterpret_cast<const f16x8*>(wb + t * 128 * 16 + a * 32 * 16);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b + dyi], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[dxi][b + dyi], acc[a][b], 0, 0, 0);
+                    }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!IMG) {
@@ -795,20 +805,20 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();                                    // a_hi is free, a_lo has landed everywhere
         if (more) conv_glds_wh(p, pl, ws, tid, ic0 + 16, ic_end, 0);
-        // phase 2: a_lo x b_hi
+        // phase 2: a_lo x b_hi (the row tiles of phase 1, still in registers)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int off = (T::dy[t] * WX_ROW + T::dx[t]) * 16;
-            f16x8 al[2], bh[2];
+        for (int dxi = 0; dxi < 3; ++dxi)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) al[a] = *reinterpret_cast<const f16x8*>(wb + WBYTES + t * 128 * 16 + a * 32 * 16);
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                const int t = dyi * 3 + dxi;
+                f16x8 al[2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bh[b] = *reinterpret_cast<const f16x8*>(xh + off + b * WX_ROW * 16);
+                for (int a = 0; a < 2; ++a) al[a] = *reinterpret_cast<const f16x8*>(wb + WBYTES + t * 128 * 16 + a * 32 * 16);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-        }
+                    for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[dxi][b + dyi], acc[a][b], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();                                    // a_lo and this patch buffer are free, a_hi(next) has landed
@@ -836,6 +846,349 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
                 }
                 yout[(((size_t)n * p.O + ch) * p.OH + gy) * p.OW + gx] = v;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_modconv_w3 (round 4): the image-fed plain 3x3 two-term convolution of k_modconv_w2<true> with a REAL software pipeline.
+// What the ISA of k_modconv_w2 showed (profiles/r04_notes.txt): the compiler tracks `buffer_load ... lds` as a pending LDS write and
+// waits `vmcnt(0)` in front of the FIRST ds_read that follows it — so the next chunk's patch, requested at the top of a chunk "to
+// land under this chunk's MFMAs", was waited for before the chunk's first MFMA; a_hi(next) had only the 36 MFMAs of phase 2 to land
+// before the `s_waitcnt(0)` of the second barrier; and the epilogue's dcoef / noise / bias loads sat behind uniform branches with a
+// `vmcnt(0)` each.  Two exposed L2 round trips per 16-channel chunk: MFMA-busy 0.13-0.42 (profiles/r03_mfma_util.json).
+// Here (the recipe of cdna_hip_programming.md "Pipelining across barriers"):
+//   * every DMA is issued from inline asm (s_mov m0 + buffer_load_dwordx4 ... lds): invisible to the compiler's wait insertion;
+//   * counted `s_waitcnt vmcnt(N)` by hand + raw s_barrier: loads stay in flight ACROSS barriers;
+//   * the weights of a chunk live in a ring of three column groups (dx = -1, 0, +1: 3 taps x hi|lo = 12 KB each); a chunk = three
+//     phases of 36 MFMAs per wave, group g is re-loaded for the next chunk right after phase g and has two phases to land; the
+//     patch is double buffered and has a whole chunk;
+//   * every wave issues the same number of DMA instructions per chunk (wave w loads the (hi|lo, k half) sub-image w of the patch:
+//     5 full + 1 partial instruction; 3 x 3 weight instructions), so the counts are compile-time constants:
+//         queue before the barrier after phase 0 / 1:  [W(g+1) 3][W(g+2) 3][patch(next) 6]   -> vmcnt(9)
+//         queue before the barrier after phase 2:      [patch(next) 6][W0(next) 3][W1(next) 3] -> vmcnt(3)
+//     chunks beyond the slice are "loaded" through a zero-length buffer resource (zeros, no traffic): no tail special cases;
+//   * B tiles are patch rows shared by the two output rows and three dy of a column group (8 + 12 reads per 36 MFMAs);
+//   * epilogue branch-free: d * 2^-10 and bias of the 64 channels staged in LDS once, stores through a buffer resource.
+// LDS (ONE array): weights 3 x 12 288 | patch 2 x [hi|lo][k half][10][34][8] f16 (2 x 21 760) | d, bias 2 x 256 = 80 896 B, two
+// workgroups per CU.  Same products as k_modconv_w2, summation order (dx-major) identical to it: bit-identical results.
+// Requires O % 64 == 0 (the 3x3 layers of the backbone / super-resolution: 512 .. 64); others take k_modconv_w2<true>.
+// ---------------------------------------------------------------------------------------------------------------------
+#define W3_GROUP_BYTES (768 * 16)
+#define W3_WBYTES (3 * W3_GROUP_BYTES)
+#define W3_SUB ((CONV_TH + 2) * WX_ROW * 16)
+#define W3_PATCH (4 * W3_SUB)
+#define W3_EPI (W3_WBYTES + 2 * W3_PATCH)
+#define W3_LDS (W3_EPI + 512)
+DEV i32x4 w3_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = CONV_RSRC_FLAGS;
+    return r;
+}
+// 64 lanes x 16 bytes from rsrc[voff] to LDS [lds_addr + lane * 16] (lds_addr wave-uniform); one wait state between the M0 write
+// and the LDS-DMA (what the compiler inserts for its own: s_nop 0)
+DEV void w3_dma16(uint32_t lds_addr, i32x4 rsrc, int voff) {
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);  // ("s" alone does not make a value uniform: s_mov_b32 m0, v75 was emitted)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+#define W3_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+__global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[W3_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // an SGPR: the LDS destinations of the DMAs (M0) derive from it
+    const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * WX_TW;
+    const int o0 = blockIdx.y * 64;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
+    const int HW = p.H * p.W;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- epilogue constants into LDS (read after the last barrier of the loop, or after the barrier below when nch == 0)
+    float* epi = reinterpret_cast<float*>(lds + W3_EPI);
+    if (tid < 64) {
+        const int ch = o0 + tid;
+        epi[tid] = (p.epilogue && p.dcoef) ? p.dcoef[(size_t)n * p.O + ch] * HX_SPLIT_UNSCALE : HX_SPLIT_UNSCALE;
+        epi[64 + tid] = (p.epilogue && p.bias) ? p.bias[ch] : 0.0f;
+    }
+    // ---- DMA plans.  Patch: wave w owns sub-image w = (hi|lo, k half); item = (row, column) of the 10 x 34 patch
+    const int sub_which = wave >> 1, sub_kh = wave & 1;
+    int pvoff[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int it = u * 64 + lane;
+        const int r = it / WX_ROW, c = it - r * WX_ROW;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        const bool ok = it < (CONV_TH + 2) * WX_ROW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pvoff[u] = ok ? ((sub_kh * p.H + iy) * p.W + ix) * 16 : CONV_OOB;
+    }
+    const bool last_lanes = lane < (CONV_TH + 2) * WX_ROW - 5 * 64;  // the sixth instruction covers items 320 .. 339
+    const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
+    auto issue_patch = [&](int chunk, int buf) {  // chunk >= nch: a zero-length resource (zeros, no traffic, same instruction count)
+        const int ic0 = ic_beg + 16 * chunk;
+        const bool in = chunk < nch;
+        const i32x4 rs = w3_rsrc(img_base + (size_t)(in ? ic0 >> 3 : 0) * HW * 16, in ? 2u * HW * 16u : 0u);
+        const uint32_t dst = lds0 + W3_WBYTES + buf * W3_PATCH + wave * W3_SUB;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) w3_dma16(dst + u * 1024, rs, pvoff[u]);
+        if (last_lanes) w3_dma16(dst + 5 * 1024, rs, pvoff[5]);
+    };
+    // Weights: piece q = u * 256 + tid of a group = (hi|lo, dy, k half, o); group g (dx = g - 1) adds g * I * 2 bytes
+    const int LO = p.O * 9 * p.I * 2;  // bytes of the hi tensor (the lo parts follow it)
+    int wvoff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int q = u * 256 + tid, which = q / 384, rem = q - which * 384;
+        const int dyi = rem >> 7, kh = (rem >> 6) & 1, o = rem & 63;
+        wvoff[u] = which * LO + (((o0 + o) * 9 + dyi * 3) * p.I + 8 * kh) * 2;
+    }
+    auto issue_w = [&](int chunk, int g) {
+        const int ic0 = ic_beg + 16 * chunk;
+        const bool in = chunk < nch;
+        const i32x4 rs = w3_rsrc((const char*)p.wh + (size_t)(in ? ic0 : 0) * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
+        const uint32_t dst = lds0 + g * W3_GROUP_BYTES + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) w3_dma16(dst + u * 4096, rs, wvoff[u] + g * p.I * 2);
+    };
+
+    f32x16 acc[2][2];  // [channel tile][row of the wave's row pair]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const int prow = 2 * wave;
+    const int blane = half * W3_SUB + (prow * WX_ROW + j) * 16;  // patch row prow, column j of this lane's k half (hi image)
+    const int alane = (half * 64 + j) * 16;
+
+    // ---- prologue: [patch(0) 6][W0(0) 3][W1(0) 3][W2(0) 3][patch(1) 6]; the first two must have landed
+    issue_patch(0, 0);
+    issue_w(0, 0);
+    issue_w(0, 1);
+    issue_w(0, 2);
+    issue_patch(1, 1);
+    W3_VMWAIT(12);
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nch; ++k) {
+        const char* pb = lds + W3_WBYTES + (k & 1) * W3_PATCH + blane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const char* wg = lds + g * W3_GROUP_BYTES + alane;
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bh[r] = *reinterpret_cast<const f16x8*>(pb + (r * WX_ROW + g) * 16);
+                bl[r] = *reinterpret_cast<const f16x8*>(pb + 2 * W3_SUB + (r * WX_ROW + g) * 16);
+            }
+#pragma unroll
+            for (int dyi = 0; dyi < 3; ++dyi) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    ah[a] = *reinterpret_cast<const f16x8*>(wg + (dyi * 128 + a * 32) * 16);
+                    al[a] = *reinterpret_cast<const f16x8*>(wg + 384 * 16 + (dyi * 128 + a * 32) * 16);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b + dyi], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b + dyi], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b + dyi], acc[a][b], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 2) W3_VMWAIT(3); else W3_VMWAIT(9);
+            __builtin_amdgcn_s_barrier();  // group g (g == 2: and this patch buffer) is free; what the next phase reads has landed
+            issue_w(k + 1, g);
+            if (g == 2) issue_patch(k + 2, k & 1);
+        }
+    }
+    W3_VMWAIT(0);  // nothing may land in LDS after this workgroup has given it back
+    // ---- epilogue (branch-free): v = act((acc * d * 2^-10 + noise) + bias) * gain, clamped; raw partials: d = 2^-10, the rest neutral
+    const bool ep = p.epilogue != 0;
+    const float alpha = (ep && p.act == 1) ? p.alpha : 1.0f, gain = ep ? p.gain : 1.0f;
+    const float cl = (ep && p.clamp >= 0.0f) ? p.clamp : __builtin_inff();
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0) + (size_t)n * p.O * p.OH * p.OW;
+    const int OHW = p.OH * p.OW;
+    auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, p.O * OHW * 4, CONV_RSRC_FLAGS);
+    const int gx = gx0 + j;
+    float nz[2];
+    int yoff[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int gy = gy0 + prow + b;
+        const bool ok = gy < p.GH && gx < p.GW;
+        yoff[b] = ok ? ((o0 + 4 * half) * OHW + gy * p.OW + gx) * 4 : CONV_OOB;
+        nz[b] = (ep && p.noise && ok) ? p.noise[(p.noise_per_sample ? (size_t)n * OHW : 0) + (size_t)gy * p.OW + gx] : 0.0f;
+    }
+    const f32x4* dq = reinterpret_cast<const f32x4*>(epi + 4 * half);        // channels a * 32 + 8 * (r >> 2) + 4 * half + (r & 3)
+    const f32x4* bq = reinterpret_cast<const f32x4*>(epi + 64 + 4 * half);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 d4 = dq[(a * 32 + 8 * r4) >> 2], b4 = bq[(a * 32 + 8 * r4) >> 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v = acc[a][b][4 * r4 + e] * d4[e];
+                    v = v + nz[b];
+                    v = v + b4[e];
+                    v = v < 0.0f ? v * alpha : v;
+                    v = v * gain;
+                    v = __builtin_fminf(__builtin_fmaxf(v, -cl), cl);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[b], (a * 32 + 8 * r4 + e) * OHW * 4, 0);
+                }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_modconv_up3 (round 4): the stride-2 transposed two-term convolution (conv0 of every block) fed from an activation IMAGE, every
+// operand by LDS-DMA, everything double buffered, ONE barrier per 16-channel chunk (k_modconv_up_h: fp32 input converted in the
+// kernel through registers, two barriers and two exposed DMA round trips per chunk — MFMA-busy 0.07-0.24, profiles/r03_mfma_util.json).
+//   workgroup = 32 output channels x 8 rows x 32 columns of grid positions ((H+1) x (W+1), four output phases each);
+//   wave w    = rows 2w, 2w + 1 (two N tiles of one row x 32 columns: lane j = column j, conflict-free ds_read_b128 at any pitch)
+//               x 4 phases = 8 accumulators; 54 MFMAs per chunk (9 taps x 2 rows x 3 two-term products), 30 ds_read_b128
+//   LDS       = weights 2 x [hi|lo][9 taps][k half][32 o][8] (2 x 18 432 B) + patch 2 x [hi|lo][k half][9 rows][34 px][8]
+//               (2 x 19 584 B) = 76 032 B: two workgroups per CU.  The chunk k + 1 is requested (inline-asm DMA, invisible to the
+//               compiler's wait insertion) at the top of chunk k and waited for (vmcnt(0)) at its end.
+// Raw store of the four phases into the (2H+1) x (2W+1) intermediate (or split-K partials); the FIR pass applies the epilogue.
+// Same products as k_modconv_up_h<true>; fp32 summation order: per tap a_hi*b_lo, a_lo*b_hi, a_hi*b_hi.
+// ---------------------------------------------------------------------------------------------------------------------
+#define U3_WB (2 * 9 * 64 * 16)                    // one buffer of weights: 18 432
+#define U3_ROWS 9
+#define U3_SUB (U3_ROWS * WX_ROW * 16)             // one (hi|lo, k half) sub-image of the patch: 4 896
+#define U3_PATCH (4 * U3_SUB)
+#define U3_LDS (2 * U3_WB + 2 * U3_PATCH)
+__global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[U3_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
+    const int gy0 = (blockIdx.x / tiles_x) * 8, gx0 = (blockIdx.x % tiles_x) * WX_TW;
+    const int o0 = blockIdx.y * 32;
+    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
+    const int HW = p.H * p.W;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    // ---- DMA plans.  Patch: wave w owns sub-image w = (hi|lo, k half): 9 x 34 items, 4 full + 1 partial instruction
+    const int sub_which = wave >> 1, sub_kh = wave & 1;
+    int pvoff[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int it = u * 64 + lane;
+        const int r = it / WX_ROW, c = it - r * WX_ROW;
+        const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+        const bool ok = it < U3_ROWS * WX_ROW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pvoff[u] = ok ? ((sub_kh * p.H + iy) * p.W + ix) * 16 : CONV_OOB;
+    }
+    const bool last_lanes = lane < U3_ROWS * WX_ROW - 4 * 64;
+    const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
+    // Weights: 1152 pieces (hi|lo, tap, k half, o) = 18 instructions; wave w issues instructions w, w + 4, ...
+    const int LO = p.O * 9 * p.I * 2;
+    int wvoff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane, which = q / 576, rem = q - which * 576;
+        const int tap = rem >> 6, kh = (rem >> 5) & 1, o = rem & 31;
+        wvoff[i] = (q < 1152 && o0 + o < p.O) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
+    }
+    const bool five = wave < 2;  // instructions 16, 17 exist for waves 0, 1 only
+    auto issue = [&](int chunk, int buf) {
+        const int ic0 = ic_beg + 16 * chunk;
+        const i32x4 rp = w3_rsrc(img_base + (size_t)(ic0 >> 3) * HW * 16, 2u * HW * 16u);
+        const i32x4 rw = w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, (uint32_t)(2 * LO - ic0 * 2));
+        const uint32_t pd = lds0 + 2 * U3_WB + buf * U3_PATCH + wave * U3_SUB;
+        const uint32_t wd = lds0 + buf * U3_WB + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w3_dma16(pd + u * 1024, rp, pvoff[u]);
+        if (last_lanes) w3_dma16(pd + 4 * 1024, rp, pvoff[4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w3_dma16(wd + i * 4096, rw, wvoff[i]);
+        if (five) w3_dma16(wd + 4 * 4096, rw, wvoff[4]);
+    };
+
+    f32x16 acc[4][2];  // [phase = 2 py + px][row of the wave's pair]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
+    // patch row 2w + 1 + t is grid row gy0 + 2w + t; column j + 1 is grid column gx0 + j
+    const int blane = half * U3_SUB + ((2 * wave) * WX_ROW + j) * 16;
+    const int alane = (half * 32 + j) * 16;
+    // (phase, tap, input) of the nine products: input 0 = x[y][x], 1 = x[y][x-1], 2 = x[y-1][x], 3 = x[y-1][x-1]
+    const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+
+    if (nch > 0) issue(0, 0);
+    W3_VMWAIT(0);
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nch; ++k) {
+        if (k + 1 < nch) issue(k + 1, (k + 1) & 1);
+        const char* pb = lds + 2 * U3_WB + (k & 1) * U3_PATCH + blane;
+        const char* wb = lds + (k & 1) * U3_WB + alane;
+        // rows 2w, 2w + 1, 2w + 2 of the patch x columns j (dx = -1), j + 1 (dx = 0), hi and lo
+        f16x8 bh[3][2], bl[3][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * WX_ROW + c) * 16);
+                bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * U3_SUB + (r * WX_ROW + c) * 16);
+            }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + TP[q] * 64 * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(wb + (9 + TP[q]) * 64 * 16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = 1 + t - (BO[q] >> 1), c = 1 - (BO[q] & 1);
+                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[r][c], acc[PH[q]][t], 0, 0, 0);
+                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[r][c], acc[PH[q]][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        W3_VMWAIT(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    // ---- raw store: a lane owns both column phases (ox = 2 gx, 2 gx + 1) of its grid point: one 8-byte store per (row phase, channel),
+    // 32 lanes = 256 contiguous bytes; the last grid column (gx = W) has only px = 0: a 4-byte store of its own
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0) + (size_t)n * p.O * p.OH * p.OW;
+    const int OHW = p.OH * p.OW;
+    auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, p.O * OHW * 4, CONV_RSRC_FLAGS);
+    const int gx = gx0 + j;
+    const bool edge_tile = gx0 + WX_TW > p.W;  // (uniform) this tile holds the column gx = W
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + 2 * wave + t;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const bool row_ok = gy <= p.H - py;
+            const int base = ((o0 + 4 * half) * OHW + (2 * gy + py) * p.OW + 2 * gx) * 4;
+            const int off2 = (row_ok && gx < p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
+            const int off1 = (row_ok && gx == p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ((r & 3) + 8 * (r >> 2)) * OHW * 4;
+                const float v0 = acc[2 * py][t][r] * HX_SPLIT_UNSCALE, v1 = acc[2 * py + 1][t][r] * HX_SPLIT_UNSCALE;
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64((i32x2){__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1)}, ry, off2, so, 0);
+                if (edge_tile) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), ry, off1, so, 0);
+            }
+        }
     }
 }
 
@@ -888,8 +1241,8 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
         if (more) conv_gload_h<SPLIT ? 0 : NT, false>(p, pl, xn, sn, ic0 + 16, ic_end, rg);
         const char* xb = xs[buf] + xlane;
         const char* wb = ws[SPLIT ? 0 : buf] + wlane;
-        auto run_pass = [&](int aoff, int boff) {
-            f16x8 bq[2][4];
+        // the four input values per N tile ([dy][dx] with dy, dx in {0, -1}; N tile 1 is two rows below), hi or lo image
+        auto load_b = [&](int boff, f16x8 (&bq)[2][4]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const char* xp = xb + boff + (2 * t * HX_PITCH) * 16;
@@ -898,6 +1251,10 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
                 bq[t][2] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16);
                 bq[t][3] = *reinterpret_cast<const f16x8*>(xp - HX_PITCH * 16 - 16);
             }
+        };
+        auto run_pass = [&](int aoff, int boff) {
+            f16x8 bq[2][4];
+            load_b(boff, bq);
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 const f16x8 a = *reinterpret_cast<const f16x8*>(wb + aoff + TP[q] * 128 * 16);
@@ -906,15 +1263,35 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
             }
         };
         if constexpr (SPLIT) {
-            // as in k_modconv_w2: the two halves of the single-buffered weight image are re-loaded under MFMAs
-            run_pass(0, HX_BYTES);   // a_hi x b_lo
-            run_pass(0, 0);          // a_hi x b_hi
+            // as in k_modconv_w2: the two halves of the single-buffered weight image are re-loaded under MFMAs.  Round 4: a_hi is read
+            // once for both of its products and the hi input tiles stay in registers for the a_lo pass: 16 + 9 + 9 = 34 ds_read_b128
+            // per wave and chunk instead of 3 x 17 = 51 for the same 54 MFMAs.
+            f16x8 bhq[2][4];
+            {
+                f16x8 blq[2][4];
+                load_b(0, bhq);
+                load_b(HX_BYTES, blq);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const f16x8 a = *reinterpret_cast<const f16x8*>(wb + TP[q] * 128 * 16);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, blq[t][BO[q]], acc[PH[q]][t], 0, 0, 0);  // a_hi x b_lo
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bhq[t][BO[q]], acc[PH[q]][t], 0, 0, 0);  // a_hi x b_hi
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) conv_lstore_hx<0, true>(xs[buf ^ 1], pl, rg, p.sat);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();         // a_hi is free, a_lo (requested before this chunk's first pass) has landed everywhere
             if (more) conv_glds_w2<NT>(p, pl, ws[0], tid, ic0 + 16, ic_end, 0);
-            run_pass(WBYTES, 0);     // a_lo x b_hi
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {  // a_lo x b_hi
+                const f16x8 a = *reinterpret_cast<const f16x8*>(wb + WBYTES + TP[q] * 128 * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bhq[t][BO[q]], acc[PH[q]][t], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();         // a_lo and this patch buffer are free, a_hi(next) has landed
@@ -1619,7 +1996,8 @@ static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
     if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
         dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (p.ximg) hipLaunchKernelGGL(k_modconv_w2<true>, gw, dim3(256), 0, st, p);
+        if (p.ximg && p.O % 64 == 0 && !getenv("P3D_NO_W3")) hipLaunchKernelGGL(k_modconv_w3, gw, dim3(256), 0, st, p);
+        else if (p.ximg) hipLaunchKernelGGL(k_modconv_w2<true>, gw, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_w2<false>, gw, dim3(256), 0, st, p);
         return;
     }
@@ -1641,6 +2019,19 @@ static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) 
     return ks;
 }
 
+// k_modconv_up3 (image-fed, DMA-pipelined transposed convolution): two-term operands, 16-channel chunks, 32-channel output tiles,
+// maps wide enough for its 32-column tiles (W + 1 grid columns: 65 -> 3 tiles)
+#ifndef P3D_UP3_MIN_W
+#define P3D_UP3_MIN_W 64
+#endif
+static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= P3D_UP3_MIN_W && !getenv("P3D_NO_UP3"); }
+static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
+    long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
+    int ks = 1;
+    while (ks < 64 && wgs * ks < P3D_KSPLIT_TARGET && I / (ks * 2) >= 16) ks *= 2;
+    return ks;
+}
+
 extern "C" {
 
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) {
@@ -1653,6 +2044,12 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
         ks = kw > ks ? kw : ks;
     }
     if (ks > 1) b += (size_t)ks * out_elems * 4;  // split-K partial sums
+    if (up == 1 && W >= WX_TW && I % 16 == 0 && O % 64 == 0) b += (size_t)N * I * H * W * 4 + 256;  // the activation image an fp32 input is turned into (k_modconv_w3)
+    if (up == 2 && up3_applies(I, O, W)) {  // k_modconv_up3: its own split-K depth, and the activation image of an fp32 input
+        const int k3 = choose_ksplit_up3(N, I, O, H, W);
+        if (k3 > ks) b += (size_t)(k3 - (ks > 1 ? ks : 0)) * out_elems * 4;
+        b += (size_t)N * I * H * W * 4 + 256;
+    }
     return b + 256;
 }
 
@@ -1686,8 +2083,20 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
-    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w2
-    const int ksplit = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W, wide ? WX_TW : CONV_TW);
+    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w3 / k_modconv_w2
+    const bool up3 = wh && wsplit && ks == 3 && up == 2 && up3_applies(I, O, W);  // k_modconv_up3
+    const int ksplit = up3 ? choose_ksplit_up3(N, I, O, H, W)
+                           : choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W, wide ? WX_TW : CONV_TW);
+    // An fp32 input of a layer the pipelined kernel can run (O % 64 == 0) is first turned into the image that kernel stages from
+    // (one pass, 8 bytes per value; the generator's blocks hand over images and never come here): ONE kernel does the arithmetic
+    // of a layer whichever way its input arrives, so both ways give the same bits.
+    if ((up3 && !ximg) || (wide && !ximg && O % 64 == 0 && I % 16 == 0 && !getenv("P3D_NO_W3"))) {
+        char* img = (char*)(part + (ksplit > 1 ? ((size_t)ksplit * out_elems + 63) / 64 * 64 : 0));
+        img = (char*)(((uintptr_t)img + 255) & ~(uintptr_t)255);
+        const long long tot = (long long)N * (I / 8) * H * W;
+        hipLaunchKernelGGL(k_act_to_image, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, styles, N, I, H * W, img, (long long)N * I * H * W * 2, sat);
+        ximg = img;
+    }
     ConvParams p;
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
@@ -1703,7 +2112,10 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (p.wh && p.wsplit) hipLaunchKernelGGL(k_modconv_up_h<true>, grid, dim3(256), 0, st, p);
+        if (up3) {
+            dim3 g3(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + 7) / 8), p.O / 32, p.N * p.ksplit);
+            hipLaunchKernelGGL(k_modconv_up3, g3, dim3(256), 0, st, p);
+        } else if (p.wh && p.wsplit) hipLaunchKernelGGL(k_modconv_up_h<true>, grid, dim3(256), 0, st, p);
         else if (p.wh) hipLaunchKernelGGL(k_modconv_up_h<false>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
     }
