@@ -40,7 +40,10 @@ extern "C" {
 #define P3D_FLAG_FORCE_SIGMOID 8 /* OSGDecoder.force_sigmoid     (training/triplane.py:539-542) */
 #define P3D_FLAG_WHITE_BACK 16   /* rendering_options.white_back (ray_marcher.py:52-53) */
 #define P3D_FLAG_NO_EARLY_OUT 32 /* p3d_render_f32: disable the exact early-outs (decode every sample; measurement / tests) */
-#define P3D_FLAG_NO_PAIR 256 /* p3d_render_f32: never use the small-launch kernel (16 rays x 2 samples per wave); tests */
+#define P3D_FLAG_NO_PAIR 256 /* p3d_render_f32: never use a small-launch kernel (8 rays x 4 samples / 16 rays x 2 samples per wave); tests */
+#define P3D_FLAG_PAIR16 16384 /* p3d_render_f32: small launches take the 16 rays x 2 samples kernel (k_render_pair) ... */
+#define P3D_FLAG_QUAD8 32768  /* ... / the 8 rays x 4 samples kernel (k_render_quad), whatever the size heuristic says (default: quad for
+                                 launches of <= 8192 rays and for the tolerance mode at 96+96 samples, pair otherwise); tests, A/B timing */
 #define P3D_FLAG_SKIP_CROPPED 128 /* p3d_grid_density_f32 with out_cropmask: points whose crop mask fires are not decoded and get
                                      out_sigma = -1000 (get_eg3d_volume overwrites their density anyway, eg3d_metrics3d.py:155-159) */
 #define P3D_FLAG_FAST_COLOR 512 /* p3d_render_f32: the caller ACCEPTS fp32-tolerance colours, so the final pass may run in its
@@ -264,7 +267,7 @@ typedef struct p3d_conv_args {
     void* workspace;           /* p3d_modconv2d_workspace_bytes(N, I, O, H, W, up) */
     uint32_t* saturated;       /* see p3d_modconv2d_f16x2mma_f32, or null */
     const void* x_img;         /* the input as an activation image (already modulated by its producer), or null: then x + styles */
-    void* y_img;               /* up = 2: the output as an activation image for the layer that follows (instead of y), or null */
+    void* y_img;               /* the output as an activation image for the layer that follows, or null: up = 2 INSTEAD of y (y null), up = 1 NEXT TO y */
     const float* y_img_styles; /* with y_img: that layer's styles [N][O] */
     size_t workspace_bytes;
     int32_t N, I, H, W, O, ks, up, demodulate, noise_per_sample, act, mma;
@@ -275,11 +278,13 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
 /* The activation IMAGE of the two-term convolution path (csrc/p3d_synthesis.hip, "activation IMAGE"): the operand of a plain 3x3
  * layer prepared by the layer in front of it — 16-byte pieces of f16 hi parts and of lo parts of 16 * s[n][c] * x[n][c][y][x], laid out
  * [hi | lo][N][C/8][H][W][8]: p3d_act_image_bytes(N, C, H, W) = N*C*H*W*4 bytes, 16-byte aligned, C % 8 == 0.  An up-sampling layer
- * writes it from its FIR + bias_act pass when p3d_conv_args.y_img / y_img_styles (the NEXT layer's styles) are set and y is null; the
- * next layer (3x3, up = 1, two-term operands, W >= 32, demod_coefs given) reads it through x_img (x and styles are then unused) with
- * buffer_load ... lds alone.  The pieces are bit for bit what that layer computes itself from the fp32 tensor, so results do not
- * change.  p3d_act_to_image_f32 builds one from an fp32 tensor (styles may be null = 1).  |16 s x| > 65504: clamped,
- * *saturated |= 1, as in p3d_modconv2d_f16x2mma_f32. */
+ * writes it from its FIR + bias_act pass when p3d_conv_args.y_img / y_img_styles (the NEXT layer's styles) are set and y is null; a
+ * plain 3x3 layer (up = 1) given y_img writes it NEXT TO y (from the convolution's own epilogue where the pipelined kernel runs
+ * unsplit, by one more pass otherwise) — the up-sampling layer of the next block reads it, ToRGB reads y.  Consumers (two-term
+ * operands, demod_coefs given, x and styles unused): a plain 3x3 layer with W >= 32, an up-sampling layer with W >= 32 and
+ * O % 32 == 0 (P3D_E_RANGE otherwise), both staging with buffer_load ... lds alone.  The pieces are bit for bit what the layer
+ * computes itself from the fp32 tensor, so results do not change.  p3d_act_to_image_f32 builds one from an fp32 tensor (styles may
+ * be null = 1).  |16 s x| > 65504: clamped, *saturated |= 1, as in p3d_modconv2d_f16x2mma_f32. */
 size_t p3d_act_image_bytes(int N, int C, int H, int W);
 int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int H, int W, void* img, uint32_t* saturated, void* stream);
 

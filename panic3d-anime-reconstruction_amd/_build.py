@@ -62,6 +62,52 @@ def needs_build():
     return built_hash() != source_hash()
 
 
+OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "obj")  # (git- and gpurun-ignored)
+HASH_UNIT = "p3d_paste.hip"  # the translation unit that holds p3d_build_info(): the only one compiled with -DP3D_SRC_HASH
+
+
+def _compile_objects(verbose=False):
+    """One object per source, the sources compiled IN PARALLEL and cached by content (source + every header + flags): editing one
+    .hip recompiles that file (and the few-second unit that embeds the source hash), not the 2.5-minute render kernels."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    hdr = hashlib.sha256()
+    for hname in sorted(HEADERS):
+        with open(os.path.join(CSRC, hname), "rb") as f:
+            hdr.update(hname.encode() + b"\0" + f.read())
+    jobs, objs = [], []
+    for src in SOURCES:
+        extra = [f'-DP3D_SRC_HASH="{source_hash()}"'] if src == HASH_UNIT else []
+        k = hashlib.sha256(hdr.digest() + " ".join(flags + extra).encode())
+        with open(os.path.join(CSRC, src), "rb") as f:
+            k.update(f.read())
+        obj = os.path.join(OBJ_DIR, f"{src}.{k.hexdigest()[:16]}.o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append((src, [_hipcc()] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj + f".{os.getpid()}.tmp"], obj))
+
+    def run(job):
+        src, cmd, obj = job
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(cmd[-1], obj)
+        finally:
+            if os.path.exists(cmd[-1]):
+                os.remove(cmd[-1])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+        keep = set(objs)  # drop the objects of older source versions
+        for fn in os.listdir(OBJ_DIR):
+            if fn.endswith(".o") and os.path.join(OBJ_DIR, fn) not in keep:
+                os.remove(os.path.join(OBJ_DIR, fn))
+    return objs
+
+
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> libpanic3d_hip.so next to this file.  Returns the path.
     Safe under torch.distributed.run (every rank may get here at once): one process compiles under an exclusive file lock into
@@ -75,10 +121,11 @@ def build(force=False, verbose=False):
             if not force and not needs_build():  # another rank built it while this one waited
                 return SO
             tmp = f"{SO}.{os.getpid()}.tmp"
-            cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DP3D_SRC_HASH="{source_hash()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
-            if verbose:
-                print(" ".join(cmd))
             try:
+                objs = _compile_objects(verbose)
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
                 subprocess.check_call(cmd)
                 os.replace(tmp, SO)  # atomic: a process that is dlopen-ing the old file keeps its inode
             finally:

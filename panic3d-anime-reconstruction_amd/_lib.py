@@ -10,6 +10,8 @@ SO = os.environ.get("P3D_LIB") or os.path.join(HERE, "libpanic3d_hip.so")  # P3D
 
 P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLAG_WHITE_BACK, P3D_FLAG_NO_EARLY_OUT, P3D_FLAG_SHARED_PLANES, P3D_FLAG_SKIP_CROPPED, P3D_FLAG_NO_PAIR, P3D_FLAG_FAST_COLOR, P3D_FLAG_PER_VIEW_CLAMP, P3D_FLAG_NO_STAGING, P3D_FLAG_FORCE_STAGING = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192
 P3D_FLAG_DISPARITY = 4096
+P3D_FLAG_PAIR16 = 16384
+P3D_FLAG_QUAD8 = 32768
 P3D_MAX_S = 192
 P3D_ABI_VERSION = 7  # include/panic3d_hip.h; lib() refuses a library built for another version
 

@@ -368,21 +368,23 @@ P3D_DEV void p3d_sort_network(float (&a)[NR]) {
 }
 
 // insertion sort of rows [0, n) of a per-wave LDS column (generic / rare path)
+template <int RS = 32>  // RS: floats per LDS row (32 rays per wave; 8 in k_render_quad)
 P3D_DEV void p3d_lds_insertion_sort(float* A, int n, int j) {
     for (int i = 1; i < n; ++i) {
-        float key = A[i * 32 + j];
+        float key = A[i * RS + j];
         int q = i - 1;
         while (q >= 0) {
-            float v = A[q * 32 + j];
+            float v = A[q * RS + j];
             if (!(v > key)) break;
-            A[(q + 1) * 32 + j] = v;
+            A[(q + 1) * RS + j] = v;
             --q;
         }
-        A[(q + 1) * 32 + j] = key;
+        A[(q + 1) * RS + j] = key;
     }
 }
 
 // one inverse-CDF draw: renderer.py:371-386.  cdf rows [0, Ns], coarse depths tc rows [0, Sc)
+template <int RS = 32>
 P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j, float ui, int& k_out) {
     // k = #{q in 0..Ns : cdf[q] <= u}  (searchsorted right=True): branchless binary search on the non-decreasing cdf
     const int n = Ns + 1;
@@ -391,25 +393,25 @@ P3D_DEV float p3d_inverse_cdf(const float* cdfA, const float* tcA, int Ns, int j
     for (int step = 128; step >= 1; step >>= 1) {
         int np = pos + step;
         if (step <= n) {  // wave-uniform
-            bool ok = (np <= n) && (cdfA[((np <= n) ? np - 1 : 0) * 32 + j] <= ui);
+            bool ok = (np <= n) && (cdfA[((np <= n) ? np - 1 : 0) * RS + j] <= ui);
             pos = ok ? np : pos;
         }
     }
     int k = pos;
     int below = k - 1 > 0 ? k - 1 : 0;
     int above = k < Ns ? k : Ns;
-    float cb = cdfA[below * 32 + j], ca = cdfA[above * 32 + j];
+    float cb = cdfA[below * RS + j], ca = cdfA[above * RS + j];
     float den = ca - cb;
     if (den < 1e-5f) den = 1.0f;
-    float bb = 0.5f * (tcA[below * 32 + j] + tcA[(below + 1) * 32 + j]);
-    float ba = 0.5f * (tcA[above * 32 + j] + tcA[(above + 1) * 32 + j]);
+    float bb = 0.5f * (tcA[below * RS + j] + tcA[(below + 1) * RS + j]);
+    float ba = 0.5f * (tcA[above * RS + j] + tcA[(above + 1) * RS + j]);
     k_out = k;
     return bb + ((ui - cb) / den) * (ba - bb);
 }
 
 // B independent draws at once: the same arithmetic as p3d_inverse_cdf, with the B LDS reads of every search step in flight
 // together (one draw is a chain of 8 dependent LDS round trips; 48 of them back to back were ~9 % of k_render).
-template <int B>
+template <int B, int RS = 32>
 P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, int j, const float (&ui)[B], float (&out)[B], int (&k_out)[B]) {
     const int n = Ns + 1;
     int pos[B];
@@ -420,7 +422,7 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
         if (step <= n) {  // wave-uniform
             float c[B];
 #pragma unroll
-            for (int q = 0; q < B; ++q) c[q] = cdfA[((pos[q] + step <= n) ? pos[q] + step - 1 : 0) * 32 + j];
+            for (int q = 0; q < B; ++q) c[q] = cdfA[((pos[q] + step <= n) ? pos[q] + step - 1 : 0) * RS + j];
 #pragma unroll
             for (int q = 0; q < B; ++q) pos[q] = ((pos[q] + step <= n) && (c[q] <= ui[q])) ? pos[q] + step : pos[q];
         }
@@ -430,9 +432,9 @@ P3D_DEV void p3d_inverse_cdf_batch(const float* cdfA, const float* tcA, int Ns, 
     for (int q = 0; q < B; ++q) {
         const int k = pos[q], below = k - 1 > 0 ? k - 1 : 0, above = k < Ns ? k : Ns;
         k_out[q] = k;
-        cb[q] = cdfA[below * 32 + j]; ca[q] = cdfA[above * 32 + j];
-        t0[q] = tcA[below * 32 + j]; t1[q] = tcA[(below + 1) * 32 + j];
-        t2[q] = tcA[above * 32 + j]; t3[q] = tcA[(above + 1) * 32 + j];
+        cb[q] = cdfA[below * RS + j]; ca[q] = cdfA[above * RS + j];
+        t0[q] = tcA[below * RS + j]; t1[q] = tcA[(below + 1) * RS + j];
+        t2[q] = tcA[above * RS + j]; t3[q] = tcA[(above + 1) * RS + j];
     }
 #pragma unroll
     for (int q = 0; q < B; ++q) {
@@ -1444,6 +1446,334 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
     }
 }
 
+// =====================================================================================================================
+// k_render_quad (round 4): the small-launch kernel with 8 rays x 4 sample slots per wave — lane = ray (j & 7) x slot (j >> 3) x
+// channel half — so that a 128^2-ray view makes 2048 waves = TWO per SIMD (k_render_pair: 1024, one per SIMD, every step's
+// bookkeeping exposed latency: ~4 us per step whether it decodes or not, profiles/r03_notes.txt).  Per-wave LDS rows hold 8 rays
+// (32 bytes per row instead of 128: 6.6 KB per wave at 96+96).  Everything per ray is executed identically by the ray's eight
+// lanes, as in k_render_pair; a step decodes four consecutive samples of every ray; sigma and the skipped flag are exchanged to
+// all lanes of the ray, the 16 colour channels only towards slot 0, whose lanes write the outputs.  Bit-identical to k_render.
+// =====================================================================================================================
+template <int NF, bool FAST>
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render_quad(RenderParams p) {  // two waves per SIMD: <= 256 registers
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
+    if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int jr = j & 7, slot = j >> 3;  // ray of the wave (8), sample slot (4)
+    constexpr int RS = 8;                 // floats per LDS row
+    const int nwaves = blockDim.x >> 6;
+    long long tile = (long long)blockIdx.x * nwaves + wave;  // 8-ray tiles
+    if (tile >= p.ntiles) return;  // no workgroup barrier below this line
+    float* wl = lds + (FAST ? P3D_LDS_FAST_FLOATS : P3D_LDS_MLP_FLOATS) + 4 + (size_t)wave * p.lds_rows * RS;
+
+    const int Sc = p.Sc, Sf = P3D_NF_EXACT(NF) ? NF : p.Sf, S = Sc + Sf;
+    long long n = tile / p.tiles_per_img, tl = tile - n * p.tiles_per_img;
+    long long r;
+    if (p.tile_w > 0) {  // 4x2 pixel tile, Morton lane order (a lane quad = a 2x2 pixel block: the quad-cooperative gathers)
+        long long ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
+        const int lx = (jr & 1) | ((jr >> 1) & 2), ly = (jr >> 1) & 1;
+        r = (ty * 2 + ly) * p.tile_w + tx * 4 + lx;
+    } else {
+        r = tl * 8 + jr;
+    }
+    const bool active = r < p.R;
+    const long long rc = active ? r : p.R - 1;
+    const size_t ray = (size_t)n * p.R + rc;
+
+    P3dPlaneGeom g;
+    g.halfW = 0.5f * (float)p.W; g.halfH = 0.5f * (float)p.H; g.fW = (float)p.W; g.fH = (float)p.H; g.W = p.W;
+    g.plane_bytes = (uint32_t)p.H * (uint32_t)p.W * 128u;
+    unsigned nlo = __builtin_amdgcn_readfirstlane((unsigned)n);
+    const float* pbase = p.planes + ((p.cfg.flags & P3D_FLAG_SHARED_PLANES) ? (size_t)0 : (size_t)nlo * 3 * (g.plane_bytes / 4));
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)pbase, 0, 3 * g.plane_bytes, 0x00020000);
+    const P3dDecodeCfg cfg = p.cfg;
+    const bool early = !(cfg.flags & P3D_FLAG_NO_EARLY_OUT);
+    const bool f_crop = (cfg.flags & P3D_FLAG_CROP) != 0;
+    int ndec = 0;
+    // value of the lane whose slot differs by X (lane ^ 8X): ds_swizzle bit mode (and 0x1f, or 0, xor 8X) — the crossbar, no address VGPR
+    auto swz8 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x201f)); };
+    auto swz16 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f)); };
+    auto swz24 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x601f)); };
+    // the value of sample slot q of this lane's ray, on EVERY lane of the ray: the lane whose slot is q sits at lane ^ 8 (slot ^ q)
+    auto of_slot = [&](int qq, float own, float x8, float x16, float x24) {
+        const int k = slot ^ qq;
+        return (k & 1) ? ((k & 2) ? x24 : x8) : ((k & 2) ? x16 : own);
+    };
+
+    const float ox = p.rays_o[ray * 3], oy = p.rays_o[ray * 3 + 1], oz = p.rays_o[ray * 3 + 2];
+    const float dx = p.rays_d[ray * 3], dy = p.rays_d[ray * 3 + 1], dz = p.rays_d[ray * 3 + 2];
+
+    // LDS rows of this wave: row(i)[jr]; both slots of a ray write the same values
+    float* tcA = wl;
+    float* wcA = tcA + Sc * RS;
+    float* tfA = (NF > 0) ? wcA : wcA + Sc * RS;
+
+    bool unsorted = false;
+    {
+        const float step = (p.ray_end - p.ray_start) / (float)(Sc - 1);
+        const float* jit = p.jitter + ray * Sc;
+        const bool limits = p.ray_start_arr != nullptr;  // per-ray limits: as in k_render
+        const float rs = limits ? p.ray_start_arr[ray] : 0.0f, span = limits ? p.ray_end_arr[ray] - rs : 0.0f;
+        const float rdelta = span / (float)(Sc - 1);
+        float prev = -__builtin_inff();
+        for (int i = 0; i < Sc; ++i) {
+            float lin = (i < Sc / 2) ? p3d_fma(step, (float)i, p.ray_start) : p3d_fma(-step, (float)(Sc - 1 - i), p.ray_end);
+            const float ji = p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 0u, ray, i) : jit[i];
+            float t = lin + ji * p.depth_delta;
+            if (limits) {
+                const float prod = ((float)i / (float)(Sc - 1)) * span;
+                t = (rs + prod) + ji * rdelta;
+            } else if (p.disparity) {
+                const float s01 = 1.0f / (float)(Sc - 1);
+                const float l01 = (i < Sc / 2) ? p3d_fma(s01, (float)i, 0.0f) : p3d_fma(-s01, (float)(Sc - 1 - i), 1.0f);
+                const float dd = l01 + ji * p.depth_delta;
+                const float ta_ = p.ray_start * (1.0f - dd), tb_ = p.ray_end * dd;
+                t = 1.0f / (ta_ + tb_);
+            }
+            tcA[i * RS + jr] = t;
+            unsorted |= (t < prev);
+            prev = t;
+        }
+    }
+    float tmin = __builtin_inff(), tmax = -__builtin_inff();
+    auto is_cropped = [&](float px, float pz) {
+        return f_crop && (__builtin_fabsf(px) > cfg.crop_limit || __builtin_fabsf(pz) > cfg.crop_limit);
+    };
+    if (Sf > 0) {
+        // ---- coarse pass, four samples per step
+        MarchState st;
+        st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+        for (int i = 0; i < Sc; i += 4) {
+            float tq[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) tq[qq] = tcA[(i + qq < Sc ? i + qq : Sc - 1) * RS + jr];
+            const float t = (slot & 2) ? ((slot & 1) ? tq[3] : tq[2]) : ((slot & 1) ? tq[1] : tq[0]);
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            float sigma = P3D_SIGMA_MASKED;
+            bool skip = false, live = true;
+            if (early) {
+                live = !(is_cropped(px, pz) || st.Td < 1e-60);  // slots 1-3: Td before the step's first interval — conservative, still exact
+                skip = __builtin_amdgcn_ballot_w64(live) == 0;
+            }
+            if (!skip) {
+                f32x16 dummy;
+                p3d_decode_wave<false, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, dummy, live);
+                ndec += 1;
+            }
+            const float s8 = swz8(sigma), s16 = swz16(sigma), s24 = swz24(sigma);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                if (i + qq < Sc) {  // uniform
+                    const float sq = of_slot(qq, sigma, s8, s16, s24);
+                    if (i + qq > 0) {
+                        float tm;
+                        wcA[(i + qq - 1) * RS + jr] = p3d_march_weight(st, tq[qq], sq, tm);
+                    }
+                    st.prev_t = tq[qq]; st.prev_sigma = sq;
+                }
+            }
+        }
+        const int Ns = Sc - 3;
+        {
+            double sum = 0.0;
+            float wa = wcA[0 * RS + jr], wb = wcA[1 * RS + jr];
+            for (int jj = 0; jj < Ns; ++jj) {
+                float wc = wcA[(jj + 2) * RS + jr];
+                float m1 = __builtin_fmaxf(wa, wb), m2 = __builtin_fmaxf(wb, wc);
+                float v = ((m1 + m2) * 0.5f + 0.01f) + 1e-5f;
+                sum += (double)v;
+                wcA[(jj + 1) * RS + jr] = v;
+                wa = wb; wb = wc;
+            }
+            float fsum = (float)sum;
+            double acc = 0.0;
+            wcA[jr] = 0.0f;
+            for (int jj = 0; jj < Ns; ++jj) {
+                float pdf = wcA[(jj + 1) * RS + jr] / fsum;
+                acc += (double)pdf;
+                wcA[(jj + 1) * RS + jr] = (float)acc;
+            }
+        }
+        const float* uu = p.u + ray * Sf;
+        if constexpr (NF > 0) {
+            // as in k_render: every load of the row issued before the first search, eight draws in lock-step (the eight LDS
+            // reads of a search step in flight together; one draw at a time was a chain of 8 dependent LDS round trips x Sf)
+            constexpr int DB = 8;
+            float tf[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) tf[i] = (i < Sf) ? (p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, i) : uu[i]) : 0.0f;
+#pragma unroll
+            for (int i0 = 0; i0 < NF; i0 += DB) {
+                if (i0 < Sf) {  // wave-uniform
+                    float ub[DB], vb[DB];
+                    int kb[DB];
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) ub[q] = tf[i0 + q];
+                    p3d_inverse_cdf_batch<DB, RS>(wcA, tcA, Ns, jr, ub, vb, kb);
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) tf[i0 + q] = (i0 + q < Sf) ? vb[q] : __builtin_inff();
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DB; ++q) tf[i0 + q] = __builtin_inff();
+                }
+            }
+            p3d_sort_network<NF>(tf);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                if (i < Sf) tfA[i * RS + jr] = tf[i];
+        } else {
+            // the generic path sorts in LDS: only slot 0 may move the keys (both slots of a ray share the column)
+            float* tmpA = tfA;
+            for (int i = 0; i < Sf; ++i) {
+                int k;
+                float v = p3d_inverse_cdf<RS>(wcA, tcA, Ns, jr, p.rng ? p3d_draw(p.seed_lo, p.seed_hi, 1u, ray, i) : uu[i], k);
+                tmpA[i * RS + jr] = v;
+            }
+            if (slot == 0 && h == 0) p3d_lds_insertion_sort<RS>(tfA, Sf, jr);
+        }
+        if (__builtin_amdgcn_ballot_w64(unsorted) != 0 && slot == 0 && h == 0) p3d_lds_insertion_sort<RS>(tcA, Sc, jr);
+    }
+    // ---- final pass: four merged samples per step
+    MarchState st;
+    st.Td = 1.0; st.W = 0.0f; st.D = 0.0f; st.prev_t = 0.0f; st.prev_sigma = 0.0f;
+    f32x16 C, prev_rgb;
+    float Cx = 0.0f, Cy = 0.0f, Cz = 0.0f, ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { C[c] = 0.0f; prev_rgb[c] = 0.0f; }
+    {
+        int ci = 0, fi = 0;
+        float ta = tcA[jr], tb = (Sf > 0) ? tfA[jr] : __builtin_inff();
+        bool prev_skipped = false;
+        auto next_depth = [&]() {  // unify_samples' merge: ties take the coarse sample first (stable sort)
+            const bool take_c = (ci < Sc) && (fi >= Sf || ta <= tb);
+            const float t = take_c ? ta : tb;
+            ci += take_c ? 1 : 0;
+            fi += take_c ? 0 : 1;
+            const int cq = ci < Sc ? ci : Sc - 1, fq = fi < Sf ? fi : (Sf > 0 ? Sf - 1 : 0);
+            const float nv = (take_c ? tcA : tfA)[(take_c ? cq : fq) * RS + jr];  // (selects, not a store through a selected pointer)
+            ta = take_c ? nv : ta;
+            tb = take_c ? tb : nv;
+            tmin = __builtin_fminf(tmin, t);
+            tmax = __builtin_fmaxf(tmax, t);
+            return t;
+        };
+        // the second half of k_render's loop body, for one sample whose decode (or skip) has already happened
+        auto consume = [&](int m, float t, float px, float py, float pz, float sigma, f32x16 rgb, bool skipped) {
+            if (m > 0) {
+                float tm;
+                float w = p3d_march_weight(st, t, sigma, tm);
+                if (early) {
+                    if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
+                        float s2;
+                        f32x16 c2;
+                        if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        else p3d_decode_wave<true>(lds, rs, g, cfg, ppx, ppy, ppz, s2, c2);
+                        if (prev_skipped) prev_rgb = c2;
+                        prev_skipped = false;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(skipped && w != 0.0f) != 0) {
+                        float s2;
+                        if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        else p3d_decode_wave<true>(lds, rs, g, cfg, px, py, pz, s2, rgb);
+                        skipped = false;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+                Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+                Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+                Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                st.W = st.W + w;
+                st.D = p3d_fma(w, tm, st.D);
+            }
+            st.prev_t = t; st.prev_sigma = sigma;
+            prev_rgb = rgb;
+            prev_skipped = skipped;
+            ppx = px; ppy = py; ppz = pz;
+        };
+        for (int m = 0; m < S; m += 4) {
+            float tq[4], pxq[4], pyq[4], pzq[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                tq[qq] = (m + qq < S) ? next_depth() : tq[qq > 0 ? qq - 1 : 0];  // (uniform condition)
+                pxq[qq] = ox + tq[qq] * dx; pyq[qq] = oy + tq[qq] * dy; pzq[qq] = oz + tq[qq] * dz;
+            }
+            const float px = (slot & 2) ? ((slot & 1) ? pxq[3] : pxq[2]) : ((slot & 1) ? pxq[1] : pxq[0]);
+            const float py = (slot & 2) ? ((slot & 1) ? pyq[3] : pyq[2]) : ((slot & 1) ? pyq[1] : pyq[0]);
+            const float pz = (slot & 2) ? ((slot & 1) ? pzq[3] : pzq[2]) : ((slot & 1) ? pzq[1] : pzq[0]);
+            float sigma = P3D_SIGMA_MASKED;
+            f32x16 rgb;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) rgb[c] = 0.0f;
+            bool skipped = false, live = true;
+            if (early) {
+                live = !(is_cropped(px, pz) || st.Td < (FAST ? 2e-6 : 1e-60));
+                skipped = __builtin_amdgcn_ballot_w64(live) == 0;
+            }
+            if (!skipped) {
+                if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0, false, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                else p3d_decode_wave<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                ndec += 1;
+                skipped = !live;
+            }
+            // exchange.  sigma and the skipped flag: every lane of the ray gets all four (the marcher state — transmittance, weights,
+            // the guards' decisions — is identical on the ray's lanes).  The colours: lane ^ 8q holds sample q only for the slot-0
+            // lanes, which are the ones that write the ray's outputs; the other slots accumulate colours in another order and never
+            // store them (48 crossbar moves per step instead of 48 + 192 selects).
+            const float s8 = swz8(sigma), s16 = swz16(sigma), s24 = swz24(sigma);
+            const float kf = skipped ? 1.0f : 0.0f;
+            const float k8 = swz8(kf), k16 = swz16(kf), k24 = swz24(kf);
+            f32x16 r8, r16, r24;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { r8[c] = swz8(rgb[c]); r16[c] = swz16(rgb[c]); r24[c] = swz24(rgb[c]); }
+            consume(m, tq[0], pxq[0], pyq[0], pzq[0], of_slot(0, sigma, s8, s16, s24), rgb, of_slot(0, kf, k8, k16, k24) != 0.0f);
+            if (m + 1 < S) consume(m + 1, tq[1], pxq[1], pyq[1], pzq[1], of_slot(1, sigma, s8, s16, s24), r8, of_slot(1, kf, k8, k16, k24) != 0.0f);
+            if (m + 2 < S) consume(m + 2, tq[2], pxq[2], pyq[2], pzq[2], of_slot(2, sigma, s8, s16, s24), r16, of_slot(2, kf, k8, k16, k24) != 0.0f);
+            if (m + 3 < S) consume(m + 3, tq[3], pxq[3], pyq[3], pzq[3], of_slot(3, sigma, s8, s16, s24), r24, of_slot(3, kf, k8, k16, k24) != 0.0f);
+        }
+    }
+    {
+        const float Wt = st.W;
+        float d = st.D / Wt;
+        if (d != d) d = __builtin_inff();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = C[c];
+            if (p.white_back) v = (v + 1.0f) - Wt;
+            C[c] = v * 2.0f - 1.0f;
+        }
+        if (p.white_back) { Cx = (Cx + 1.0f) - Wt; Cy = (Cy + 1.0f) - Wt; Cz = (Cz + 1.0f) - Wt; }
+        Cx = Cx * 2.0f - 1.0f; Cy = Cy * 2.0f - 1.0f; Cz = Cz * 2.0f - 1.0f;
+        if (active && slot == 0) {
+            float* dst = p.out_feat + ray * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){C[4 * q], C[4 * q + 1], C[4 * q + 2], C[4 * q + 3]};
+            if (h == 0) {
+                p.out_depth[ray] = d;
+                p.out_wsum[ray] = Wt;
+                p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz;
+            }
+        }
+    }
+    if (!active) { tmin = __builtin_inff(); tmax = -__builtin_inff(); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        tmin = __builtin_fminf(tmin, __shfl_xor(tmin, o));
+        tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, o));
+    }
+    if (lane == 0) {
+        atomicMin(p.gminmax, p3d_f2ord(tmin));
+        atomicMax(p.gminmax + 1, p3d_f2ord(tmax));
+        if (p.per_view_clamp) {
+            atomicMin(p.gminmax + 4 + 2 * nlo, p3d_f2ord(tmin));
+            atomicMax(p.gminmax + 5 + 2 * nlo, p3d_f2ord(tmax));
+        }
+        atomicAdd((unsigned long long*)(p.gminmax + 2), (unsigned long long)ndec);
+    }
+}
+
 __global__ void k_minmax_init(uint32_t* g, int nviews) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -1684,10 +2014,7 @@ static P3dDecodeCfg make_cfg(const p3d_opts* o) {
 
 extern "C" {
 
-#ifndef P3D_SRC_HASH
-#define P3D_SRC_HASH "unknown"
-#endif
-const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1 src=" P3D_SRC_HASH; }
+// (p3d_build_info lives in p3d_paste.hip: the small translation unit that is recompiled when any source changes)
 int p3d_abi_version(void) { return P3D_ABI_VERSION; }
 
 int p3d_struct_layout(int which, size_t* out, int cap) {
@@ -1947,6 +2274,48 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     hipLaunchKernelGGL(k_minmax_init, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, p.gminmax, p.per_view_clamp ? N : 0);
     // small launches: 16 rays x 2 samples per wave (k_render_pair) while its waves still fit in ONE round on the 1024 SIMDs
     // (measured at 48+48: 128^2 rays 0.74 -> 0.49 ms, but 192^2 = 1152 tiles 0.99 -> 1.28 ms: its steps are ~30 % dearer)
+    // ... and of those, 8 rays x 4 samples per wave (k_render_quad) where it measured faster (profiles/r04_notes.txt): launches of at
+    // most 8192 rays — fewer 16-ray waves than SIMDs: 64^2 x (96+96) 0.80 -> 0.60 ms exact, 0.60 -> 0.45 tolerance — and the
+    // tolerance mode at 96+96 (128^2: 0.63 -> 0.57 ms).  NOT the 128^2 exact launches (0.80 -> 0.88 at 96+96, 0.44 -> 0.49 at 48+48):
+    // a decode step is ~4k MFMA clocks + ~1.5k VALU instructions of ISSUE, which ONE wave per SIMD already saturates; a second wave
+    // per SIMD has nothing to hide and the per-ray work (draws, sort, marcher) is then done by twice as many waves.
+    // P3D_FLAG_QUAD8 / P3D_FLAG_PAIR16 force one of the two (tests, A/B timing).
+    const bool quad = pair && !(opts->flags & P3D_FLAG_PAIR16) &&
+                      ((opts->flags & P3D_FLAG_QUAD8) || (long long)N * R <= 8192 || (fast && nf == 96));
+    if (quad) {
+        if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 2); }
+        else p.tiles_per_img = (R + 7) / 8;
+        p.ntiles = p.tiles_per_img * N;
+        nwaves = P3D_RENDER_WAVES;
+        for (;; nwaves >>= 1) {
+            lds_bytes = lds_fixed + (size_t)nwaves * p.lds_rows * 32;  // rows of 8 rays
+            if (2 * lds_bytes <= 160 * 1024) break;                    // two workgroups per CU
+            if (nwaves == 1) { if (lds_bytes <= 160 * 1024) break; return P3D_E_RANGE; }
+        }
+        dim3 grid4((unsigned)((p.ntiles + nwaves - 1) / nwaves)), blk4(64 * nwaves);
+        hipError_t e4 = hipSuccess;
+#define P3D_LAUNCH4F(NFV, FV)                                                                                        \
+    do {                                                                                                             \
+        e4 = p3d_ensure_dynamic_lds(k_render_quad<NFV, FV>, lds_bytes);                                              \
+        if (e4 == hipSuccess) hipLaunchKernelGGL((k_render_quad<NFV, FV>), grid4, blk4, lds_bytes, st, p);          \
+    } while (0)
+#define P3D_LAUNCH4(NFV) do { if (fast) P3D_LAUNCH4F(NFV, true); else P3D_LAUNCH4F(NFV, false); } while (0)
+#ifdef P3D_ONLY_NF
+        P3D_LAUNCH4(P3D_ONLY_NF);
+#else
+        if (nf == 48) P3D_LAUNCH4(48);
+        else if (nf == 64) P3D_LAUNCH4(64);
+        else if (nf == 96) P3D_LAUNCH4(96);
+        else P3D_LAUNCH4(0);
+#endif
+        if (e4 != hipSuccess) return (int)e4;
+        int rc4 = p3d_check_launch();
+        if (rc4) return rc4;
+        long long NR4 = (long long)N * R;
+        hipLaunchKernelGGL(k_render_finish, dim3((unsigned)((NR4 + 255) / 256)), dim3(256), 0, st, out_depth, NR4, p.gminmax,
+                           (float*)nullptr, p.per_view_clamp ? (long long)R : 0LL);
+        return p3d_check_launch();
+    }
     if (pair) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 4); }
         else p.tiles_per_img = (R + 15) / 16;

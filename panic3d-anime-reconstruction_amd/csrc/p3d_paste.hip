@@ -152,6 +152,13 @@ __global__ __launch_bounds__(256) void k_paste_front(p3d_paste_args a) {
     a.out_mask_dxyz[mo] = dmask;
 }
 
+// Library identification with the content hash of ALL kernel sources (the build passes -DP3D_SRC_HASH to this translation unit
+// only, so that a change in one source recompiles that source and this small file, not the others).
+#ifndef P3D_SRC_HASH
+#define P3D_SRC_HASH "unknown"
+#endif
+extern "C" const char* p3d_build_info(void) { return "libpanic3d_hip gfx950 (MI355X) f32 contract v1 src=" P3D_SRC_HASH; }
+
 extern "C" int p3d_paste_front_f32(const p3d_paste_args* args, void* stream) {
     if (!args) return P3D_E_ARG;
     const p3d_paste_args& a = *args;

@@ -59,6 +59,10 @@ struct ConvParams {
     // ---- the activation IMAGE path (the producer prepares the consumer's operand; see "activation IMAGE" below)
     const void* ximg;     // input as an image [hi | lo][N][I/8][H][W] of 16-byte pieces, or null (then x + styles are used)
     long long ximg_lo;    // byte offset of the lo half of ximg (= N*I*H*W*2)
+    // k_modconv_w3 only: ALSO write the result as the image of a following layer with styles ystyles [N][O] (next to the fp32 y)
+    void* yimg;
+    long long yimg_lo;    // = N*O*OH*OW*2
+    const float* ystyles;
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 #define W3_SUB ((CONV_TH + 2) * WX_ROW * 16)
 #define W3_PATCH (4 * W3_SUB)
 #define W3_EPI (W3_WBYTES + 2 * W3_PATCH)
-#define W3_LDS (W3_EPI + 512)
+#define W3_LDS (W3_EPI + 768)
 DEV i32x4 w3_rsrc(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
     i32x4 r;
@@ -916,6 +920,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
         const int ch = o0 + tid;
         epi[tid] = (p.epilogue && p.dcoef) ? p.dcoef[(size_t)n * p.O + ch] * HX_SPLIT_UNSCALE : HX_SPLIT_UNSCALE;
         epi[64 + tid] = (p.epilogue && p.bias) ? p.bias[ch] : 0.0f;
+        epi[128 + tid] = p.yimg ? p.ystyles[(size_t)n * p.O + ch] : 0.0f;
     }
     // ---- DMA plans.  Patch: wave w owns sub-image w = (hi|lo, k half); item = (row, column) of the 10 x 34 patch
     const int sub_which = wave >> 1, sub_kh = wave & 1;
@@ -1031,24 +1036,59 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     }
     const f32x4* dq = reinterpret_cast<const f32x4*>(epi + 4 * half);        // channels a * 32 + 8 * (r >> 2) + 4 * half + (r & 3)
     const f32x4* bq = reinterpret_cast<const f32x4*>(epi + 64 + 4 * half);
+    const f32x4* sq = reinterpret_cast<const f32x4*>(epi + 128 + 4 * half);
+    // the optional image of the result for the layer that follows (the next block's up-sampling conv0): this lane's four channels
+    // of a group of eight are half a 16-byte piece — 8 bytes of hi parts and 8 of lo parts per (pixel, channel group), the two
+    // channel halves of the wave fill the piece.  Same arithmetic as k_act_to_image on the fp32 result: (s * v) * 16, clamp, RNE, residual.
+    const bool wimg = p.yimg != nullptr;  // (uniform)
+    const char* ib = (const char*)p.yimg + (size_t)n * (p.O >> 3) * OHW * 16;
+    auto rih = __builtin_amdgcn_make_buffer_rsrc((void*)ib, 0, wimg ? (p.O >> 3) * OHW * 16 : 0, CONV_RSRC_FLAGS);
+    auto ril = __builtin_amdgcn_make_buffer_rsrc((void*)(ib + p.yimg_lo), 0, wimg ? (p.O >> 3) * OHW * 16 : 0, CONV_RSRC_FLAGS);
+    int ioff[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int gy = gy0 + prow + b;
+        ioff[b] = (gy < p.GH && gx < p.GW) ? ((o0 >> 3) * OHW + gy * p.OW + gx) * 16 + 8 * half : CONV_OOB;
+    }
+    bool bad = false;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 d4 = dq[(a * 32 + 8 * r4) >> 2], b4 = bq[(a * 32 + 8 * r4) >> 2];
+            const f32x4 d4 = dq[(a * 32 + 8 * r4) >> 2], b4 = bq[(a * 32 + 8 * r4) >> 2], s4 = sq[(a * 32 + 8 * r4) >> 2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int b = 0; b < 2; ++b) {
+                float vv[4];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int e = 0; e < 4; ++e) {
                     float v = acc[a][b][4 * r4 + e] * d4[e];
                     v = v + nz[b];
                     v = v + b4[e];
                     v = v < 0.0f ? v * alpha : v;
                     v = v * gain;
                     v = __builtin_fminf(__builtin_fmaxf(v, -cl), cl);
+                    vv[e] = v;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[b], (a * 32 + 8 * r4 + e) * OHW * 4, 0);
                 }
+                if (wimg) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    f16x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = s4[e] * vv[e] * HX_SPLIT_SCALE_X;
+                        bad = bad || !(__builtin_fabsf(m) <= 65504.0f);
+                        m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+                        hv[e] = (_Float16)m;
+                        lv[e] = (_Float16)(m - (float)hv[e]);
+                    }
+                    const int so = (a * 4 + r4) * OHW * 16;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hv), rih, ioff[b], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lv), ril, ioff[b], so, 0);
+                }
+            }
         }
+    if (wimg && bad && p.sat) atomicOr(p.sat, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2020,11 +2060,15 @@ static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) 
 }
 
 // k_modconv_up3 (image-fed, DMA-pipelined transposed convolution): two-term operands, 16-channel chunks, 32-channel output tiles,
-// maps wide enough for its 32-column tiles (W + 1 grid columns: 65 -> 3 tiles)
+// maps wide enough for its 32-column tiles (W + 1 grid columns; measured: W = 32 -> 2 tiles, 65.2 -> 47.7 + 4.8 us at 512 -> 512)
 #ifndef P3D_UP3_MIN_W
-#define P3D_UP3_MIN_W 64
+#define P3D_UP3_MIN_W 32
 #endif
-static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= P3D_UP3_MIN_W && !getenv("P3D_NO_UP3"); }
+static int up3_min_w() {  // (P3D_UP3_MIN_W in the environment: A/B runs)
+    static const int v = getenv("P3D_UP3_MIN_W") ? atoi(getenv("P3D_UP3_MIN_W")) : P3D_UP3_MIN_W;
+    return v;
+}
+static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= up3_min_w() && !getenv("P3D_NO_UP3"); }
 static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
     int ks = 1;
@@ -2058,14 +2102,17 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                         size_t workspace_bytes, void* stream, unsigned int* sat = nullptr, const void* ximg = nullptr,
                         void* yimg = nullptr, const float* ystyles = nullptr) {
-    if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg) || (y && yimg) || !workspace || N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return P3D_E_ARG;
-    if (ximg) {  // an image input (already modulated by its producer): the wide two-term kernel; demodulation must be precomputed
+    if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg) || (y && yimg && up == 2) || (!y && up == 1) || !workspace || N <= 0 || I <= 0 || O <= 0 ||
+        H <= 0 || W <= 0)
+        return P3D_E_ARG;
+    if (ximg) {  // an image input (already modulated by its producer): the pipelined two-term kernels; demodulation must be precomputed
         if (!wh || !wsplit || (demodulate && !dcoef_in)) return P3D_E_ARG;
-        if (ks != 3 || up != 1 || I % 16 != 0 || W < WX_TW || ((uintptr_t)ximg & 15)) return P3D_E_RANGE;
+        if (ks != 3 || I % 16 != 0 || ((uintptr_t)ximg & 15)) return P3D_E_RANGE;
+        if (up == 1 ? W < WX_TW : !up3_applies(I, O, W)) return P3D_E_RANGE;  // (an up-sampling layer reads images only through k_modconv_up3)
     }
-    if (yimg) {      // an image output: written by the FIR pass of an up-sampling layer, for a consumer with styles ystyles [N][O]
+    if (yimg) {      // an image output for a consumer with styles ystyles [N][O]: up = 2: written by the FIR pass INSTEAD of y; up = 1: next to y
         if (!ystyles) return P3D_E_ARG;
-        if (up != 2 || O % 8 != 0 || ((uintptr_t)yimg & 15)) return P3D_E_RANGE;
+        if (O % 8 != 0 || ((uintptr_t)yimg & 15)) return P3D_E_RANGE;
     }
     // 32-bit byte offsets inside one image / the weight tensor (raw buffer addressing)
     if ((long long)I * H * W * 4 >= (1ll << 31) || (long long)O * I * ks * ks * 4 >= (1ll << 31)) return P3D_E_RANGE;
@@ -2102,6 +2149,9 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
     p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2;
+    // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
+    const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !getenv("P3D_NO_W3");
+    p.yimg = w3_img ? yimg : nullptr; p.yimg_lo = (long long)N * O * H * W * 2; p.ystyles = ystyles;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
     float* conv_dst = (ksplit > 1) ? part : (up == 2 ? tmp : y);
     p.y = conv_dst;
@@ -2132,7 +2182,14 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         r.act = act; r.epilogue = (up == 1) ? 1 : 0; r.alpha = alpha; r.gain = gain; r.clamp = clamp;
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, r);
     }
-    if (up == 1) return chk();
+    if (up == 1) {
+        if (yimg && !w3_img) {  // (split-K layers, channel counts the pipelined kernel does not take: the image from the finished y)
+            const long long tot = (long long)N * (O / 8) * H * W;
+            hipLaunchKernelGGL(k_act_to_image, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, y, ystyles, N, O, H * W, (char*)yimg,
+                               (long long)N * O * H * W * 2, sat);
+        }
+        return chk();
+    }
     // FIR (pad 1; the caller passes the 4x4 filter already flipped and multiplied by up^2, upfirdn2d.py:193-196) + epilogue
     FirParams q;
     q.x = fir_sums ? part : tmp; q.ksplit = fir_sums ? ksplit : 1; q.slice = (long long)out_elems;

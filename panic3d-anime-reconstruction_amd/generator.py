@@ -72,8 +72,11 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             plan = stylegan2.StylePlan(stylegan2.plan_entries([("block0", self.block0), ("block1", self.block1)], [0, 0]))
             self.__dict__["_style_plan"] = plan
         pre = plan(ws, memo_of=ws_in)
-        x, rgb = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], **block_kwargs)
+        # block0.conv1 hands block1.conv0 its operand (an activation image next to the fp32 tensor ToRGB reads): no conversion pass
+        ns = stylegan2._next_conv0_styles(self.block1, pre["block1"], self.block0.resolution)
+        out = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], next_styles=ns, **block_kwargs)
+        x, rgb, x_image = out if ns is not None else (out[0], out[1], None)
+        x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], x_image=x_image, **block_kwargs)
         return rgb
 
     def __getstate__(self):

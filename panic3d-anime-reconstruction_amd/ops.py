@@ -5,6 +5,7 @@ libpanic3d_hip.so.  All tensors must be float32 CUDA(ROCm) tensors; misuse raise
 (TORCH_CHECK -> RuntimeError, torch_utils/ops/bias_act.cpp:39-55).
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -71,6 +72,10 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         flags |= _lib.P3D_FLAG_NO_EARLY_OUT
     if not small_launch_kernel:  # keep small launches on the 32-rays-per-wave kernel (tests)
         flags |= _lib.P3D_FLAG_NO_PAIR
+    elif small_launch_kernel == "pair":  # ... or force the 16 rays x 2 samples kernel / the 8 rays x 4 samples one (tests, A/B);
+        flags |= _lib.P3D_FLAG_PAIR16    # True: the library's size heuristic picks (p3d_render_f32)
+    elif small_launch_kernel == "quad":
+        flags |= _lib.P3D_FLAG_QUAD8
     if fast_color:  # opt-in tolerance mode of the final pass (include/panic3d_hip.h P3D_FLAG_FAST_COLOR)
         flags |= _lib.P3D_FLAG_FAST_COLOR
     rs, re = (0.0, 0.0) if auto else (float(ro["ray_start"]), float(ro["ray_end"]))
@@ -340,12 +345,18 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         tiled = bool(ray_tile_w and R % ray_tile_w == 0 and ray_tile_w % 8 == 0 and (R // ray_tile_w) % 4 == 0)
         tiles = (R // 32) * N if tiled else -(-R // 32) * N
         pair = not dumps and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
-        if pair:  # 16 rays x 2 samples per wave-step
+        quad = pair and not (opts.flags & _lib.P3D_FLAG_PAIR16) and bool((opts.flags & _lib.P3D_FLAG_QUAD8) or N * R <= 8192 or
+                                                                         ((opts.flags & _lib.P3D_FLAG_FAST_COLOR) and Sf == 96 and Sc <= 96))
+        kind = ("quad" if quad else "pair") if pair else None
+        if kind == "pair":  # 16 rays x 2 samples per wave-step
             tiles = (R // 16) * N if tiled else -(-R // 16) * N
             full = tiles * ((-(-Sc // 2) + -(-(Sc + Sf) // 2)) if Sf > 0 else -(-Sc // 2))
+        elif kind == "quad":  # 8 rays x 4 samples per wave-step
+            tiles = (R // 8) * N if tiled else -(-R // 8) * N
+            full = tiles * ((-(-Sc // 4) + -(-(Sc + Sf) // 4)) if Sf > 0 else -(-Sc // 4))
         else:
             full = tiles * (Sc + Sc + Sf if Sf > 0 else Sc)
-        stats.update(decode_steps=steps, decode_steps_full=full, small_launch_kernel=pair)
+        stats.update(decode_steps=steps, decode_steps_full=full, small_launch_kernel=pair, small_launch_kind=kind)
     return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)
 
 
@@ -677,6 +688,14 @@ class ActImage:
         return v.permute(0, 1, 4, 2, 3).reshape(N, C, H, W).contiguous()
 
 
+UP_IMAGE_MIN_W = int(os.environ.get("P3D_UP3_MIN_W", "32"))  # (the library reads the same variable: csrc/p3d_synthesis.hip up3_min_w)
+
+
+def takes_image_up(I, O, W):
+    """An up-sampling 3x3 layer with these sizes stages its input from an ActImage (k_modconv_up3)."""
+    return I % 16 == 0 and O % 32 == 0 and W >= UP_IMAGE_MIN_W and not os.environ.get("P3D_NO_UP3")
+
+
 def act_to_image(x, styles=None, saturated=None):
     """p3d_act_to_image_f32: fp32 [N,C,H,W] (* styles [N,C]) -> ActImage."""
     x = _chk(x, "x")
@@ -705,6 +724,8 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     return the result as the ActImage of a following layer with those styles instead of an fp32 tensor."""
     ximg = x if isinstance(x, ActImage) else None
     if ximg is not None:
+        if up == 2 and not takes_image_up(ximg.shape[1], weight.shape[0], ximg.shape[3]):
+            raise RuntimeError("modulated_conv2d: an up-sampling layer stages from an ActImage only with I % 16 == 0, O % 32 == 0 and W >= UP_IMAGE_MIN_W")
         if weight_f16 is None or weight_f16.ndim != 4 or (demodulate and dcoef is None):
             raise RuntimeError("modulated_conv2d: an ActImage input needs two-term weights (conv_weights_to_f16(split=True)) and precomputed dcoef")
         x = None
@@ -742,9 +763,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     out_image = next_styles is not None
     if out_image:
         next_styles = _chk(next_styles, "next_styles")
-        if up != 2 or tuple(next_styles.shape) != (N, O):
-            raise RuntimeError("next_styles [N,O] goes with an up-sampling layer")
-    y = None if out_image else torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=dev_)
+        if tuple(next_styles.shape) != (N, O) or kh != 3:
+            raise RuntimeError("next_styles [N,O] goes with a 3x3 layer")
+    both = out_image and up == 1  # a plain layer writes the image NEXT TO the fp32 result (ToRGB reads the one, the next conv0 the other)
+    y = None if (out_image and not both) else torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=dev_)
     yimg = ActImage.empty(N, O, H * up, W * up, dev_) if out_image else None
     L = _lib.lib()
     mma = _lib.P3D_CONV_MMA_F32
@@ -767,4 +789,4 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
                           ximg.data.data_ptr() if ximg is not None else None, yimg.data.data_ptr() if yimg is not None else None,
                           next_styles.data_ptr() if yimg is not None else None, ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv)
         _lib.check(L.p3d_modconv2d_ex_f32(C.byref(a), _stream()), "p3d_modconv2d_ex_f32")
-    return yimg if out_image else y
+    return (y, yimg) if both else (yimg if out_image else y)

@@ -136,6 +136,19 @@ def _takes_image(layer, res):
     return CONV_IMG and mode == "x2" and layer.up == 1 and layer.weight.shape[-1] == 3 and layer.in_channels % 16 == 0 and res >= IMG_MIN_RES
 
 
+def _next_conv0_styles(next_block, next_pre, res):
+    """The styles of next_block.conv0 if that layer will stage its input (a res x res map) from an activation image, else None."""
+    if next_block is None or next_pre is None or not CONV_IMG or next_pre.get("conv0") is None or next_pre["conv0"][1] is None:
+        return None
+    layer = next_block.conv0
+    mode = getattr(layer, "mma_f16", None)
+    if mode is None:
+        mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
+    if mode != "x2" or not ops.takes_image_up(layer.in_channels, layer.out_channels, res):
+        return None
+    return next_pre["conv0"][0]
+
+
 def _f16_operand(layer):
     """The cached f16 operand copy of layer.weight when the layer runs on f16 MFMA operands, else None.  `layer.mma_f16`:
     False = fp32 operands, True = one f16 term ([O,k*k,I]; TriPlaneGenerator.set_sr_mma_f16), "x2" = two-term operands
@@ -380,9 +393,13 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, pre=None, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, pre=None, x_image=None, next_styles=None,
+                **layer_kwargs):
         """pre: {layer name: (styles, demod coefficients)} from a StylePlan (all affine layers of the network in one GEMM),
-        or None: every layer runs its own affine like the reference (networks_stylegan2.py:342,377)."""
+        or None: every layer runs its own affine like the reference (networks_stylegan2.py:342,377).
+        x_image: x as the ops.ActImage the previous block's conv1 wrote for this block's conv0 (then x itself is not read by conv0);
+        next_styles: the styles of the NEXT block's conv0 -> conv1 also writes its result as that layer's image and the block returns
+        (x, img, image) instead of (x, img)."""
         w_iter = iter(ws.unbind(dim=1))
         pre = pre or {}
         if self.in_channels == 0:
@@ -393,11 +410,17 @@ class SynthesisBlock(torch.nn.Module):
             # coefficients are known up front (a StylePlan)
             p1 = pre.get("conv1")
             img_ok = p1 is not None and p1[1] is not None and _takes_image(self.conv1, self.resolution) and self.conv1.in_channels % 8 == 0
-            x = self.conv0(x.to(torch.float32), next(w_iter), pre=pre.get("conv0"), next_styles=p1[0] if img_ok else None, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), pre=p1, **layer_kwargs)
+            x0 = x_image if (x_image is not None and pre.get("conv0") is not None and pre["conv0"][1] is not None) else x.to(torch.float32)
+            x = self.conv0(x0, next(w_iter), pre=pre.get("conv0"), next_styles=p1[0] if img_ok else None, **layer_kwargs)
+            if next_styles is not None and isinstance(x, ops.ActImage):  # conv1 takes an image (the pipelined kernel) and hands one on
+                x, x_next = self.conv1(x, next(w_iter), pre=p1, next_styles=next_styles, **layer_kwargs)
+            else:
+                x, x_next = self.conv1(x, next(w_iter), pre=p1, **layer_kwargs), None
         # y = torgb(x); img = upsample2d(img, resample_filter); img = img.add_(y)  (networks_stylegan2.py:476-478): one launch
         img = self.torgb(x, next(w_iter), pre=pre.get("torgb"), skip=None if img is None else img.to(torch.float32),
                          skip_filter=self.resample_filter)
+        if next_styles is not None:
+            return x, img, (x_next if self.in_channels != 0 else None)
         return x, img
 
 
@@ -546,8 +569,15 @@ class SynthesisNetwork(_CacheFree):
             plan = StylePlan(plan_entries([(f"b{res}", getattr(self, f"b{res}")) for res in self.block_resolutions], starts))
             self.__dict__["_style_plan"] = plan
         pre = plan(ws, memo_of=ws)  # every layer's styles + demodulation coefficients: one GEMM + three small launches
+        x_image = None
         for lvl, (res, cur_ws) in enumerate(zip(self.block_resolutions, block_ws)):
-            x, img = getattr(self, f"b{res}")(x, img, cur_ws, pre=pre[f"b{res}"], **block_kwargs)
+            # conv1 of this block writes its result also as the image the next block's conv0 stages from (no conversion pass in
+            # front of that layer) — unless something between the blocks edits x: the conditioning of this level, a latent injection
+            nxt = getattr(self, f"b{self.block_resolutions[lvl + 1]}") if lvl + 1 < len(self.block_resolutions) else None
+            x_untouched = self.cond_mode == "none" and not (latent_injection is not None and f"da_{lvl}" in latent_injection)
+            ns = _next_conv0_styles(nxt, pre.get(f"b{self.block_resolutions[lvl + 1]}") if nxt is not None else None, res) if x_untouched else None
+            out = getattr(self, f"b{res}")(x, img, cur_ws, pre=pre[f"b{res}"], x_image=x_image, next_styles=ns, **block_kwargs)
+            x, img, x_image = out if ns is not None else (out[0], out[1], None)
             x, img = self._condition(lvl, res, x, img, cond, cm, chonk)
             x, img = x.contiguous(), img.contiguous()
             ximgs.append((x, img))

@@ -97,10 +97,11 @@ def test_render_bit_exact_vs_oracle(hip, oracle, name, tiled):
 
 @pytest.mark.parametrize("name", T.RENDER_GOLDENS + T.RENDER_GOLDENS_AUTO)
 @pytest.mark.parametrize("early_out", [True, False])
-@pytest.mark.parametrize("pair", [True, False])
+@pytest.mark.parametrize("pair", ["quad", "pair", False])
 def test_render_production_kernel_bit_exact(hip, oracle, name, early_out, pair):
-    """The kernel variants that ship (no dumps; with and without the exact early-outs; the small-launch kernel with 16 rays x 2
-    samples per wave and the 32-rays-per-wave kernel) against the oracle: outputs only."""
+    """The kernel variants that ship (no dumps; with and without the exact early-outs; the small-launch kernels — 8 rays x 4 samples
+    per wave ("quad") and 16 rays x 2 samples ("pair"), forced — and the 32-rays-per-wave kernel) against the
+    oracle: outputs only."""
     g = T.load_golden(name + ".npz")
     inp = T.golden_render_inputs(g)
     R = inp["rays_o"].shape[1]
@@ -117,7 +118,7 @@ def test_render_production_kernel_bit_exact(hip, oracle, name, early_out, pair):
                          ray_limits=None if inp["ray_limits"] is None else tuple(dev(x) for x in inp["ray_limits"]))
     for name_, a, b in zip(("feat", "depth", "wsum", "xyz"), out, ref):
         assert np.array_equal(a.cpu().numpy(), b), name_
-    assert st["small_launch_kernel"] == pair
+    assert st["small_launch_kernel"] == bool(pair) and st["small_launch_kind"] == (pair or None)
     assert 0 < st["decode_steps"] <= st["decode_steps_full"]
     if not early_out:
         assert st["decode_steps"] == st["decode_steps_full"]
@@ -421,7 +422,7 @@ def test_96p96_large_launch_kernel_honours_ray_limits_and_disparity(hip, oracle,
     assert float(ref[2].mean()) > 0.05  # the scene has surfaces: the depths matter
 
 
-@pytest.mark.parametrize("pair", [True, False])
+@pytest.mark.parametrize("pair", ["quad", "pair", False])
 @pytest.mark.parametrize("seed", range(100, 124))
 def test_render_random_configs_bit_exact(hip, oracle, seed, pair):
     """Randomised sweep over what the golden fixtures do not enumerate: N 1-3, non-square planes of odd sizes, ragged ray

@@ -637,8 +637,17 @@ def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O,
     assert not ops.conv_domain_violated(flag)
     ops.modulated_conv2d(x * 3e4, w0, s0, next_styles=s1, saturated=flag, **kz)
     assert ops.conv_domain_violated(flag)
-    with pytest.raises(RuntimeError):  # next_styles is for up-sampling layers
-        ops.modulated_conv2d(mid, w1, s1, next_styles=s1, **k1)
+    # round 4: a PLAIN layer called with next_styles returns (fp32 result, its image for the layer that follows) — the next block's
+    # up-sampling conv0 stages from the image, ToRGB reads the tensor: same bits as the result alone and as act_to_image of it
+    if 2 * H >= 32:
+        y_alone = ops.modulated_conv2d(mid, w1, s1, **k1)
+        y_both, img_next = ops.modulated_conv2d(mid, w1, s1, next_styles=s0.new_ones(N, O) * 0.75, **k1)
+        assert torch.equal(y_both, y_alone) and isinstance(img_next, ops.ActImage)
+        assert torch.equal(img_next.data, ops.act_to_image(y_alone, s0.new_ones(N, O) * 0.75).data)
+        y_b2, img_n2 = ops.modulated_conv2d(img, w1, None, next_styles=s1, **k1)  # image in, image out (the generator's case)
+        assert torch.equal(y_b2, y_alone) and torch.equal(img_n2.data, ops.act_to_image(y_alone, s1).data)
+    with pytest.raises(RuntimeError):  # next_styles of the wrong shape
+        ops.modulated_conv2d(mid, w1, s1, next_styles=s1[:, :1], **k1)
 
 
 def test_generator_blocks_use_the_activation_image(hip, monkeypatch):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One small view (default 128^2 rays, 96+96 samples: what generate.py renders per view) on the two render kernels:
-the small-launch kernel (16 rays x 2 samples per wave) and the 32-rays-per-wave kernel."""
+"""One small view (default 128^2 rays, 96+96 samples: what generate.py renders per view) on the three render kernels:
+the small-launch kernels (8 rays x 4 samples and 16 rays x 2 samples per wave) and the 32-rays-per-wave kernel."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,8 +19,8 @@ R = res * res
 jit = torch.rand((1, R, S, 1), device=dev); u = torch.rand((R, S), device=dev)
 out = {}
 ref = None
-for name, pair, fast in (("pair_16rays_x2samples", True, False), ("classic_32rays", False, False), ("pair_tolerance", True, True),
-                         ("classic_32rays_tolerance", False, True)):
+for name, pair, fast in (("quad_8rays_x4samples", "quad", False), ("pair_16rays_x2samples", "pair", False), ("classic_32rays", False, False),
+                         ("quad_tolerance", "quad", True), ("pair_tolerance", "pair", True), ("classic_32rays_tolerance", False, True), ("default_choice", True, False), ("default_choice_tolerance", True, True)):
     opts = ops.make_opts(ro, triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True, small_launch_kernel=pair, fast_color=fast)
     for _ in range(3):
         r = ops.render(nhwc, o, d, jit, u, mlp, opts, ray_tile_w=res)
