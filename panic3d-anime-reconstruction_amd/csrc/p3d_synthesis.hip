@@ -54,6 +54,8 @@ struct ConvParams {
     int act;              // 0 linear, 1 lrelu
     float alpha, gain, clamp;
     int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
+    int tox;              // up = 2: the intermediate T [N][O][2H+1][OW = pitch] stores column ox at index ox + tox (tox = 1, pitch = 2W + 4: the
+                          // FIR pass reads its 36-column windows — columns X0 - 1 .. X0 + 34 — as aligned 16-byte loads); 0 elsewhere
     int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
     unsigned int* sat;    // caller-owned device word, OR-ed with 1 when a two-term operand left its domain (or null: not reported)
     // ---- the activation IMAGE path (the producer prepares the consumer's operand; see "activation IMAGE" below)
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = o0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox] = acc[ph][t][r];
+                if (ch < p.O) yout[(((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox + p.tox] = acc[ph][t][r];
             }
         }
     }
@@ -1217,7 +1219,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
             const bool row_ok = gy <= p.H - py;
-            const int base = ((o0 + 4 * half) * OHW + (2 * gy + py) * p.OW + 2 * gx) * 4;
+            const int base = ((o0 + 4 * half) * OHW + (2 * gy + py) * p.OW + 2 * gx + p.tox) * 4;
             const int off2 = (row_ok && gx < p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
             const int off1 = (row_ok && gx == p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
 #pragma unroll
@@ -1363,7 +1365,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
                 if (ch >= p.O) continue;
                 const float v0 = SPLIT ? acc[2 * py][t][r] * HX_SPLIT_UNSCALE : acc[2 * py][t][r];
                 const float v1 = SPLIT ? acc[2 * py + 1][t][r] * HX_SPLIT_UNSCALE : acc[2 * py + 1][t][r];
-                float* dst = yout + (((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox;
+                float* dst = yout + (((size_t)n * p.O + ch) * p.OH + oy) * p.OW + ox + p.tox;
                 if (both) *reinterpret_cast<f32x2u*>(dst) = (f32x2u){v0, v1};
                 else dst[0] = v0;
             }
@@ -1711,6 +1713,8 @@ struct FirParams {
     const float* nstyles; // k_fir4x4_img: the consuming layer's styles [N][C] (the image holds split(16 * s * y))
     int ksplit;           // k_fir4x4_tiled: x holds ksplit split-K partial tensors, `slice` elements apart, summed in slice order
     long long slice;      // while the tile is loaded (shallow splits only: see modconv_impl); 1 / 0 otherwise
+    int pitch, xoff;      // k_fir4x4_*: x rows are `pitch` floats apart and column v sits at index v + xoff (ConvParams::tox); the generic
+                          // operator ignores them (pitch = W, xoff = 0)
 };
 
 // y[Y][X] = sum_{fy,fx} f[fy][fx] * xz[Y*down + fy - pady0][X*down + fx - padx0],  xz = zero-inserted x (xz[u*up][v*up] = x[u][v])
@@ -1809,9 +1813,34 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
     const int tiles_x = (p.OW + 31) / 32;
     const int X0 = (blockIdx.x % tiles_x) * 32, Y0 = (blockIdx.x / tiles_x) * 32;
     const long long nc = blockIdx.y;
-    const float* xc = p.x + nc * p.H * p.W;
     if (tid < 16) fs[tid] = p.f[tid];
-    {   // 7 rows x 36 columns per pass (column 35 only pads the b128 reads)
+    {   // the 35 x 36 window (columns X0 - padx0 .. + 35; column 35 only pads the b128 reads).  Round 4: when the rows are 16-byte
+        // aligned (the padded intermediate of the up-sampling layers: pitch % 4 == 0, xoff == padx0) a thread loads 4 columns at a
+        // time — 315 16-byte loads per channel instead of 1260 4-byte ones; same values, same sums
+        const bool vec = (p.pitch & 3) == 0 && p.xoff == p.padx0 && (((uintptr_t)p.x | (uintptr_t)(p.slice * 4)) & 15) == 0;
+        if (vec) {
+            auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + nc * (long long)p.H * p.pitch), 0, p.H * p.pitch * 4, CONV_RSRC_FLAGS);
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int it = tid + ps * 256, r = it / 9, c4 = it - r * 9;
+                if (it >= 35 * 9) break;
+                const int u = Y0 + r - p.pady0;
+                const int off = (u >= 0 && u < p.H) ? (u * p.pitch + X0 + 4 * c4) * 4 : CONV_OOB;
+                f32x4 val = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce)
+                    auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + nc * (long long)p.H * p.pitch + (size_t)k * p.slice), 0, p.H * p.pitch * 4, CONV_RSRC_FLAGS);
+                    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+                    val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w;
+                }
+                const int v0 = X0 + 4 * c4 - p.padx0;  // logical column of val.x
+                val.x = (v0 >= 0 && v0 < p.W) ? val.x : 0.0f;
+                val.y = (v0 + 1 >= 0 && v0 + 1 < p.W) ? val.y : 0.0f;
+                val.z = (v0 + 2 >= 0 && v0 + 2 < p.W) ? val.z : 0.0f;
+                val.w = (v0 + 3 >= 0 && v0 + 3 < p.W) ? val.w : 0.0f;
+                *reinterpret_cast<f32x4*>(tile + r * FIR_PITCH + 4 * c4) = val;
+            }
+        } else {
+        const float* xc = p.x + nc * (long long)p.H * p.pitch + p.xoff;
         const int r0 = tid / 36, c = tid - r0 * 36;
         const int v = X0 + c - p.padx0;
         const bool cv = tid < 252 && v >= 0 && v < p.W;
@@ -1820,11 +1849,12 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
             const int r = ps * 7 + r0, u = Y0 + r - p.pady0;
             float val = 0.0f;
             if (cv && u >= 0 && u < p.H) {
-                const float* q = xc + (size_t)u * p.W + v;
+                const float* q = xc + (size_t)u * p.pitch + v;
                 val = q[0];
                 for (int k = 1; k < p.ksplit; ++k) val += q[(size_t)k * p.slice];  // split-K partials, slice order (= k_splitk_reduce)
             }
             if (tid < 252) tile[r * FIR_PITCH + c] = val;
+        }
         }
     }
     __syncthreads();
@@ -1892,6 +1922,7 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
 // contiguous bytes per 8 threads.  Always applies the epilogue.  (Measured at 512^2 x 128 channels, whole up-convolution: channel
 // by channel through two buffers 381 us, all eight tiles resident (45 KB, 3 workgroups per CU) 342 us, fp32 output 303 us.)
 #define FIRI_PITCH 40
+template <bool VEC>  // VEC: the input rows are 16-byte aligned (decided by the host: fir_rows_aligned)
 __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restrict__ yimg, long long lo_off, unsigned int* sat) {
     __shared__ __attribute__((aligned(16))) float tile[4][35 * FIRI_PITCH];
     __shared__ float fs[16];
@@ -1902,43 +1933,97 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
     const long long n = g / (p.C >> 3);
     const int c0 = (int)(g - n * (p.C >> 3)) * 8;
     if (tid < 16) fs[tid] = p.f[tid];
+    const int HP = p.H * p.pitch;  // floats per channel plane of the input
+    const float* xg = p.x + (n * p.C + c0) * (long long)HP;
+    // Round 4: rows of the padded intermediate are 16-byte aligned (pitch % 4 == 0, column v at index v + xoff, xoff == padx0): the
+    // 35 x 36 window is 315 16-byte loads per channel (2 per thread: rows 0-27, then 28-34) instead of 1260 4-byte ones (5 per
+    // thread) — same values (columns outside [0, W) are zeroed in registers), same sums
+    constexpr bool vec = VEC;
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 8 * HP * 4, CONV_RSRC_FLAGS);
+    // scalar plan (odd pitches: callers' own tensors)
     const int r0 = tid / 36, c = tid - r0 * 36;
     const int vcol = X0 + c - p.padx0;
     const bool cv = tid < 252 && vcol >= 0 && vcol < p.W;
-    const float* xg = p.x + (n * p.C + c0) * (long long)p.H * p.W;
-    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 8 * p.H * p.W * 4, CONV_RSRC_FLAGS);
     int off[5];
 #pragma unroll
     for (int ps = 0; ps < 5; ++ps) {
         const int u = Y0 + ps * 7 + r0 - p.pady0;
-        off[ps] = (cv && u >= 0 && u < p.H) ? (u * p.W + vcol) * 4 : CONV_OOB;
+        off[ps] = (cv && u >= 0 && u < p.H) ? (u * p.pitch + vcol + p.xoff) * 4 : CONV_OOB;
     }
-    auto fetch = [&](int half, float (&val)[4][5]) {
+    // vector plan: item it = tid + 256 ps -> row it / 9, column quad it % 9
+    int voff[2], vr[2], vc4[2];
+    bool vm[2][4];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int it = tid + ps * 256, r = it / 9, c4 = it - r * 9;
+        const int u = Y0 + r - p.pady0;
+        vr[ps] = r; vc4[ps] = c4;
+        voff[ps] = (it < 35 * 9 && u >= 0 && u < p.H) ? (u * p.pitch + X0 + 4 * c4) * 4 : CONV_OOB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int v = X0 + 4 * c4 + e - p.padx0; vm[ps][e] = v >= 0 && v < p.W; }
+    }
+    struct Stage { float s[VEC ? 1 : 4][5]; f32x4 v[VEC ? 4 : 1][2]; };
+    auto fetch = [&](int half, Stage& st) {
+        if constexpr (vec) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+                    st.v[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[ps], (half * 4 + ch) * HP * 4, 0));
+            for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce)
+                auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * HP * 4, CONV_RSRC_FLAGS);
+                f32x4 t[4][2];
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps)
+                        t[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff[ps], (half * 4 + ch) * HP * 4, 0));
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) { st.v[ch][ps].x += t[ch][ps].x; st.v[ch][ps].y += t[ch][ps].y; st.v[ch][ps].z += t[ch][ps].z; st.v[ch][ps].w += t[ch][ps].w; }
+            }
+        } else {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
             for (int ps = 0; ps < 5; ++ps)
-                val[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[ps], (half * 4 + ch) * p.H * p.W * 4, 0));
+                st.s[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[ps], (half * 4 + ch) * HP * 4, 0));
         for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce); 20 independent loads per slice
-            auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * p.H * p.W * 4, CONV_RSRC_FLAGS);
+            auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * HP * 4, CONV_RSRC_FLAGS);
             float t[4][5];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
                 for (int ps = 0; ps < 5; ++ps)
-                    t[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[ps], (half * 4 + ch) * p.H * p.W * 4, 0));
+                    t[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[ps], (half * 4 + ch) * HP * 4, 0));
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-                for (int ps = 0; ps < 5; ++ps) val[ch][ps] += t[ch][ps];
+                for (int ps = 0; ps < 5; ++ps) st.s[ch][ps] += t[ch][ps];
+        }
         }
     };
-    auto put = [&](const float (&val)[4][5]) {
+    auto put = [&](const Stage& st) {
+        if constexpr (vec) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                if (tid + ps * 256 < 35 * 9) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        f32x4 v = st.v[ch][ps];
+                        v.x = vm[ps][0] ? v.x : 0.0f; v.y = vm[ps][1] ? v.y : 0.0f; v.z = vm[ps][2] ? v.z : 0.0f; v.w = vm[ps][3] ? v.w : 0.0f;
+                        *reinterpret_cast<f32x4*>(&tile[ch][vr[ps] * FIRI_PITCH + 4 * vc4[ps]]) = v;
+                    }
+                }
+            }
+        } else {
         if (tid < 252) {
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-                for (int ps = 0; ps < 5; ++ps) tile[ch][(ps * 7 + r0) * FIRI_PITCH + c] = val[ch][ps];
+                for (int ps = 0; ps < 5; ++ps) tile[ch][(ps * 7 + r0) * FIRI_PITCH + c] = st.s[ch][ps];
+        }
         }
     };
     const int lx = (tid & 7) * 4, ly = tid >> 3;
@@ -1966,7 +2051,7 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
             }
         }
     };
-    float va[4][5], vb[4][5];
+    Stage va, vb;
     fetch(0, va);
     fetch(1, vb);
     put(va);
@@ -2080,7 +2165,7 @@ extern "C" {
 
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) {
     size_t b = (size_t)N * O * 4 + 256;  // demodulation coefficients
-    size_t out_elems = (up == 2) ? (size_t)N * O * (2 * H + 1) * (2 * W + 1) : (size_t)N * O * H * W;
+    size_t out_elems = (up == 2) ? (size_t)N * O * (2 * H + 1) * (2 * W + 4) : (size_t)N * O * H * W;  // (up = 2: the intermediate's row pitch)
     if (up == 2) b += out_elems * 4;  // transposed-conv intermediate
     int ks = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
     if (up == 1 && W >= WX_TW) {  // the wide tile of the two-term kernel may split deeper
@@ -2122,7 +2207,9 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     hipStream_t st = (hipStream_t)stream;
     float* dco = (float*)workspace;
     float* tmp = dco + (((size_t)N * O + 63) / 64) * 64;
-    const int OH = (up == 2) ? 2 * H + 1 : H, OW = (up == 2) ? 2 * W + 1 : W;
+    // up = 2: the intermediate T has 2W + 1 columns, stored at a pitch of 2W + 4 floats with column ox at index ox + 1, so that the
+    // FIR pass reads 16-byte aligned windows (k_fir4x4_*); OW below is that PITCH for everything that indexes T
+    const int OH = (up == 2) ? 2 * H + 1 : H, OW = (up == 2) ? 2 * W + 4 : W;
     const size_t out_elems = (size_t)N * O * OH * OW;
     float* part = (up == 2) ? tmp + ((out_elems + 63) / 64) * 64 : tmp;
     if (demodulate && dcoef_in) dco = const_cast<float*>(dcoef_in);  // precomputed by p3d_demod_coefs_f32 (one launch per network)
@@ -2148,7 +2235,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
-    p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2;
+    p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2; p.tox = up == 2 ? 1 : 0;
     // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
     const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !getenv("P3D_NO_W3");
     p.yimg = w3_img ? yimg : nullptr; p.yimg_lo = (long long)N * O * H * W * 2; p.ystyles = ystyles;
@@ -2194,13 +2281,15 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     FirParams q;
     q.x = fir_sums ? part : tmp; q.ksplit = fir_sums ? ksplit : 1; q.slice = (long long)out_elems;
     q.f = fir; q.y = y; q.dcoef = demodulate ? dco : nullptr; q.noise = noise; q.bias = bias;
-    q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4;
+    q.NC = (long long)N * O; q.C = O; q.H = 2 * H + 1; q.W = 2 * W + 1; q.OH = 2 * H; q.OW = 2 * W; q.fh = 4; q.fw = 4; q.pitch = OW; q.xoff = 1;
     q.up = 1; q.down = 1; q.padx0 = 1; q.pady0 = 1; q.noise_per_sample = noise_per_sample; q.act = act; q.epilogue = 1;
     q.alpha = alpha; q.gain = gain; q.clamp = clamp; q.nstyles = ystyles;
     dim3 grid(((q.OW + 31) / 32) * ((q.OH + 31) / 32), (unsigned)q.NC);
     if (yimg) {
         dim3 gi(grid.x, (unsigned)(q.NC / 8));
-        hipLaunchKernelGGL(k_fir4x4_img, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
+        const bool rows_aligned = (q.pitch & 3) == 0 && q.xoff == q.padx0 && (((uintptr_t)q.x | (uintptr_t)(q.slice * 4)) & 15) == 0;
+        if (rows_aligned) hipLaunchKernelGGL(k_fir4x4_img<true>, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
+        else hipLaunchKernelGGL(k_fir4x4_img<false>, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
     } else hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
     return chk();
 }
@@ -2325,7 +2414,7 @@ int p3d_upfirdn2d_f32(const float* x, int64_t NC, int H, int W, const float* f, 
     q.OW = (W * up + padx0 + padx1 - fw) / down + 1;
     if (q.OH <= 0 || q.OW <= 0) return P3D_E_RANGE;
     q.fh = fh; q.fw = fw; q.up = up; q.down = down; q.padx0 = padx0; q.pady0 = pady0;
-    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1; q.ksplit = 1; q.slice = 0; q.nstyles = nullptr;
+    q.noise_per_sample = 0; q.act = 0; q.epilogue = 0; q.alpha = 0; q.gain = 1; q.clamp = -1; q.ksplit = 1; q.slice = 0; q.nstyles = nullptr; q.pitch = W; q.xoff = 0;
     long long total = q.NC * q.OH * q.OW;
     hipLaunchKernelGGL(k_upfirdn2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
     return chk();

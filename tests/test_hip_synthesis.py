@@ -651,8 +651,8 @@ def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O,
 
 
 def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
-    """SynthesisBlock hands conv1 an ops.ActImage from res 32 on (StylePlan styles), and the planes do not change by a bit when
-    the path is switched off."""
+    """SynthesisBlock hands conv1 an ops.ActImage from res 32 on (StylePlan styles), conv1 hands the next block's up-sampling conv0 one
+    (maps of 32 columns and more, nothing editing x in between), and the planes do not change by a bit when the path is switched off."""
     sg = hip.stylegan2
     torch.manual_seed(5)
     net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="none", channel_base=8192, channel_max=128, num_fp16_res=0).cuda()
@@ -667,7 +667,7 @@ def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
     monkeypatch.setattr(hip.ops, "modulated_conv2d", spy)
     with torch.no_grad():
         a = net(ws, {}, noise_mode="const")
-        assert sum(seen) == 2  # conv1 of b32 and b64
+        assert sum(seen) == 3  # conv1 of b32 and b64, and (round 4) conv0 of b64: b32.conv1 hands it its operand next to the fp32 tensor
         monkeypatch.setattr(sg, "CONV_IMG", False)
         seen.clear()
         b = net(ws, {}, noise_mode="const")
