@@ -22,6 +22,28 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _on(device):
+    """The C ABI launches on the CURRENT device's stream, so a call has to run with its tensors' device current.
+    `torch.cuda.device(...)` costs ~10 us of host time per entry (get + set + restore); when the device already is the current one
+    — always, with one process per GPU — nothing has to be switched: a G.f call makes ~35 such calls and starts with an empty
+    queue, so this is latency the GPU waits for (profiles/r04_notes.txt)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOGUARD
+    return torch.cuda.device(device)
+
+
 def _chk(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
@@ -113,7 +135,7 @@ def planes_to_nhwc(planes):
         raise RuntimeError(f"planes must be [N,3,32,H,W], got {tuple(planes.shape)}")
     N, _, Cc, H, W = planes.shape
     out = torch.empty((N, 3, H, W, Cc), dtype=torch.float32, device=planes.device)
-    with torch.cuda.device(planes.device):
+    with _on(planes.device):
         _lib.check(_lib.lib().p3d_planes_to_nhwc_f32(_p(planes), N * 3, Cc, H, W, _p(out), _stream()), "p3d_planes_to_nhwc_f32")
     return out
 
@@ -139,7 +161,7 @@ def triplane_decode(planes_nhwc, coords, mlp, opts, density_only=False):
     M = coords.shape[1]
     sigma = torch.empty((N, M, 1), dtype=torch.float32, device=coords.device)
     rgb = None if density_only else torch.empty((N, M, 32), dtype=torch.float32, device=coords.device)
-    with torch.cuda.device(coords.device):
+    with _on(coords.device):
         rc = _lib.lib().p3d_triplane_decode_f32(_p(planes_nhwc), N, H, W, _p(coords), M, _p(w0), _p(b0), _p(w1), _p(b1),
                                                 C.byref(opts), _p(sigma), _p(rgb), _stream())
     _lib.check(rc, "p3d_triplane_decode_f32")
@@ -155,7 +177,7 @@ def decode_features(feats, mlp, force_sigmoid=True):
     w0, b0, w1, b1 = _chk_mlp(mlp)
     sigma = torch.empty((N, M, 1), dtype=torch.float32, device=feats.device)
     rgb = torch.empty((N, M, 32), dtype=torch.float32, device=feats.device)
-    with torch.cuda.device(feats.device):
+    with _on(feats.device):
         rc = _lib.lib().p3d_decode_features_f32(_p(feats), N, M, _p(w0), _p(b0), _p(w1), _p(b1), int(bool(force_sigmoid)), _p(sigma),
                                                 _p(rgb), _stream())
     _lib.check(rc, "p3d_decode_features_f32")
@@ -180,7 +202,7 @@ def grid_density(planes_nhwc, grid_n, lo, hi, voxel_size, offsets, mlp, opts, cr
     w0, b0, w1, b1 = _chk_mlp(mlp)
     sigma = torch.empty((1, hi - lo, 1), dtype=torch.float32, device=planes_nhwc.device)
     msk = torch.empty((1, hi - lo, 1), dtype=torch.uint8, device=planes_nhwc.device) if crop_limit is not None else None
-    with torch.cuda.device(planes_nhwc.device):
+    with _on(planes_nhwc.device):
         rc = _lib.lib().p3d_grid_density_f32(_p(planes_nhwc), H, W, int(grid_n), int(lo), int(hi), np.float32(voxel_size),
                                               np.float32(offsets[0]), np.float32(offsets[1]), np.float32(offsets[2]), _p(w0),
                                               _p(b0), _p(w1), _p(b1), C.byref(opts), _p(sigma), _p(msk),
@@ -200,7 +222,7 @@ def sigma2density(sigma, cropmask=None, cull=None):
         cm = cm.view(torch.uint8) if cm.dtype == torch.bool else cm.to(torch.uint8)  # bool is one 0 / 1 byte: reinterpret
         if cm.numel() != sigma.numel() or not cm.is_cuda:
             raise RuntimeError("cropmask must be a CUDA tensor with one entry per sigma")
-    with torch.cuda.device(sigma.device):
+    with _on(sigma.device):
         rc = _lib.lib().p3d_sigma2density_f32(_p(sigma), _p(cm), sigma.numel(), np.float32(-1.0 if cull is None else cull), _p(out),
                                               _stream())
     _lib.check(rc, "p3d_sigma2density_f32")
@@ -249,7 +271,7 @@ def marching_cubes(vol, level, flip0=False, allow_degenerate=True):
     dev = vol.device
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     counts = torch.empty(2, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.p3d_mc_count_f32(_p(vol), n, int(bool(flip0)), np.float32(level), _p(ws), wsb, _p(counts), _stream()),
                    "p3d_mc_count_f32")
         V, F = (int(x) for x in counts.tolist())
@@ -330,7 +352,7 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         rs_t, re_t = _chk(ray_limits[0], "ray_limits[0]"), _chk(ray_limits[1], "ray_limits[1]")
         if rs_t.numel() != N * R or re_t.numel() != N * R:
             raise RuntimeError(f"ray_limits must hold N*R = {N * R} values each")
-    with torch.cuda.device(dev):
+    with _on(dev):
         if rng_seed is not None:
             rc = L.p3d_render_rng_f32(_p(planes_nhwc), N, H, W, _p(rays_o), _p(rays_d), R, int(ray_tile_w), int(rng_seed) & (2 ** 64 - 1),
                                       _p(w0), _p(b0), _p(w1), _p(b1), _p(rs_t), _p(re_t), C.byref(opts), _p(feat), _p(depth),
@@ -365,7 +387,7 @@ def sample_stratified(ray_start, ray_end, S, jitter):
     jitter = _chk(jitter, "jitter")
     out = torch.empty_like(jitter)
     NR = jitter.numel() // S
-    with torch.cuda.device(jitter.device):
+    with _on(jitter.device):
         rc = _lib.lib().p3d_sample_stratified_f32(np.float32(ray_start), np.float32(ray_end),
                                                   np.float32((float(ray_end) - float(ray_start)) / (S - 1)), int(S),
                                                   _p(jitter), NR, _p(out), _stream())
@@ -387,7 +409,7 @@ def composite(colors, densities, depths, white_back=True):
     depth = torch.empty(lead + (1,), dtype=torch.float32, device=dev)
     w = torch.empty(lead + (S - 1, 1), dtype=torch.float32, device=dev)
     ws = torch.empty((_lib.lib().p3d_composite_workspace_bytes(NR, S, K),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.lib().p3d_composite_f32(_p(colors), _p(densities), _p(depths), NR, S, K, int(bool(white_back)), _p(rgb),
                                           _p(depth), _p(w), _p(ws), _stream())
     _lib.check(rc, "p3d_composite_f32")
@@ -414,7 +436,7 @@ def paste_front(weights, xyz, occ, rays_o, rays_d, front, image, thresh_weight, 
                        _p(image).value, *[_p(out[k]).value for k in ("image", "paste", "mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz")],
                        N, r, S, int(front.shape[0] == 1 and N > 1), int(bool(normalize_images)),
                        np.float32(thresh_weight), np.float32(thresh_edges), np.float32(thresh_occ), np.float32(thresh_dxyz), np.float32(box_warp))
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.lib().p3d_paste_front_f32(C.byref(a), _stream())
     _lib.check(rc, "p3d_paste_front_f32")
     return out
@@ -425,7 +447,7 @@ def depth_minmax(depths):
     depths = _chk(depths, "depths")
     out = torch.empty((2,), dtype=torch.float32, device=depths.device)
     ws = torch.empty((16,), dtype=torch.uint8, device=depths.device)
-    with torch.cuda.device(depths.device):
+    with _on(depths.device):
         rc = _lib.lib().p3d_depth_minmax_f32(_p(depths), depths.numel(), _p(out), _p(ws), 16, _stream())
     _lib.check(rc, "p3d_depth_minmax_f32")
     return out
@@ -441,7 +463,7 @@ def importance(depths, weights, u, return_inds=False):
         raise RuntimeError("weights must hold Sc-1 values per ray")
     out = torch.empty(tuple(depths.shape[:2]) + (Sf, 1) if depths.dim() == 4 else (NR, Sf), dtype=torch.float32, device=u.device)
     inds = torch.empty((NR, Sf), dtype=torch.int32, device=u.device) if return_inds else None
-    with torch.cuda.device(u.device):
+    with _on(u.device):
         rc = _lib.lib().p3d_importance_f32(_p(depths), _p(weights), NR, Sc, Sf, _p(u), _p(out), _p(inds), _stream())
     _lib.check(rc, "p3d_importance_f32")
     return (out, inds) if return_inds else out
@@ -453,7 +475,7 @@ def unify_perm(depths_coarse, depths_fine):
     NR = dc.shape[0] if dc.dim() == 2 else dc.numel() // dc.shape[-2]
     Sc, Sf = dc.numel() // NR, df.numel() // NR
     perm = torch.empty((NR, Sc + Sf), dtype=torch.int32, device=dc.device)
-    with torch.cuda.device(dc.device):
+    with _on(dc.device):
         rc = _lib.lib().p3d_unify_perm_f32(_p(dc), _p(df), NR, Sc, Sf, _p(perm), _stream())
     _lib.check(rc, "p3d_unify_perm_f32")
     return perm
@@ -482,7 +504,7 @@ def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None):
     outer = int(np.prod(x.shape[:dim])) if dim > 0 else 1
     inner = int(np.prod(x.shape[dim + 1:])) if dim + 1 < x.ndim else 1
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.lib().p3d_bias_act_f32(_p(x), _p(b), outer, C, inner, idx, alpha, gain, clamp, _p(y), _stream())
     _lib.check(rc, "p3d_bias_act_f32")
     return y
@@ -538,7 +560,7 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     OH = (H * up + py0 + py1 - fh) // down + 1
     OW = (W * up + px0 + px1 - fw) // down + 1
     y = torch.empty((N, Cc, OH, OW), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.lib().p3d_upfirdn2d_f32(_p(x), N * Cc, H, W, _p(ff), fh, fw, int(up), int(down), px0, px1, py0, py1, _p(y), _stream())
     _lib.check(rc, "p3d_upfirdn2d_f32")
     return y
@@ -566,7 +588,7 @@ def upsample2d_add(x, f, add=None):
         if tuple(add.shape) != (N, Cc, 2 * H, 2 * W):
             raise RuntimeError("add must be [N,C,2H,2W]")
     y = torch.empty((N, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.lib().p3d_upsample2d_add_f32(_p(x), N * Cc, H, W, _p(ff), _p(add), _p(y), _stream())
     _lib.check(rc, "p3d_upsample2d_add_f32")
     return y
@@ -579,7 +601,7 @@ def torgb_weights(weight):
     if weight.shape[2:] != (1, 1) or O > 96:
         raise RuntimeError("torgb_weights: [O <= 96, I, 1, 1]")
     wt = torch.empty((I, 32 if O <= 32 else 96), dtype=torch.float32, device=weight.device)
-    with torch.cuda.device(weight.device):
+    with _on(weight.device):
         _lib.check(_lib.lib().p3d_torgb_weights_f32(_p(weight), O, I, _p(wt), _stream()), "p3d_torgb_weights_f32")
     return wt
 
@@ -604,7 +626,7 @@ def torgb(x, weight_t, out_channels, styles, bias=None, clamp=None, skip=None, s
         if tuple(skipf.shape) != (4, 4):
             raise NotImplementedError("skip_filter must be the 4x4 [1,3,3,1] filter")
     y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = _lib.lib().p3d_torgb_f32(_p(x), N, I, H, W, _p(weight_t), O, _p(styles), _p(bias), float(clamp if clamp is not None else -1),
                                       _p(skip), _p(skipf), _p(y), _stream())
     _lib.check(rc, "p3d_torgb_f32")
@@ -617,7 +639,7 @@ def conv_weights_to_f16(weight, split=False):
     weight = _chk(weight, "weight")
     O, I, kh, kw = weight.shape
     wh = torch.empty((2, O, kh * kw, I) if split else (O, kh * kw, I), dtype=torch.float16, device=weight.device)
-    with torch.cuda.device(weight.device):
+    with _on(weight.device):
         if split:
             _lib.check(_lib.lib().p3d_conv_weights_to_f16x2(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16x2")
         else:
@@ -641,13 +663,14 @@ def conv_domain_violated(flag, reset=True):
 
 def demod_coefs(w2_all, styles_all, table, L, N, total_waves, out):
     """Demodulation coefficients of L layers in one launch (p3d_demod_coefs_f32); see stylegan2.StylePlan."""
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         rc = _lib.lib().p3d_demod_coefs_f32(_p(w2_all), _p(styles_all), _p(table), int(L), int(N), int(total_waves), _p(out), _stream())
     _lib.check(rc, "p3d_demod_coefs_f32")
     return out
 
 
 _CONV_SCRATCH = {}  # (device index, stream handle) -> workspace tensor
+_WSB = {}           # (N, I, O, H, W, up) -> p3d_modconv2d_workspace_bytes (a pure function of the shape)
 
 
 def _conv_scratch(device, nbytes):
@@ -705,7 +728,7 @@ def act_to_image(x, styles=None, saturated=None):
         if tuple(styles.shape) != (N, C):
             raise RuntimeError("act_to_image: styles [N,C]")
     img = ActImage.empty(N, C, H, W, x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().p3d_act_to_image_f32(_p(x), _p(styles), N, C, H, W, _p(img.data), _p(saturated), _stream()), "p3d_act_to_image_f32")
     return img
 
@@ -778,8 +801,11 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
         mma = _lib.P3D_CONV_MMA_F16X2 if split else _lib.P3D_CONV_MMA_F16
         if split and saturated is not None and (saturated.dtype != torch.int32 or saturated.numel() != 1 or saturated.device != dev_):
             raise RuntimeError("saturated must be an int32 [1] tensor on x's device (ops.conv_domain_flag)")
-    with torch.cuda.device(dev_):
-        wsb = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
+    with _on(dev_):
+        key = (N, I, O, H, W, up)
+        wsb = _WSB.get(key)
+        if wsb is None:
+            wsb = _WSB[key] = L.p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)
         ws = _conv_scratch(dev_, wsb)
         a = _lib.ConvArgs(x.data_ptr() if x is not None else None, weight.data_ptr(), weight_f16.data_ptr() if weight_f16 is not None else None,
                           styles.data_ptr() if styles is not None else None, dcoef.data_ptr() if dcoef is not None else None,

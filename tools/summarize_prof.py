@@ -26,7 +26,7 @@ N_CU, N_SIMD = 256, 1024
 
 
 def is_render(name):
-    return ("k_render<" in name or name.startswith("k_render(") or "k_render_pair" in name) and "finish" not in name
+    return ("k_render<" in name or name.startswith("k_render(") or "k_render_pair" in name or "k_render_quad" in name) and "finish" not in name
 
 
 def main():
