@@ -129,7 +129,7 @@ P3D_DEV void p3d_tap_offsets(const P3dPlaneGeom& g, uint32_t plane_off, uint32_t
 
 // The lane's 64 B of one tap as four 16-B loads (per-lane gathers: one lane = one sample's half texel).  The vector L1 charges
 // such an instruction by the distinct texels it touches (tools/ubench/l1_gather*.hip, in-kernel ablations in
-// profiles/r02_notes.txt); rotating the 16-B slot by the quad index helps in the micro-benchmark and not in the kernels, sharing
+// profiles/history/r02_notes.txt); rotating the 16-B slot by the quad index helps in the micro-benchmark and not in the kernels, sharing
 // a texel inside a quad helps in both: p3d_load16_quad below.
 template <typename RSRC>
 P3D_DEV f32x16 p3d_load16(RSRC rs, uint32_t off) {
@@ -184,7 +184,7 @@ P3D_DEV void p3d_pin16(f32x16& v) {
                       "+v"(v.s9), "+v"(v.sa), "+v"(v.sb), "+v"(v.sc), "+v"(v.sd), "+v"(v.se), "+v"(v.sf) : : "memory");
 }
 #ifndef P3D_GATHER_DEPTH
-#define P3D_GATHER_DEPTH 4  // taps in flight per lane (2 / 3 / 4 / 6 measured within 3 % of each other: profiles/r02_notes.txt)
+#define P3D_GATHER_DEPTH 4  // taps in flight per lane (2 / 3 / 4 / 6 measured within 3 % of each other: profiles/history/r02_notes.txt)
 #endif
 // Tap-granular software pipeline over the 12 taps of a sample (3 planes x nw, ne, sw, se): P3D_GATHER_DEPTH taps (16 registers
 // each) are in flight while the oldest one is folded into its plane's bilinear sum, in the contract's order (nw, ne, sw, se;
@@ -238,7 +238,7 @@ P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
 }
 
 // ---- quad-cooperative gathers ----------------------------------------------------------------------------------------------
-// The vector L1 charges a gather instruction by the distinct texels it touches (profiles/r02_notes.txt: "every ray its own
+// The vector L1 charges a gather instruction by the distinct texels it touches (profiles/history/r02_notes.txt: "every ray its own
 // texel" 63 clk, "a quad shares a texel" 16 clk per instruction), so the four lanes of a quad (4 consecutive samples, same
 // channel half) fetch the half-texel of ONE of their samples per instruction — lane i piece i, 64 contiguous bytes — instead
 // of four pieces of four different texels: instruction r serves sample r of the quad.  A lane then holds 4 channels of each of

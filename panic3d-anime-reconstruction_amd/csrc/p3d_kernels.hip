@@ -856,7 +856,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, TCG)) void k_
     // prev_t / prev_sigma move.  A dead ray (Td < 1e-60: every later weight is exactly 0) drops all its remaining samples.
     // The merge itself runs ONCE, ahead of the walk, as a uniform loop that leaves two bit rows per lane in LDS (merged sample q
     // is coarse / is known); the walk then jumps over a whole run of known samples with a count-trailing-ones — consuming them
-    // one at a time was a chain of two LDS round trips per sample and a quarter of the kernel (profiles/r02_notes.txt).
+    // one at a time was a chain of two LDS round trips per sample and a quarter of the kernel (profiles/history/r02_notes.txt).
     // What is left — the samples that can matter — is decoded one per wave-step until every lane has finished, so a tile of
     // rays that miss the subject runs ~Sf/2 steps instead of Sc + Sf.  A consumed sample's colour is fetched after all if one
     // of its interval weights turns out non-zero (sigma of a neighbour >= ~794): results are bit-identical by construction.
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
 // =====================================================================================================================
 // k_render_quad (round 4): the small-launch kernel with 8 rays x 4 sample slots per wave — lane = ray (j & 7) x slot (j >> 3) x
 // channel half — so that a 128^2-ray view makes 2048 waves = TWO per SIMD (k_render_pair: 1024, one per SIMD, every step's
-// bookkeeping exposed latency: ~4 us per step whether it decodes or not, profiles/r03_notes.txt).  Per-wave LDS rows hold 8 rays
+// bookkeeping exposed latency: ~4 us per step whether it decodes or not, profiles/history/r03_notes.txt).  Per-wave LDS rows hold 8 rays
 // (32 bytes per row instead of 128: 6.6 KB per wave at 96+96).  Everything per ray is executed identically by the ray's eight
 // lanes, as in k_render_pair; a step decodes four consecutive samples of every ray; sigma and the skipped flag are exchanged to
 // all lanes of the ray, the 16 colour channels only towards slot 0, whose lanes write the outputs.  Bit-identical to k_render.

@@ -693,7 +693,7 @@ DEV void conv_glds_wh(const ConvParams& p, const ConvStagePlanW& pl, char* ws, i
 // with buffer_load ... lds only (the patch's LDS order (k half, row, column) IS ascending item order, so every wave writes 64
 // consecutive pieces; padding / channel tail arrive as zeros through the buffer's range check): no staging registers, no
 // conversion VALU, and the O/64 channel-tile workgroups no longer each repeat the fp32 -> hi/lo split of the same patch.
-// Measured (profiles/r03_notes.txt): k_modconv_w2 -4 % .. -16 % per layer, the image-writing FIR pass +2 .. +5 us.
+// Measured (profiles/history/r03_notes.txt): k_modconv_w2 -4 % .. -16 % per layer, the image-writing FIR pass +2 .. +5 us.
 // Variants built on the way and dropped: an UNMODULATED image for every consumer (3x3, transposed 3x3, ToRGB) with the modulation
 // on per-sample weights — the weight preparation (30 us per backbone pass, x N) and the slower ToRGB ate the convolutions' gain.
 // =====================================================================================================================
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
         // b under tap dy reads patch row b + dy, so the wave's two output rows and three dy share FOUR row tiles per dx instead of
         // reading six — and the hi row tiles stay in registers (12 x 4 VGPRs) for phase 2, which then reads weights only:
         // 42 + 18 = 60 ds_read_b128 per wave and chunk instead of 54 + 36 = 90 for the same 108 MFMAs (the LDS port was as busy as the
-        // matrix cores: profiles/r03_notes.txt).  Same products, another summation order (dx-major).
+        // matrix cores: profiles/history/r03_notes.txt).  Same products, another summation order (dx-major).
         f16x8 bh[3][4];
 #pragma unroll
         for (int dxi = 0; dxi < 3; ++dxi) {
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 // waits `vmcnt(0)` in front of the FIRST ds_read that follows it — so the next chunk's patch, requested at the top of a chunk "to
 // land under this chunk's MFMAs", was waited for before the chunk's first MFMA; a_hi(next) had only the 36 MFMAs of phase 2 to land
 // before the `s_waitcnt(0)` of the second barrier; and the epilogue's dcoef / noise / bias loads sat behind uniform branches with a
-// `vmcnt(0)` each.  Two exposed L2 round trips per 16-channel chunk: MFMA-busy 0.13-0.42 (profiles/r03_mfma_util.json).
+// `vmcnt(0)` each.  Two exposed L2 round trips per 16-channel chunk: MFMA-busy 0.13-0.42 (profiles/history/r03_mfma_util.json).
 // Here (the recipe of cdna_hip_programming.md "Pipelining across barriers"):
 //   * every DMA is issued from inline asm (s_mov m0 + buffer_load_dwordx4 ... lds): invisible to the compiler's wait insertion;
 //   * counted `s_waitcnt vmcnt(N)` by hand + raw s_barrier: loads stay in flight ACROSS barriers;
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // k_modconv_up3 (round 4): the stride-2 transposed two-term convolution (conv0 of every block) fed from an activation IMAGE, every
 // operand by LDS-DMA, everything double buffered, ONE barrier per 16-channel chunk (k_modconv_up_h: fp32 input converted in the
-// kernel through registers, two barriers and two exposed DMA round trips per chunk — MFMA-busy 0.07-0.24, profiles/r03_mfma_util.json).
+// kernel through registers, two barriers and two exposed DMA round trips per chunk — MFMA-busy 0.07-0.24, profiles/history/r03_mfma_util.json).
 //   workgroup = 32 output channels x 8 rows x 32 columns of grid positions ((H+1) x (W+1), four output phases each);
 //   wave w    = rows 2w, 2w + 1 (two N tiles of one row x 32 columns: lane j = column j, conflict-free ds_read_b128 at any pitch)
 //               x 4 phases = 8 accumulators; 54 MFMAs per chunk (9 taps x 2 rows x 3 two-term products), 30 ds_read_b128
@@ -1803,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_upsample2x_add(const float* __restrict_
 // y[Y][X] = sum_{fy,fx} f[fy][fx] * x[Y + fy - pady0][X + fx - padx0]
 // Round 3: a thread computes FOUR consecutive outputs of one row from a 4 x 7 window = 8 ds_read_b128 (was 2 x 2 outputs from a
 // 5 x 5 window = 25 ds_read_b32 at a 2-float lane stride: LDS bank-conflict cycles 0.52 of the LDS cycles, VALU-active 0.66;
-// profiles/r03a_mfma_util.json).  Row pitch 96 floats: consecutive rows start 32 banks apart (of the 64 a b128 read sees), so the
+// profiles/history/r03a_mfma_util.json).  Row pitch 96 floats: consecutive rows start 32 banks apart (of the 64 a b128 read sees), so the
 // 16 lanes of every b128 group — 2-4 rows x 4-8 column quads — hit 64 distinct banks.  Same fma order (fy, then fx): same bits.
 #define FIR_PITCH 96
 __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
@@ -2132,14 +2132,14 @@ static void launch_conv(ConvParams p, hipStream_t st) {
 }
 
 #ifndef P3D_KSPLIT_TARGET
-#define P3D_KSPLIT_TARGET 256  // workgroups a launch is split towards.  Batch-1 backbone, ms: 64 -> 1.31, 128 -> 1.15, 256 -> 1.08, 512 (rounds 1-2) -> 1.15, 1024 -> 1.36 (profiles/r03_notes.txt)
+#define P3D_KSPLIT_TARGET 256  // workgroups a launch is split towards.  Batch-1 backbone, ms: 64 -> 1.31, 128 -> 1.15, 256 -> 1.08, 512 (rounds 1-2) -> 1.15, 1024 -> 1.36 (profiles/history/r03_notes.txt)
 #endif
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
 static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) {
     long long wgs = (long long)((GW + tw - 1) / tw) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
     // down to ONE 8-channel chunk per workgroup: at batch 1 the 4^2..16^2 layers are a weight stream (9.4 MB for 512 -> 512 x 3x3)
-    // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/r02_notes.txt
+    // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/history/r02_notes.txt
     while (ks < 64 && wgs * ks < P3D_KSPLIT_TARGET && I / (ks * 2) >= 8) ks *= 2;
     return ks;
 }
@@ -2259,7 +2259,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     // Split-K partial sums.  Up-sampling layer with a SHALLOW split (<= 8 slices: the 64^2 .. 256^2 layers at batch 1): the FIR pass
     // below sums the slices while it loads its tiles — one launch and one round trip of the (2H+1)x(2W+1) intermediate less, the
     // same slice-ordered sum.  Deep splits (the 4^2 .. 32^2 layers, up to 64 slices) keep the separate, chip-wide reduction:
-    // measured (profiles/r03_notes.txt) both a per-element slice loop inside the FIR pass (4.8 + 5.8 -> 37 us at 64 slices) and an
+    // measured (profiles/history/r03_notes.txt) both a per-element slice loop inside the FIR pass (4.8 + 5.8 -> 37 us at 64 slices) and an
     // in-launch last-arriver reduction of the plain convolutions (release / ticket / acquire: +15 .. +50 us per layer) lose to it.
     const bool fir_sums = up == 2 && ksplit > 1 && ksplit <= 8;
     if (ksplit > 1 && !fir_sums) {

@@ -7,7 +7,7 @@ lerp — the reference runs three bilinear resizes, a Sobel, a nearest resize, a
 
 kornia is not a dependency: the kernel restates kornia 0.6.5 `kornia.filters.sobel(x, normalized=True, eps=1e-6)` (3x3
 Sobel kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + eps)) — "parity unpinned": kornia cannot be installed here
-(profiles/r02_notes.txt; tests/golden/make_golden_mesh.py generates the pin where it can).  `front_weight_erosion >= 1`
+(profiles/history/r02_notes.txt; tests/golden/make_golden_mesh.py generates the pin where it can).  `front_weight_erosion >= 1`
 (kornia.morphology.erosion; not used by _scripts/eval/generate.py:55-66) is not mirrored.  `sobel_magnitude`,
 `sample_orthofront` and `xyz_discrepancy` below are the torch formulation of the same steps, kept as the kernel's reference
 in tests/ (`paste_front_torch`).

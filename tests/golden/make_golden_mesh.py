@@ -5,7 +5,7 @@
   * kornia.filters.sobel (kornia 0.6.5)                                                           (training/triplane.py:632,652)
 
 Neither package is installed in the build container and `pip install scikit-image kornia==0.6.5` has no index to talk to
-(profiles/r02_notes.txt records the attempt), so this script is the generator to run in an environment that has them:
+(profiles/history/r02_notes.txt records the attempt), so this script is the generator to run in an environment that has them:
 
     python tests/golden/make_golden_mesh.py        -> tests/golden/mesh_lewiner_{64,128}.npz, tests/golden/sobel_kornia.npz
 

@@ -9,7 +9,7 @@ build/lib_phase.so and leaves the tree untouched:
 The patches are anchored on source text; when an anchor no longer matches the script stops with the anchor it missed.
 Slots: 0/1 coarse gather / MLP, 2/3 final gather / MLP, 4/5 coarse / final decode steps, 6 merge pre-pass, 7 waves,
 8 weights -> LDS, 9 stratified, 10 coarse loop, 11 cdf, 12 draws + sort, 13 final loop, 14 select / skip, 15 march + composite,
-16 wave lifetime.  Results of round 2: profiles/r02_notes.txt.
+16 wave lifetime.  Results of round 2: profiles/history/r02_notes.txt.
 """
 import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

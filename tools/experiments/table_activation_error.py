@@ -5,7 +5,7 @@ Builds the oracle twice — as shipped (polynomial exp / log1p softplus and sigm
 -DOR_EXPERIMENT_TABLE_ACT (cubic-Hermite tables with step 1/16 for the 64 hidden softplus and the 32 colour sigmoids; the
 marcher's own softplus / exp are untouched) — and compares both against every golden the reference produced:
 max |error| per output, inverse-CDF index mismatches, and how far the two variants are from each other.
-    python tools/experiments/table_activation_error.py            (writes profiles/r01_table_activation_experiment.txt)"""
+    python tools/experiments/table_activation_error.py            (writes profiles/history/r01_table_activation_experiment.txt)"""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

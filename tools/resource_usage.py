@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch / occupancy table of every shipped instantiation.
 
-    python tools/resource_usage.py [-o profiles/r03_resource_usage.txt] [-D P3D_XYZ=1 ...]
+    python tools/resource_usage.py [-o profiles/history/r03_resource_usage.txt] [-D P3D_XYZ=1 ...]
 
 Compiles each csrc/*.hip for gfx950 with the product's flags plus `-Rpass-analysis=kernel-resource-usage` (no GPU needed) and
 prints one row per kernel: SGPRs, VGPRs, AGPRs, scratch bytes per lane, waves per SIMD, SGPR / VGPR spills, static LDS.
