@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/panic3d_hip.h"
 
@@ -57,6 +58,7 @@ struct ConvParams {
     int tox;              // up = 2: the intermediate T [N][O][2H+1][OW = pitch] stores column ox at index ox + tox (tox = 1, pitch = 2W + 4: the
                           // FIR pass reads its 36-column windows — columns X0 - 1 .. X0 + 34 — as aligned 16-byte loads); 0 elsewhere
     int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
+    int xcd;              // k_modconv_w3 / k_modconv_up3: XCD-aware workgroup order (p3d_wg_order)
     unsigned int* sat;    // caller-owned device word, OR-ed with 1 when a two-term operand left its domain (or null: not reported)
     // ---- the activation IMAGE path (the producer prepares the consumer's operand; see "activation IMAGE" below)
     const void* ximg;     // input as an image [hi | lo][N][I/8][H][W] of 16-byte pieces, or null (then x + styles are used)
@@ -879,6 +881,26 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 // workgroups per CU.  Same products as k_modconv_w2, summation order (dx-major) identical to it: bit-identical results.
 // Requires O % 64 == 0 (the 3x3 layers of the backbone / super-resolution: 512 .. 64); others take k_modconv_w2<true>.
 // ---------------------------------------------------------------------------------------------------------------------
+// Workgroup order of the image-fed kernels.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with an L2
+// of its own, and in (tile, channel tile) order the four channel tiles of a spatial tile — which read the SAME patch — landed on four
+// different XCDs at four different times: 256 -> 256 @256^2 staged 356 MB of patches out of a 67 MB image, all of it past the L2s.
+// Here XCD x is given a CONTIGUOUS range of the (slice, tile, channel tile) sequence, channel tile fastest: the channel tiles of a
+// tile, and neighbouring tiles with their shared halos, run back to back on one XCD and meet in its L2.
+struct WgOrder { int tile, otile, z; };
+DEV WgOrder p3d_wg_order(bool xcd) {
+    const int T = gridDim.x * gridDim.y * gridDim.z;
+    int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    WgOrder r;
+    if (!xcd) { r.tile = blockIdx.x; r.otile = blockIdx.y; r.z = blockIdx.z; return r; }
+    const int q = T >> 3, rem = T & 7, x = L & 7, m = L >> 3;
+    L = x * q + (x < rem ? x : rem) + m;
+    r.otile = L % gridDim.y;
+    L /= gridDim.y;
+    r.tile = L % gridDim.x;
+    r.z = L / gridDim.x;
+    return r;
+}
+
 #define W3_GROUP_BYTES (768 * 16)
 #define W3_WBYTES (3 * W3_GROUP_BYTES)
 #define W3_SUB ((CONV_TH + 2) * WX_ROW * 16)
@@ -907,9 +929,10 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // an SGPR: the LDS destinations of the DMAs (M0) derive from it
     const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
-    const int gy0 = (blockIdx.x / tiles_x) * CONV_TH, gx0 = (blockIdx.x % tiles_x) * WX_TW;
-    const int o0 = blockIdx.y * 64;
-    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const WgOrder wo = p3d_wg_order(p.xcd != 0);
+    const int gy0 = (wo.tile / tiles_x) * CONV_TH, gx0 = (wo.tile % tiles_x) * WX_TW;
+    const int o0 = wo.otile * 64;
+    const int n = wo.z / p.ksplit, kz = wo.z - n * p.ksplit;
     const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
     const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
     const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
@@ -937,14 +960,15 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     }
     const bool last_lanes = lane < (CONV_TH + 2) * WX_ROW - 5 * 64;  // the sixth instruction covers items 320 .. 339
     const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
-    auto issue_patch = [&](int chunk, int buf) {  // chunk >= nch: a zero-length resource (zeros, no traffic, same instruction count)
-        const int ic0 = ic_beg + 16 * chunk;
+    // chunk >= nch: a zero-length resource (zeros, no traffic, same instruction count)
+    auto patch_rsrc = [&](int chunk) {
         const bool in = chunk < nch;
-        const i32x4 rs = w3_rsrc(img_base + (size_t)(in ? ic0 >> 3 : 0) * HW * 16, in ? 2u * HW * 16u : 0u);
-        const uint32_t dst = lds0 + W3_WBYTES + buf * W3_PATCH + wave * W3_SUB;
-#pragma unroll
-        for (int u = 0; u < 5; ++u) w3_dma16(dst + u * 1024, rs, pvoff[u]);
-        if (last_lanes) w3_dma16(dst + 5 * 1024, rs, pvoff[5]);
+        return w3_rsrc(img_base + (size_t)(in ? (ic_beg + 16 * chunk) >> 3 : 0) * HW * 16, in ? 2u * HW * 16u : 0u);
+    };
+    auto patch_piece = [&](const i32x4& rs, int buf, int u) {  // u: compile-time after unrolling
+        const uint32_t dst = lds0 + W3_WBYTES + buf * W3_PATCH + wave * W3_SUB + u * 1024;
+        if (u < 5) w3_dma16(dst, rs, pvoff[u]);
+        else if (last_lanes) w3_dma16(dst, rs, pvoff[5]);
     };
     // Weights: piece q = u * 256 + tid of a group = (hi|lo, dy, k half, o); group g (dx = g - 1) adds g * I * 2 bytes
     const int LO = p.O * 9 * p.I * 2;  // bytes of the hi tensor (the lo parts follow it)
@@ -955,13 +979,13 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
         const int dyi = rem >> 7, kh = (rem >> 6) & 1, o = rem & 63;
         wvoff[u] = which * LO + (((o0 + o) * 9 + dyi * 3) * p.I + 8 * kh) * 2;
     }
-    auto issue_w = [&](int chunk, int g) {
+    auto w_rsrc = [&](int chunk) {
         const int ic0 = ic_beg + 16 * chunk;
         const bool in = chunk < nch;
-        const i32x4 rs = w3_rsrc((const char*)p.wh + (size_t)(in ? ic0 : 0) * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
-        const uint32_t dst = lds0 + g * W3_GROUP_BYTES + wave * 1024;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) w3_dma16(dst + u * 4096, rs, wvoff[u] + g * p.I * 2);
+        return w3_rsrc((const char*)p.wh + (size_t)(in ? ic0 : 0) * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
+    };
+    auto w_piece = [&](const i32x4& rs, int g, int u) {
+        w3_dma16(lds0 + g * W3_GROUP_BYTES + wave * 1024 + u * 4096, rs, wvoff[u] + g * p.I * 2);
     };
 
     f32x16 acc[2][2];  // [channel tile][row of the wave's row pair]
@@ -975,16 +999,24 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     const int blane = half * W3_SUB + (prow * WX_ROW + j) * 16;  // patch row prow, column j of this lane's k half (hi image)
     const int alane = (half * 64 + j) * 16;
 
-    // ---- prologue: [patch(0) 6][W0(0) 3][W1(0) 3][W2(0) 3][patch(1) 6]; the first two must have landed
-    issue_patch(0, 0);
-    issue_w(0, 0);
-    issue_w(0, 1);
-    issue_w(0, 2);
-    issue_patch(1, 1);
-    W3_VMWAIT(12);
+    // ---- prologue: [patch(0) 6][W0(0) 3][W1(0) 3]; the first two must have landed.
+    // The loop issues its DMA pieces BETWEEN the MFMAs of a phase (an LDS-DMA costs ~100 issue clocks; back to back after a barrier
+    // they were a bubble of the matrix core): phase 0 of chunk k requests patch(k+1) and W2(k) (9 pieces), phase 1 W0(k+1), phase 2
+    // W1(k+1) (3 each).  A barrier needs what EARLIER phases requested, so its counted wait leaves this phase's own pieces in flight.
+    {
+        const i32x4 rp = patch_rsrc(0), rw = w_rsrc(0);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) patch_piece(rp, 0, u);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) w_piece(rw, 0, u);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) w_piece(rw, 1, u);
+    }
+    W3_VMWAIT(3);
     __builtin_amdgcn_s_barrier();
     for (int k = 0; k < nch; ++k) {
         const char* pb = lds + W3_WBYTES + (k & 1) * W3_PATCH + blane;
+        const i32x4 rp = patch_rsrc(k + 1), rw0 = w_rsrc(k), rw1 = w_rsrc(k + 1);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const char* wg = lds + g * W3_GROUP_BYTES + alane;
@@ -1003,19 +1035,28 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
                     al[a] = *reinterpret_cast<const f16x8*>(wg + 384 * 16 + (dyi * 128 + a * 32) * 16);
                 }
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b + dyi], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b + dyi], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b + dyi], acc[a][b], 0, 0, 0);
                     }
+                    if (a == 0) {  // half of this tap row's MFMAs are queued: the pieces issue under them
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g == 0) {
+                            patch_piece(rp, (k + 1) & 1, 2 * dyi);
+                            patch_piece(rp, (k + 1) & 1, 2 * dyi + 1);
+                            w_piece(rw0, 2, dyi);
+                        } else {
+                            w_piece(rw1, g - 1, dyi);
+                        }
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (g == 2) W3_VMWAIT(3); else W3_VMWAIT(9);
-            __builtin_amdgcn_s_barrier();  // group g (g == 2: and this patch buffer) is free; what the next phase reads has landed
-            issue_w(k + 1, g);
-            if (g == 2) issue_patch(k + 2, k & 1);
+            if (g == 0) W3_VMWAIT(9); else W3_VMWAIT(3);
+            __builtin_amdgcn_s_barrier();  // what the next phase reads has landed; group g (g == 2: and this patch buffer) is free
         }
     }
     W3_VMWAIT(0);  // nothing may land in LDS after this workgroup has given it back
@@ -1116,9 +1157,10 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
-    const int gy0 = (blockIdx.x / tiles_x) * 8, gx0 = (blockIdx.x % tiles_x) * WX_TW;
-    const int o0 = blockIdx.y * 32;
-    const int n = blockIdx.z / p.ksplit, kz = blockIdx.z - n * p.ksplit;
+    const WgOrder wo = p3d_wg_order(p.xcd != 0);
+    const int gy0 = (wo.tile / tiles_x) * 8, gx0 = (wo.tile % tiles_x) * WX_TW;
+    const int o0 = wo.otile * 32;
+    const int n = wo.z / p.ksplit, kz = wo.z - n * p.ksplit;
     const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
     const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
     const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
@@ -1147,18 +1189,24 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
         wvoff[i] = (q < 1152 && o0 + o < p.O) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
     }
     const bool five = wave < 2;  // instructions 16, 17 exist for waves 0, 1 only
-    auto issue = [&](int chunk, int buf) {
-        const int ic0 = ic_beg + 16 * chunk;
-        const i32x4 rp = w3_rsrc(img_base + (size_t)(ic0 >> 3) * HW * 16, 2u * HW * 16u);
-        const i32x4 rw = w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, (uint32_t)(2 * LO - ic0 * 2));
+    // piece i of chunk `chunk` into buffer `buf`: 0 .. 4 the patch (4: partial), 5 .. 9 the weights (9: waves 0, 1).  chunk >= nch: a
+    // zero-length resource (zeros into the idle buffer, no traffic, the same instruction count)
+    struct U3Rs { i32x4 rp, rw; };
+    auto rsrcs = [&](int chunk) {
+        const bool in = chunk < nch;
+        const int ic0 = in ? ic_beg + 16 * chunk : 0;
+        U3Rs r;
+        r.rp = w3_rsrc(img_base + (size_t)(ic0 >> 3) * HW * 16, in ? 2u * HW * 16u : 0u);
+        r.rw = w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
+        return r;
+    };
+    auto piece = [&](const U3Rs& r, int buf, int i) {  // i: compile-time after unrolling
         const uint32_t pd = lds0 + 2 * U3_WB + buf * U3_PATCH + wave * U3_SUB;
         const uint32_t wd = lds0 + buf * U3_WB + wave * 1024;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w3_dma16(pd + u * 1024, rp, pvoff[u]);
-        if (last_lanes) w3_dma16(pd + 4 * 1024, rp, pvoff[4]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w3_dma16(wd + i * 4096, rw, wvoff[i]);
-        if (five) w3_dma16(wd + 4 * 4096, rw, wvoff[4]);
+        if (i < 4) w3_dma16(pd + i * 1024, r.rp, pvoff[i]);
+        else if (i == 4) { if (last_lanes) w3_dma16(pd + 4 * 1024, r.rp, pvoff[4]); }
+        else if (i < 9) w3_dma16(wd + (i - 5) * 4096, r.rw, wvoff[i - 5]);
+        else if (five) w3_dma16(wd + 4 * 4096, r.rw, wvoff[4]);
     };
 
     f32x16 acc[4][2];  // [phase = 2 py + px][row of the wave's pair]
@@ -1174,37 +1222,69 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     // (phase, tap, input) of the nine products: input 0 = x[y][x], 1 = x[y][x-1], 2 = x[y-1][x], 3 = x[y-1][x-1]
     const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
 
-    if (nch > 0) issue(0, 0);
+    {
+        const U3Rs r0 = rsrcs(0);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) piece(r0, 0, i);
+    }
     W3_VMWAIT(0);
     __builtin_amdgcn_s_barrier();
-    for (int k = 0; k < nch; ++k) {
-        if (k + 1 < nch) issue(k + 1, (k + 1) & 1);
-        const char* pb = lds + 2 * U3_WB + (k & 1) * U3_PATCH + blane;
-        const char* wb = lds + (k & 1) * U3_WB + alane;
-        // rows 2w, 2w + 1, 2w + 2 of the patch x columns j (dx = -1), j + 1 (dx = 0), hi and lo
-        f16x8 bh[3][2], bl[3][2];
+    // QM: the taps (bits of q) this tile needs, NT: its rows per wave, W0: only wave 0 has a valid row.  The grid is (H + 1) x (W + 1):
+    // its last column / row is a tile of its own whose lanes see zeros for x[.][W] / x[H][.], i.e. 6 of the 9 taps add exact zeros
+    // (never -0: an accumulator that starts at +0 cannot become -0) — those tiles skip them and leave the matrix core to their neighbours.
+    auto run = [&](auto QMc, auto NTc, auto W0c) {
+        constexpr int QM = decltype(QMc)::value, NT = decltype(NTc)::value;
+        constexpr bool W0 = decltype(W0c)::value, FULL = QM == 0x1FF;
+        for (int k = 0; k < nch; ++k) {
+            const U3Rs rn = rsrcs(k + 1);
+            if (!FULL) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * WX_ROW + c) * 16);
-                bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * U3_SUB + (r * WX_ROW + c) * 16);
+                for (int i = 0; i < 10; ++i) piece(rn, (k + 1) & 1, i);
             }
+            if (!W0 || wave == 0) {
+                const char* pb = lds + 2 * U3_WB + (k & 1) * U3_PATCH + blane;
+                const char* wb = lds + (k & 1) * U3_WB + alane;
+                // rows 2w, 2w + 1, 2w + 2 of the patch x columns j (dx = -1), j + 1 (dx = 0), hi and lo
+                f16x8 bh[3][2], bl[3][2];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + TP[q] * 64 * 16);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(wb + (9 + TP[q]) * 64 * 16);
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int r = 1 + t - (BO[q] >> 1), c = 1 - (BO[q] & 1);
-                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[r][c], acc[PH[q]][t], 0, 0, 0);
-                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[r][c], acc[PH[q]][t], 0, 0, 0);
-                acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                    for (int c = 0; c < 2; ++c) {
+                        bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * WX_ROW + c) * 16);
+                        bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * U3_SUB + (r * WX_ROW + c) * 16);
+                    }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    if (!((QM >> q) & 1)) continue;
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + TP[q] * 64 * 16);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + (9 + TP[q]) * 64 * 16);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int r = 1 + t - (BO[q] >> 1), c = 1 - (BO[q] & 1);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[r][c], acc[PH[q]][t], 0, 0, 0);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                        // a full tile issues the next chunk's ten pieces two at a time under the MFMAs of its first five taps
+                        if (FULL && t == 0 && q < 5) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            piece(rn, (k + 1) & 1, 2 * q);
+                            piece(rn, (k + 1) & 1, 2 * q + 1);
+                        }
+                    }
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            W3_VMWAIT(0);
+            __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        W3_VMWAIT(0);
-        __builtin_amdgcn_s_barrier();
+    };
+    {
+        using std::integral_constant;
+        const bool col_edge = gx0 == p.W, row_edge = gy0 == p.H;  // (uniform)
+        if (!col_edge && !row_edge) run(integral_constant<int, 0x1FF>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else if (!row_edge) run(integral_constant<int, 0x130>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else if (!col_edge) run(integral_constant<int, 0x1C0>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        else run(integral_constant<int, 0x100>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
     }
     // ---- raw store: a lane owns both column phases (ox = 2 gx, 2 gx + 1) of its grid point: one 8-byte store per (row phase, channel),
     // 32 lanes = 256 contiguous bytes; the last grid column (gx = W) has only px = 0: a 4-byte store of its own
@@ -1423,9 +1503,15 @@ struct TorgbParams {
     float clamp;
 };
 #define TG_KC 64
-template <int MT, bool KS>
+// MS (KS only, MT = 1): the workgroup multiplies ONE of the three 32-channel tiles of a 96-channel layer (blockIdx.z): on the
+// 4^2 .. 64^2 maps a launch is a handful of workgroups, each a serial chain of 192 f32 MFMAs per wave (64 clocks each) — three times
+// the workgroups, a third of the chain; the same sums in the same order.
+template <int MT, bool KS, bool MS = false>
 __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
+    static_assert(!MS || (KS && MT == 1), "the channel-tile split is a variant of the small-map shape");
     constexpr int OP = 32 * MT, ABUF = TG_KC * OP;  // floats per A chunk
+    constexpr int OPW = MS ? 96 : OP;               // floats per row of wt
+    const int chb = MS ? 32 * blockIdx.z : 0;       // first output channel of this workgroup
     extern __shared__ __attribute__((aligned(16))) float tg_lds[];
     float* As = tg_lds;                 // [2][TG_KC][OP]
     float* Ss = tg_lds + 2 * ABUF;      // [I] styles of this image (I <= 512... sized by the host)
@@ -1438,7 +1524,7 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
     for (int i = tid; i < ((p.I + TG_KC - 1) / TG_KC) * TG_KC; i += 256) Ss[i] = i < p.I ? p.styles[(size_t)n * p.I + i] : 0.0f;  // zero tail: no predicate in the K loop
     // x of this image through a buffer resource: per-lane offset = ((channel pair + h) * HW + pixel) * 4
     auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.I * HW), 0, p.I * HW * 4, CONV_RSRC_FLAGS);
-    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.I * OP * 4, CONV_RSRC_FLAGS);
+    auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.I * OPW * 4, CONV_RSRC_FLAGS);
     const int xoff = (h * HW + pxc) * 4;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // one A chunk = TG_KC * OP floats, contiguous in wt: 16 bytes per lane per instruction (channels beyond I arrive as zeros)
@@ -1446,9 +1532,11 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
         const int base = chunk * ABUF * 4;
         static_assert((ABUF * 4) % 4096 == 0, "a chunk is a whole number of 256-lane x 16-byte rounds");
 #pragma unroll
-        for (int u = 0; u < ABUF * 4 / 4096; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)((char*)(As + buf * ABUF) + (u * 256 + (tid & ~63)) * 16), 16,
-                                                     base + (u * 256 + tid) * 16, 0, 0, 0);
+        for (int u = 0; u < ABUF * 4 / 4096; ++u) {
+            const int idx = u * 256 + tid;  // 16-byte piece of the chunk; MS: row idx / 8 of wt, 128 bytes from column chb
+            const int src = MS ? ((chunk * TG_KC + (idx >> 3)) * OPW + chb) * 4 + (idx & 7) * 16 : base + idx * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)((char*)(As + buf * ABUF) + (u * 256 + (tid & ~63)) * 16), 16, src, 0, 0, 0);
+        }
     };
     constexpr int NC = KS ? TG_KC / 8 : TG_KC / 2;  // channel pairs of a chunk this wave multiplies: all 32, or its quarter
     const int c0 = KS ? wave * NC : 0;
@@ -1559,7 +1647,7 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
 #pragma unroll
         for (int e = 0; e < GS; ++e) {  // values (branch-free)
             const int slot = ebase + (g8 * GS + e) * estride, t = slot >> 4, r = slot & 15;
-            const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ch = chb + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int chc = ch < p.O ? ch : p.O - 1;
             float v = vals[g8 * GS + e];
             const float bb = bp[has_bias ? chc : 0];
@@ -1574,7 +1662,7 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
 #pragma unroll
         for (int e = 0; e < GS; ++e) {  // stores
             const int slot = ebase + (g8 * GS + e) * estride, t = slot >> 4, r = slot & 15;
-            const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ch = chb + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (ch < p.O) yn[(size_t)ch * HW] = outv[e];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2051,14 +2139,14 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
             }
         }
     };
-    Stage va, vb;
+    Stage va;  // ONE staging set: the second half is requested once the first sits in LDS and lands under its filtering
     fetch(0, va);
-    fetch(1, vb);
     put(va);
     __syncthreads();
+    fetch(1, va);
     filter(0);
     __syncthreads();
-    put(vb);
+    put(va);
     __syncthreads();
     filter(1);
     if (Y >= p.OH || Xb >= p.OW) return;
@@ -2135,9 +2223,17 @@ static void launch_conv(ConvParams p, hipStream_t st) {
 #define P3D_KSPLIT_TARGET 256  // workgroups a launch is split towards.  Batch-1 backbone, ms: 64 -> 1.31, 128 -> 1.15, 256 -> 1.08, 512 (rounds 1-2) -> 1.15, 1024 -> 1.36 (profiles/history/r03_notes.txt)
 #endif
 // split-K factor: small feature maps (4^2..64^2) give too few workgroups for 256 CUs; split the K loop until ~512
+static int ksplit_target_image() {  // the image-fed kernels (k_modconv_w3 / k_modconv_up3); P3D_KSPLIT_TARGET_IMG in the environment: A/B runs
+    static const int v = getenv("P3D_KSPLIT_TARGET_IMG") ? atoi(getenv("P3D_KSPLIT_TARGET_IMG")) : P3D_KSPLIT_TARGET;
+    return v;
+}
 static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) {
     long long wgs = (long long)((GW + tw - 1) / tw) * ((GH + CONV_TH - 1) / CONV_TH) * ((O + 63) / 64) * N;
     int ks = 1;
+    if (tw == WX_TW) {
+        while (ks < 64 && wgs * ks < ksplit_target_image() && I / (ks * 2) >= 8) ks *= 2;
+        return ks;
+    }
     // down to ONE 8-channel chunk per workgroup: at batch 1 the 4^2..16^2 layers are a weight stream (9.4 MB for 512 -> 512 x 3x3)
     // that 8..16 workgroups cannot pull in; measured at batch 1: b4.conv1 36 -> see profiles/history/r02_notes.txt
     while (ks < 64 && wgs * ks < P3D_KSPLIT_TARGET && I / (ks * 2) >= 8) ks *= 2;
@@ -2157,7 +2253,7 @@ static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0
 static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
     int ks = 1;
-    while (ks < 64 && wgs * ks < P3D_KSPLIT_TARGET && I / (ks * 2) >= 16) ks *= 2;
+    while (ks < 64 && wgs * ks < ksplit_target_image() && I / (ks * 2) >= 16) ks *= 2;
     return ks;
 }
 
@@ -2236,6 +2332,8 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
     p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2; p.tox = up == 2 ? 1 : 0;
+    static const bool xcd_order = !getenv("P3D_NO_XCD_ORDER");  // (A/B runs)
+    p.xcd = xcd_order ? 1 : 0;
     // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
     const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !getenv("P3D_NO_W3");
     p.yimg = w3_img ? yimg : nullptr; p.yimg_lo = (long long)N * O * H * W * 2; p.ystyles = ystyles;
@@ -2394,11 +2492,14 @@ int p3d_torgb_f32(const float* x, int N, int I, int H, int W, const float* w_t, 
     // PX shape (a wave = 32 pixels x all K) once the map alone gives >= 512 workgroups of 128 pixels; KS (a workgroup = 32 pixels,
     // waves split K) below that
     const bool ks = (long long)N * ((HW + 127) / 128) < 512;
-    const size_t lds = (size_t)(2 * TG_KC * 32 * MT + ((I + 63) / 64) * 64) * 4;
-    dim3 grid((unsigned)(ks ? (HW + 31) / 32 : (HW + 127) / 128), (unsigned)N);
+    // small maps of a 96-channel layer: one workgroup per 32-channel tile while that still leaves the chip underfilled
+    const bool ms = ks && MT == 3 && (long long)N * ((HW + 31) / 32) * 3 <= 1024 && !getenv("P3D_NO_TORGB_MS");
+    const size_t lds = (size_t)(2 * TG_KC * 32 * (ms ? 1 : MT) + ((I + 63) / 64) * 64) * 4;
+    dim3 grid((unsigned)(ks ? (HW + 31) / 32 : (HW + 127) / 128), (unsigned)N, ms ? 3u : 1u);
     if (lds > 64 * 1024) return P3D_E_RANGE;  // (53 KB at I = 1024, O = 96: inside the default dynamic-LDS limit, no per-device attribute to set)
 #define P3D_TORGB(MTV, KSV) hipLaunchKernelGGL((k_torgb<MTV, KSV>), grid, dim3(256), lds, (hipStream_t)stream, p)
     if (MT == 1) { if (ks) P3D_TORGB(1, true); else P3D_TORGB(1, false); }
+    else if (ms) hipLaunchKernelGGL((k_torgb<1, true, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else { if (ks) P3D_TORGB(3, true); else P3D_TORGB(3, false); }
     return chk();
 }
