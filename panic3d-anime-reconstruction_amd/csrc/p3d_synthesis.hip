@@ -67,6 +67,7 @@ struct ConvParams {
     void* yimg;
     long long yimg_lo;    // = N*O*OH*OW*2
     const float* ystyles;
+    const float* fir;     // k_modconv_up3<true>: the 4x4 filter of the FIR pass it contains (flipped, times up^2)
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
@@ -1152,13 +1153,24 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
 #define U3_SUB (U3_ROWS * WX_ROW * 16)             // one (hi|lo, k half) sub-image of the patch: 4 896
 #define U3_PATCH (4 * U3_SUB)
 #define U3_LDS (2 * U3_WB + 2 * U3_PATCH)
+// FUSED (unsplit launches whose consumer takes an activation image): the FIR pass and the layer's epilogue run IN this kernel — the
+// (2H+1) x (2W+1) fp32 intermediate (135 MB written and read back at 256 -> 128 @256^2 -> 512^2: the transposed convolution was
+// bound by that store, not by its MFMAs) never exists.  A workgroup's 8 x 32 grid points are 16 x 64 intermediate values per channel,
+// enough for 12 x 60 outputs of the 4x4 filter: tiles advance by 6 x 30 grid points (1.42 x the MFMA work), the accumulators go to LDS
+// (the pipeline's buffers, free after the K loop) sixteen channels at a time, and every thread filters 4 pixels x 8 channels and
+// stores the consumer's 16-byte pieces — the products, sums and filter order of k_modconv_up3<false> + k_fir4x4_img, bit for bit.
+#define U3F_PS (16 * 64 + 8)   // floats per channel plane of the intermediate tile in LDS (16 rows x 64 columns + 8: the four channel pairs a wave reads at once start 16 banks apart)
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[U3_LDS];
+    static_assert(16 * U3F_PS * 4 <= U3_LDS, "sixteen channels of a 16 x 64 intermediate tile fit the pipeline's buffers");
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (p.GW + WX_TW - 1) / WX_TW;
+    const int tiles_x = FUSED ? (2 * p.W + 59) / 60 : (p.GW + WX_TW - 1) / WX_TW;
     const WgOrder wo = p3d_wg_order(p.xcd != 0);
-    const int gy0 = (wo.tile / tiles_x) * 8, gx0 = (wo.tile % tiles_x) * WX_TW;
+    // FUSED: outputs [12 ty, 12 ty + 12) x [60 tx, 60 tx + 60) need intermediate rows 12 ty - 1 .. and columns 60 tx - 1 ..: grid origin -1
+    const int gy0 = FUSED ? (wo.tile / tiles_x) * 6 - 1 : (wo.tile / tiles_x) * 8;
+    const int gx0 = FUSED ? (wo.tile % tiles_x) * 30 - 1 : (wo.tile % tiles_x) * WX_TW;
     const int o0 = wo.otile * 32;
     const int n = wo.z / p.ksplit, kz = wo.z - n * p.ksplit;
     const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
@@ -1166,6 +1178,25 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
     const int HW = p.H * p.W;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    // FUSED: the epilogue's per-channel constants (read after the K loop's barriers) and this thread's twelve noise values, requested
+    // here so that no global round trip is left between the K loop and the stores
+    __shared__ float epi[FUSED ? 96 : 1];
+    float nzv[FUSED ? 12 : 1];
+    if constexpr (FUSED) {
+        if (tid < 32) {
+            const int ch = o0 + tid;
+            epi[tid] = p.dcoef ? p.dcoef[(size_t)n * p.O + ch] : 1.0f;
+            epi[32 + tid] = p.bias ? p.bias[ch] : 0.0f;
+            epi[64 + tid] = p.ystyles[(size_t)n * p.O + ch];
+        }
+        const int OHo = 2 * p.H, OWo = 2 * p.W, X = 2 * gx0 + 2 + (tid >> 2);
+        const float* nz = p.noise ? p.noise + (p.noise_per_sample ? (long long)n * OHo * OWo : 0) : nullptr;
+#pragma unroll
+        for (int ly = 1; ly < 13; ++ly) {
+            const int Y = 2 * gy0 + 1 + ly;
+            nzv[ly - 1] = (nz && (tid >> 2) < 60 && X < OWo && Y < OHo) ? nz[(long long)Y * OWo + X] : 0.0f;
+        }
+    }
     // ---- DMA plans.  Patch: wave w owns sub-image w = (hi|lo, k half): 9 x 34 items, 4 full + 1 partial instruction
     const int sub_which = wave >> 1, sub_kh = wave & 1;
     int pvoff[5];
@@ -1280,11 +1311,107 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     };
     {
         using std::integral_constant;
-        const bool col_edge = gx0 == p.W, row_edge = gy0 == p.H;  // (uniform)
+        const bool col_edge = !FUSED && gx0 == p.W, row_edge = !FUSED && gy0 == p.H;  // (uniform)
         if (!col_edge && !row_edge) run(integral_constant<int, 0x1FF>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
         else if (!row_edge) run(integral_constant<int, 0x130>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
         else if (!col_edge) run(integral_constant<int, 0x1C0>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
         else run(integral_constant<int, 0x100>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    }
+    if constexpr (FUSED) {
+        // ---- FIR + epilogue.  Output (Y, X) = (2 gy0 + 1 + ly, 2 gx0 + 1 + lx), ly in [1, 13), lx in [1, 61), reads the local
+        // intermediate rows ly .. ly + 3, columns lx .. lx + 3 (= T[Y - 1 + fy][X - 1 + fx]); grid points outside the map gave exact
+        // zeros (the FIR pass's zero padding).  Sixteen channels at a time through LDS; a thread = (channel pair, output column) and
+        // walks the 12 rows with a 4 x 4 window per channel in registers: consecutive lanes = the four channel pairs of a 16-byte
+        // piece, then the next pixel — a wave's 4-byte stores are 256 contiguous bytes of the hi (and of the lo) image.
+        float* T = reinterpret_cast<float*>(lds);  // [16 channels][16 rows][64] at a plane stride of U3F_PS floats
+        const int OHo = 2 * p.H, OWo = 2 * p.W;
+        float fs[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fs[i] = p.fir[i];
+        const long long lo_off = (long long)p.N * p.O * OHo * OWo * 2;
+        const bool has_nz = p.noise != nullptr;
+        const int xq = tid >> 2, cpl = tid & 3;      // output column 1 + xq of the tile, channel pair cpl of its 8-channel group
+        const int X = 2 * gx0 + 2 + xq;
+        const bool col_ok = xq < 60 && X < OWo;
+        bool bad = false;
+#pragma unroll 1
+        for (int bt = 0; bt < 2; ++bt) {
+            if (bt) __builtin_amdgcn_s_barrier();  // (the loop ended on a barrier: every wave is done with the buffers)
+            if (bt == 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr)
+                            T[((rr & 3) + 8 * (rr >> 2) + 4 * half) * U3F_PS + (2 * (2 * wave + t) + (ph >> 1)) * 64 + 2 * j + (ph & 1)] =
+                                acc[ph][t][rr] * HX_SPLIT_UNSCALE;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr)
+                            T[((rr & 3) + 8 * (rr >> 2) + 4 * half) * U3F_PS + (2 * (2 * wave + t) + (ph >> 1)) * 64 + 2 * j + (ph & 1)] =
+                                acc[ph][t][8 + rr] * HX_SPLIT_UNSCALE;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int c8 = (o0 >> 3) + 2 * bt + g2;   // channels 8 c8 .. 8 c8 + 7 of the layer; this thread: 8 c8 + 2 cpl, + 1
+                float dc[2], bs[2], ns[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int cl = 16 * bt + 8 * g2 + 2 * cpl + c;  // channel of the workgroup's 32
+                    dc[c] = epi[cl]; bs[c] = epi[32 + cl]; ns[c] = epi[64 + cl];
+                }
+                const float* Tc = T + (g2 * 8 + 2 * cpl) * U3F_PS + 1 + (xq < 60 ? xq : 0);
+                float win[2][4][4];  // [channel][row slot = local row & 3][tap column]
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 1; r < 4; ++r)
+#pragma unroll
+                        for (int fx = 0; fx < 4; ++fx) win[c][r][fx] = Tc[c * U3F_PS + r * 64 + fx];
+                char* dst = (char*)p.yimg + (((size_t)n * (p.O >> 3) + c8) * OHo * (size_t)OWo + X) * 16 + cpl * 4;
+#pragma unroll
+                for (int ly = 1; ly < 13; ++ly) {
+                    const int Y = 2 * gy0 + 1 + ly;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int fx = 0; fx < 4; ++fx) win[c][(ly + 3) & 3][fx] = Tc[c * U3F_PS + (ly + 3) * 64 + fx];
+                    const bool ok = col_ok && Y < OHo;
+                    const float nvv = nzv[ly - 1];
+                    _Float16 hh[2], ll[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float o = 0.0f;
+#pragma unroll
+                        for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+                            for (int fx = 0; fx < 4; ++fx) o = __builtin_fmaf(fs[fy * 4 + fx], win[c][(ly + fy) & 3][fx], o);
+                        float a = o * dc[c];
+                        a = has_nz ? a + nvv : a;
+                        a = a + bs[c];
+                        a = ns[c] * act_apply(a, p.act, p.alpha, p.gain, p.clamp) * HX_SPLIT_SCALE_X;  // (k_fir4x4_img's epilogue)
+                        bad = bad || (ok && !(__builtin_fabsf(a) <= 65504.0f));
+                        a = __builtin_fminf(__builtin_fmaxf(a, -65504.0f), 65504.0f);
+                        hh[c] = (_Float16)a;
+                        ll[c] = (_Float16)(a - (float)hh[c]);
+                    }
+                    if (ok) {
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<f16x2*>(dst + (size_t)Y * OWo * 16) = (f16x2){hh[0], hh[1]};
+                        *reinterpret_cast<f16x2*>(dst + lo_off + (size_t)Y * OWo * 16) = (f16x2){ll[0], ll[1]};
+                    }
+                    if ((ly & 3) == 0) asm volatile("" ::: "memory");  // four rows of LDS reads in flight, not all twelve in one 100-register block
+                }
+            }
+        }
+        if (bad && p.sat) atomicOr(p.sat, 1u);
+        return;
     }
     // ---- raw store: a lane owns both column phases (ox = 2 gx, 2 gx + 1) of its grid point: one 8-byte store per (row phase, channel),
     // 32 lanes = 256 contiguous bytes; the last grid column (gx = W) has only px = 0: a 4-byte store of its own
@@ -2005,14 +2132,15 @@ __global__ __launch_bounds__(256) void k_fir4x4_tiled(FirParams p) {
 }
 
 // k_fir4x4_tiled writing an activation IMAGE for the layer that follows (FirParams::nstyles): a workgroup = a 32 x 32 output tile of EIGHT consecutive channels (blockIdx.y = (n, c8)),
-// in two halves of four channels through one LDS image (pitch 40: 22 KB, seven workgroups per CU): the second half's loads are in
-// flight while the first is filtered.  A thread's 4 pixels x 8 channels leave as 4 pieces of hi parts + 4 of lo parts, 512
+// in 8 / CPS stages of CPS channels through one LDS image (pitch 40; CPS = 2: 11 KB, 125 VGPRs): the next stage's loads are in
+// flight while this one is filtered.  A thread's 4 pixels x 8 channels leave as 4 pieces of hi parts + 4 of lo parts, 512
 // contiguous bytes per 8 threads.  Always applies the epilogue.  (Measured at 512^2 x 128 channels, whole up-convolution: channel
 // by channel through two buffers 381 us, all eight tiles resident (45 KB, 3 workgroups per CU) 342 us, fp32 output 303 us.)
 #define FIRI_PITCH 40
-template <bool VEC>  // VEC: the input rows are 16-byte aligned (decided by the host: fir_rows_aligned)
-__global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restrict__ yimg, long long lo_off, unsigned int* sat) {
-    __shared__ __attribute__((aligned(16))) float tile[4][35 * FIRI_PITCH];
+// CPS: channels per LDS stage (8 / CPS stages per tile); WPE: waves per SIMD the register budget is held to
+template <bool VEC, int CPS, int WPE>  // VEC: the input rows are 16-byte aligned (decided by the host: fir_rows_aligned)
+__global__ __launch_bounds__(256, WPE) void k_fir4x4_img(FirParams p, char* __restrict__ yimg, long long lo_off, unsigned int* sat) {
+    __shared__ __attribute__((aligned(16))) float tile[CPS][35 * FIRI_PITCH];
     __shared__ float fs[16];
     const int tid = threadIdx.x;
     const int tiles_x = (p.OW + 31) / 32;
@@ -2050,43 +2178,43 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const int v = X0 + 4 * c4 + e - p.padx0; vm[ps][e] = v >= 0 && v < p.W; }
     }
-    struct Stage { float s[VEC ? 1 : 4][5]; f32x4 v[VEC ? 4 : 1][2]; };
+    struct Stage { float s[VEC ? 1 : CPS][5]; f32x4 v[VEC ? CPS : 1][2]; };
     auto fetch = [&](int half, Stage& st) {
         if constexpr (vec) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps)
-                    st.v[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[ps], (half * 4 + ch) * HP * 4, 0));
+                    st.v[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[ps], (half * CPS + ch) * HP * 4, 0));
             for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce)
                 auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * HP * 4, CONV_RSRC_FLAGS);
-                f32x4 t[4][2];
+                f32x4 t[CPS][2];
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
+                for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps)
-                        t[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff[ps], (half * 4 + ch) * HP * 4, 0));
+                        t[ch][ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff[ps], (half * CPS + ch) * HP * 4, 0));
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
+                for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) { st.v[ch][ps].x += t[ch][ps].x; st.v[ch][ps].y += t[ch][ps].y; st.v[ch][ps].z += t[ch][ps].z; st.v[ch][ps].w += t[ch][ps].w; }
             }
         } else {
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
+        for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
             for (int ps = 0; ps < 5; ++ps)
-                st.s[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[ps], (half * 4 + ch) * HP * 4, 0));
+                st.s[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off[ps], (half * CPS + ch) * HP * 4, 0));
         for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce); 20 independent loads per slice
             auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)k * p.slice), 0, 8 * HP * 4, CONV_RSRC_FLAGS);
-            float t[4][5];
+            float t[CPS][5];
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                 for (int ps = 0; ps < 5; ++ps)
-                    t[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[ps], (half * 4 + ch) * HP * 4, 0));
+                    t[ch][ps] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[ps], (half * CPS + ch) * HP * 4, 0));
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                 for (int ps = 0; ps < 5; ++ps) st.s[ch][ps] += t[ch][ps];
         }
@@ -2098,7 +2226,7 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
             for (int ps = 0; ps < 2; ++ps) {
                 if (tid + ps * 256 < 35 * 9) {
 #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
+                    for (int ch = 0; ch < CPS; ++ch) {
                         f32x4 v = st.v[ch][ps];
                         v.x = vm[ps][0] ? v.x : 0.0f; v.y = vm[ps][1] ? v.y : 0.0f; v.z = vm[ps][2] ? v.z : 0.0f; v.w = vm[ps][3] ? v.w : 0.0f;
                         *reinterpret_cast<f32x4*>(&tile[ch][vr[ps] * FIRI_PITCH + 4 * vc4[ps]]) = v;
@@ -2108,7 +2236,7 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
         } else {
         if (tid < 252) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int ch = 0; ch < CPS; ++ch)
 #pragma unroll
                 for (int ps = 0; ps < 5; ++ps) tile[ch][(ps * 7 + r0) * FIRI_PITCH + c] = st.s[ch][ps];
         }
@@ -2119,7 +2247,7 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
     float out[8][4];
     auto filter = [&](int half) {
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
+        for (int ch = 0; ch < CPS; ++ch) {
             float win[4][8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -2135,20 +2263,24 @@ __global__ __launch_bounds__(256) void k_fir4x4_img(FirParams p, char* __restric
                 for (int fy = 0; fy < 4; ++fy)
 #pragma unroll
                     for (int fx = 0; fx < 4; ++fx) acc = __builtin_fmaf(fs[fy * 4 + fx], win[fy][j + fx], acc);
-                out[half * 4 + ch][j] = acc;
+                out[half * CPS + ch][j] = acc;
             }
         }
     };
-    Stage va;  // ONE staging set: the second half is requested once the first sits in LDS and lands under its filtering
+    Stage va;  // ONE staging set: the next stage is requested once this one sits in LDS and lands under its filtering
     fetch(0, va);
     put(va);
     __syncthreads();
-    fetch(1, va);
-    filter(0);
-    __syncthreads();
-    put(va);
-    __syncthreads();
-    filter(1);
+#pragma unroll
+    for (int part = 0; part < 8 / CPS; ++part) {
+        if (part + 1 < 8 / CPS) fetch(part + 1, va);
+        filter(part);
+        if (part + 1 < 8 / CPS) {
+            __syncthreads();
+            put(va);
+            __syncthreads();
+        }
+    }
     if (Y >= p.OH || Xb >= p.OW) return;
     float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (p.noise) {
@@ -2336,7 +2468,13 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.xcd = xcd_order ? 1 : 0;
     // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
     const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !getenv("P3D_NO_W3");
-    p.yimg = w3_img ? yimg : nullptr; p.yimg_lo = (long long)N * O * H * W * 2; p.ystyles = ystyles;
+    // up = 2 into an image, unsplit, few input channels: the FIR pass and the epilogue run inside k_modconv_up3<true> (no
+    // intermediate).  Measured (tools/conv_layers_time.py, us): 32 -> 256 @128^2 -> 256^2 71 -> 56; 256 -> 128 @256^2 -> 512^2 240 -> 254:
+    // with a long K loop the filter's VALU work (76 us chip-wide) and the 1.42 x MFMA work of the overlapping tiles cost more than
+    // the intermediate's round trip.  P3D_UP3_FUSED=0/1 in the environment overrides the choice (tests, A/B runs).
+    const char* fused_env = getenv("P3D_UP3_FUSED");
+    const bool up3_fused = up3 && yimg && ksplit == 1 && (fused_env ? atoi(fused_env) != 0 : I <= 64);
+    p.yimg = (w3_img || up3_fused) ? yimg : nullptr; p.yimg_lo = (long long)N * O * H * W * 2; p.ystyles = ystyles; p.fir = fir;
     // conv output goes to: y (up 1, no split), tmp (up 2, no split) or the partial buffer (split-K), raw unless final
     float* conv_dst = (ksplit > 1) ? part : (up == 2 ? tmp : y);
     p.y = conv_dst;
@@ -2349,7 +2487,12 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
         if (up3) {
             dim3 g3(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + 7) / 8), p.O / 32, p.N * p.ksplit);
-            hipLaunchKernelGGL(k_modconv_up3, g3, dim3(256), 0, st, p);
+            if (up3_fused) {
+                dim3 gf(((2 * W + 59) / 60) * ((2 * H + 11) / 12), p.O / 32, p.N);
+                hipLaunchKernelGGL(k_modconv_up3<true>, gf, dim3(256), 0, st, p);
+                return chk();
+            }
+            hipLaunchKernelGGL(k_modconv_up3<false>, g3, dim3(256), 0, st, p);
         } else if (p.wh && p.wsplit) hipLaunchKernelGGL(k_modconv_up_h<true>, grid, dim3(256), 0, st, p);
         else if (p.wh) hipLaunchKernelGGL(k_modconv_up_h<false>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_up, grid, dim3(256), 0, st, p);
@@ -2386,8 +2529,9 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     if (yimg) {
         dim3 gi(grid.x, (unsigned)(q.NC / 8));
         const bool rows_aligned = (q.pitch & 3) == 0 && q.xoff == q.padx0 && (((uintptr_t)q.x | (uintptr_t)(q.slice * 4)) & 15) == 0;
-        if (rows_aligned) hipLaunchKernelGGL(k_fir4x4_img<true>, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
-        else hipLaunchKernelGGL(k_fir4x4_img<false>, gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
+        // two channels per stage: 125 VGPRs, four waves per SIMD (four per stage: 195, two; measured 2-5 % slower)
+        if (rows_aligned) hipLaunchKernelGGL((k_fir4x4_img<true, 2, 3>), gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
+        else hipLaunchKernelGGL((k_fir4x4_img<false, 4, 2>), gi, dim3(256), 0, st, q, (char*)yimg, (long long)N * O * q.OH * q.OW * 2, sat);
     } else hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
     return chk();
 }

@@ -598,7 +598,8 @@ def test_torgb_gemm_kernel_vs_the_three_launch_form(hip, N, I, O, H):
 
 
 @pytest.mark.parametrize("N,I,O,H", [(1, 256, 128, 128), (2, 512, 512, 16), (1, 32, 256, 64), (3, 64, 48, 32), (1, 128, 64, 20), (1, 64, 32, 8),
-                                     (2, 24, 32, 32)])  # (I = 24: conv0 itself runs on fp32 operands, its FIR pass still writes the image)
+                                     (2, 24, 32, 32),  # (I = 24: conv0 itself runs on fp32 operands, its FIR pass still writes the image)
+                                     (2, 16, 64, 40), (1, 16, 32, 72)])  # (unsplit launches: the FIR pass runs inside k_modconv_up3<true>; 80^2 / 144^2 outputs: ragged 12 x 60 tiles)
 def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O, H):
     """Round 3: an up-sampling layer called with next_styles writes the following layer's two-term operand
     (ops.ActImage: split(16 * s1 * y), the pieces k_modconv_w2 would build itself) from its FIR pass instead of the fp32 tensor.
@@ -648,6 +649,35 @@ def test_activation_image_between_conv0_and_conv1_is_bit_identical(hip, N, I, O,
         assert torch.equal(y_b2, y_alone) and torch.equal(img_n2.data, ops.act_to_image(y_alone, s1).data)
     with pytest.raises(RuntimeError):  # next_styles of the wrong shape
         ops.modulated_conv2d(mid, w1, s1, next_styles=s1[:, :1], **k1)
+
+
+def test_up_conv_with_the_fir_pass_inside_is_bit_identical(hip, monkeypatch):
+    """k_modconv_up3<true> (the FIR pass and the epilogue inside the transposed convolution; chosen for unsplit layers of <= 64 input
+    channels, forced here by P3D_UP3_FUSED) writes the image the two-pass path writes, bit for bit: a 16-chunk K loop, batch 2 with
+    per-sample noise and a clamp, ragged 12 x 60 output tiles (176^2), and the domain flag."""
+    ops = hip.ops
+    filt = ops.setup_filter([1, 3, 3, 1]).cuda()
+    for N, I, O, H in ((1, 256, 128, 128), (2, 64, 128, 88), (1, 32, 256, 128)):
+        g = torch.Generator().manual_seed(I + O + H)
+        rn = lambda *s: torch.randn(*s, generator=g).cuda()
+        x, w0 = rn(N, I, H, H), rn(O, I, 3, 3)
+        s0, s1 = rn(N, I) * 0.4 + 1.0, rn(N, O) * 0.4 + 1.0
+        d0 = ((w0[None] * s0[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+        wf0 = ops.conv_weights_to_f16(w0, split=True)
+        nz = rn(N, 1, 2 * H, 2 * H) * 0.1 if N > 1 else rn(2 * H, 2 * H) * 0.1
+        k0 = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz, weight_f16=wf0,
+                  clamp=1.5 if N > 1 else None, next_styles=s1)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("P3D_UP3_FUSED", mode)
+            flag = ops.conv_domain_flag(x.device)
+            out[mode] = ops.modulated_conv2d(x, w0, s0, saturated=flag, **k0).data.clone()
+            assert not ops.conv_domain_violated(flag)
+        assert torch.equal(out["0"], out["1"]), (N, I, O, H)
+        monkeypatch.setenv("P3D_UP3_FUSED", "1")
+        flag = ops.conv_domain_flag(x.device)
+        ops.modulated_conv2d(x * 3e4, w0, s0, saturated=flag, **dict(k0, clamp=None))
+        assert ops.conv_domain_violated(flag)
 
 
 def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
