@@ -2373,9 +2373,11 @@ static int choose_ksplit(int N, int I, int O, int GH, int GW, int tw = CONV_TW) 
 }
 
 // k_modconv_up3 (image-fed, DMA-pipelined transposed convolution): two-term operands, 16-channel chunks, 32-channel output tiles,
-// maps wide enough for its 32-column tiles (W + 1 grid columns; measured: W = 32 -> 2 tiles, 65.2 -> 47.7 + 4.8 us at 512 -> 512)
+// every map from 4^2 up: below W = 32 its 32-column tile is mostly empty, but the 4^2 .. 16^2 layers are latency, not arithmetic, and
+// the pipelined kernel (+ the 5 us conversion pass of its input) still beats k_modconv_up_h there (measured, batch-1 backbone as a
+// hipGraph replay: W >= 32 only 0.709 ms, >= 16 0.688, >= 8 0.680-0.689, >= 4 0.689; W = 32: 65.2 -> 47.7 + 4.8 us at 512 -> 512)
 #ifndef P3D_UP3_MIN_W
-#define P3D_UP3_MIN_W 32
+#define P3D_UP3_MIN_W 4
 #endif
 static int up3_min_w() {  // (P3D_UP3_MIN_W in the environment: A/B runs)
     static const int v = getenv("P3D_UP3_MIN_W") ? atoi(getenv("P3D_UP3_MIN_W")) : P3D_UP3_MIN_W;

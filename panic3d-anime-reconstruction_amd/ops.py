@@ -711,7 +711,7 @@ class ActImage:
         return v.permute(0, 1, 4, 2, 3).reshape(N, C, H, W).contiguous()
 
 
-UP_IMAGE_MIN_W = int(os.environ.get("P3D_UP3_MIN_W", "32"))  # (the library reads the same variable: csrc/p3d_synthesis.hip up3_min_w)
+UP_IMAGE_MIN_W = int(os.environ.get("P3D_UP3_MIN_W", "4"))  # (the library reads the same variable: csrc/p3d_synthesis.hip up3_min_w)
 
 
 def takes_image_up(I, O, W):
