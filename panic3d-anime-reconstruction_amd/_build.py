@@ -34,6 +34,22 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+RENDER_UNIT = ["p3d_kernels.hip", "p3d_decode.hpp", "p3d_math.hpp", os.path.join("..", "..", "include", "panic3d_hip.h"),
+               os.path.join("..", "..", "include", "p3d_numerics.h")]
+
+
+def render_source_hash():
+    """sha256[:16] over the translation unit of the renderer kernels (p3d_kernels.hip and everything it includes): the kernels
+    bench.py times.  A PMC capture of k_render stays valid while THIS is unchanged — an edit of the synthesis / mesh / paste
+    units compiles into other objects and cannot change the renderer's code."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(RENDER_UNIT):
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def built_hash(so=SO):
     """The source hash a library was compiled from (embedded by build() as -DP3D_SRC_HASH in p3d_build_info's string), or None.
     Read from the FILE, not through dlopen: a library loaded here to ask it would stay mapped under its path, and the dlopen that

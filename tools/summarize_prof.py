@@ -7,8 +7,8 @@ Writes, per scene (canonical / surface) and mode (exact_early = the default laun
 exact early-outs on; exact_noearly = every sample decoded; early / noearly = the same in the tolerance mode, bench.py --fast):
   profiles/<tag>_<scene>_<mode>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (kernel names cut to 80 chars)
   profiles/<tag>_pmc.json                          per-launch averages of every counter for k_render + dispatch info
-  profiles/pmc_latest.json                         {"<scene>/<exact|tolerance>": {kernel_src_sha, hbm_bytes_per_launch, bounds, source}} —
-                                                   bench.py prints it only when kernel_src_sha matches the sources it runs.
+  profiles/pmc_latest.json                         {"<scene>/<exact|tolerance>": {kernel_src_sha, render_src_sha, hbm_bytes_per_launch, bounds, source}} —
+                                                   bench.py prints it only when render_src_sha (the renderer's translation unit) matches the sources it runs.
 Units / corrections: FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE gets the gfx950 x2 correction of
 /opt/skills/guides/MI355X_MICROARCH.md §HBM (the gathers are 16-B-per-lane loads); GRBM_GUI_ACTIVE is summed over the 8 XCDs
 (÷8 = active GPU clocks of the launch); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x4 = clocks);
@@ -35,6 +35,16 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     sha = open(os.path.join(src, "kernel_src_sha.txt")).read().strip()
+    # the renderer's translation unit (what a k_render capture is a capture OF): recorded by the box (collect_profile.sh), or computed
+    # here when the box's sources are the ones in this tree
+    sys.path.insert(0, ROOT)
+    import panic3d_amd as P
+    rs = os.path.join(src, "render_src_sha.txt")
+    if os.path.exists(rs):
+        render_sha = open(rs).read().strip()
+    else:
+        assert P._build.source_hash() == sha, "the capture is from other kernel sources than this tree: no render_src_sha to stamp"
+        render_sha = P._build.render_source_hash()
     allpmc, latest = {}, {}
     for scene in ("canonical", "surface"):
         for mode in ("early", "noearly", "exact_early", "exact_noearly"):
@@ -93,9 +103,9 @@ def main():
             allpmc[f"{scene}/{mode}"] = ent
             if mode in ("early", "exact_early"):  # the two timed launches of bench.py: --fast and the default (exact)
                 latest[f"{scene}/{'tolerance' if mode == 'early' else 'exact'}"] = {
-                    "kernel_src_sha": sha, "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "bounds": b,
+                    "kernel_src_sha": sha, "render_src_sha": render_sha, "hbm_bytes_per_launch": ent.get("hbm_bytes_per_launch"), "bounds": b,
                     "rocprof_kernel_avg_ms": ent["rocprof_kernel_avg_ms"], "source": f"profiles/{tag}_pmc.json [{scene}/{mode}]"}
-    json.dump({"tag": tag, "kernel_src_sha": sha, "captures": allpmc}, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1)
+    json.dump({"tag": tag, "kernel_src_sha": sha, "render_src_sha": render_sha, "captures": allpmc}, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1)
     if latest:
         json.dump(latest, open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
     # the bench lines the runs themselves printed
