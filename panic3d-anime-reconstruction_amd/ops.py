@@ -18,8 +18,20 @@ __all__ = ["make_opts", "prescale_mlp", "planes_to_nhwc", "triplane_decode", "re
            "importance", "unify_perm"]
 
 
+# torch.cuda.current_stream() builds a Stream object through three layers of Python (~7 us) and torch.cuda.current_device() goes
+# through _lazy_init (~1 us); a G.f call asks ~45 times for each while the GPU waits for the launches of its 4^2 .. 32^2 layers
+# (tools/host_profile.py: 0.3 ms of a 2.5 ms call).  The two C entry points below are what those wrappers end in.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
+def _stream_id(index=None):
+    """The current HIP stream of device `index` (default: the current device) as an integer handle."""
+    return _raw_stream(_cur_device() if index is None else index)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 class _NoGuard:
@@ -39,7 +51,7 @@ def _on(device):
     — always, with one process per GPU — nothing has to be switched: a G.f call makes ~35 such calls and starts with an empty
     queue, so this is latency the GPU waits for (profiles/r04_notes.txt)."""
     idx = device.index
-    if idx is None or idx == torch.cuda.current_device():
+    if idx is None or idx == _cur_device():
         return _NOGUARD
     return torch.cuda.device(device)
 
@@ -534,7 +546,7 @@ _FIR_CACHE = {}
 def prepared_filter(f, device, gain=1.0, flip_filter=False):
     """`f * gain`, flipped for convolution unless flip_filter (upfirdn2d.py:193-196), float32 contiguous on `device` — made
     once per (filter tensor object, version, gain, flip): the reference rebuilds it on every call (three tiny launches)."""
-    key = (id(f), str(device), float(gain), bool(flip_filter))
+    key = (id(f), device, float(gain), bool(flip_filter))
     hit = _FIR_CACHE.get(key)
     if memo.enabled() and hit is not None and hit[0]() is f and hit[1] == f._version:
         return hit[2]
@@ -677,7 +689,8 @@ def _conv_scratch(device, nbytes):
     """The convolution workspace (demodulation coefficients, the transposed-conv intermediate, split-K partial sums), per
     (device, stream): launches on one stream are ordered, so consecutive convolutions share ONE workspace instead of allocating
     one per call (the batch-1 backbone is host-bound in its 4^2 .. 32^2 layers)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else _cur_device()
+    key = (idx, _raw_stream(idx))
     ws = _CONV_SCRATCH.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty((int(nbytes * 1.25) + 4096,), dtype=torch.uint8, device=device)

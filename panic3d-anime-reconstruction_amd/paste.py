@@ -40,7 +40,9 @@ def front_occlusion(G, x, out, offset=0.01):
     surface points along +z.  The reference calls G.f again for this (backbone + renderer + super-resolution, and with its
     default noise_mode='random' on different planes); only `image_weights` is used, so this renders the SAME planes
     (`out['triplane']`) once more through the fused renderer and skips the rest."""
-    ro = out["image_xyz"] * torch.tensor([-1, 1, -1], device=out["image_xyz"].device)[None, :, None, None]
+    # (G._sign: the (-1, 1, -1) tensor kept on the device — a torch.tensor(..., device=...) here is a pageable host->device copy
+    # that waits for everything queued on the stream, i.e. for the whole view: ~1 ms of idle GPU per pasted view, tools/host_profile.py)
+    ro = out["image_xyz"] * G._sign(out["image_xyz"].device)
     ro[:, 2, :, :] -= G.rendering_kwargs["ray_start"] - offset
     rd = torch.zeros_like(out["image_xyz"])
     rd[:, 2, :, :] = 1

@@ -18,7 +18,7 @@ from . import memo, ops
 SQRT2 = float(np.sqrt(2))
 
 # derived tensors the modules keep as plain attributes (never part of the state_dict, dropped when pickled / deep-copied)
-_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan", "_cond_cache", "conv_domain_flag")
+_CACHE_ATTRS = ("_scaled_wb", "_scaled_key", "_wh", "_wh_key", "_wt", "_wt_key", "_noise_cache", "_style_plan", "_cond_cache", "conv_domain_flag", "_noise_pool")
 
 
 class _CacheFree(torch.nn.Module):
@@ -125,23 +125,26 @@ CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
 # (the pass timings of tools/bench_backbone.py, graph_backbone.py, profile_backbone.py are taken that way).
 STYLE_MEMO = os.environ.get("P3D_STYLE_MEMO", "1") != "0"
 IMG_MIN_RES = 32
+# noise_mode='random': one draw per pass for all layers (NoisePool) instead of one per layer.  P3D_NOISE_POOL=0: the reference's
+# call-for-call sequence of torch.randn calls.
+NOISE_POOL = os.environ.get("P3D_NOISE_POOL", "1") != "0"
 
 
 def _takes_image(layer, res):
     """A plain 3x3 layer that can stage its input from an activation image: two-term operands, 16-channel K chunks, a map of at
     least IMG_MIN_RES columns (the wide-tile kernel)."""
-    mode = getattr(layer, "mma_f16", None)
+    mode = layer.__dict__.get("mma_f16")
     if mode is None:
         mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
-    return CONV_IMG and mode == "x2" and layer.up == 1 and layer.weight.shape[-1] == 3 and layer.in_channels % 16 == 0 and res >= IMG_MIN_RES
+    return CONV_IMG and mode == "x2" and layer.up == 1 and layer._parameters["weight"].shape[-1] == 3 and layer.in_channels % 16 == 0 and res >= IMG_MIN_RES
 
 
 def _next_conv0_styles(next_block, next_pre, res):
     """The styles of next_block.conv0 if that layer will stage its input (a res x res map) from an activation image, else None."""
     if next_block is None or next_pre is None or not CONV_IMG or next_pre.get("conv0") is None or next_pre["conv0"][1] is None:
         return None
-    layer = next_block.conv0
-    mode = getattr(layer, "mma_f16", None)
+    layer = next_block._modules["conv0"]
+    mode = layer.__dict__.get("mma_f16")
     if mode is None:
         mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
     if mode != "x2" or not ops.takes_image_up(layer.in_channels, layer.out_channels, res):
@@ -154,15 +157,17 @@ def _f16_operand(layer):
     False = fp32 operands, True = one f16 term ([O,k*k,I]; TriPlaneGenerator.set_sr_mma_f16), "x2" = two-term operands
     ([2,O,k*k,I]); unset = DEFAULT_CONV_MMA for the plain 3x3 layers.  A plain attribute, not a buffer: the state_dict stays
     the reference's."""
-    mode = getattr(layer, "mma_f16", None)  # None | False | True | "x2"
+    mode = layer.__dict__.get("mma_f16")  # None | False | True | "x2"
     if mode is None:
-        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and (layer.weight.shape[-1] == 3 or DEFAULT_CONV_MMA_1X1 == "x2")) else False
+        mode = "x2" if (DEFAULT_CONV_MMA == "x2" and (layer._parameters["weight"].shape[-1] == 3 or DEFAULT_CONV_MMA_1X1 == "x2")) else False
     if not mode or layer.in_channels % 16 != 0:
         return None
-    key = (layer.weight.data_ptr(), layer.weight._version, mode)
-    if getattr(layer, "_wh_key", None) != key or not memo.enabled():
-        layer._wh, layer._wh_key = ops.conv_weights_to_f16(layer.weight.detach(), split=(mode == "x2")), key
-    return layer._wh
+    w = layer._parameters["weight"]
+    key = (w.data_ptr(), w._version, mode)
+    d = layer.__dict__
+    if d.get("_wh_key") != key or not memo.enabled():
+        d["_wh"], d["_wh_key"] = ops.conv_weights_to_f16(w.detach(), split=(mode == "x2")), key
+    return d["_wh"]
 
 
 class DomainFlags:
@@ -183,7 +188,7 @@ class DomainFlags:
 
 
 def _domain_flag(layer, device):
-    f = getattr(layer, "conv_domain_flag", None)
+    f = layer.__dict__.get("conv_domain_flag")
     return f.get(device) if isinstance(f, DomainFlags) else f  # (a bare int32 tensor set by hand is still honoured)
 
 
@@ -205,29 +210,75 @@ class SynthesisLayer(_CacheFree):
 
     def _const_noise(self):
         """`noise_const * noise_strength` (networks_stylegan2.py:346), once per parameter version instead of once per call."""
-        key = (self.noise_const.data_ptr(), self.noise_const._version, self.noise_strength.data_ptr(), self.noise_strength._version)
-        hit = getattr(self, "_noise_cache", None)
+        nc, ns = self._buffers["noise_const"], self._parameters["noise_strength"]  # (dict reads: nn.Module.__getattr__ is ~10x slower)
+        key = (nc.data_ptr(), nc._version, ns.data_ptr(), ns._version)
+        hit = self.__dict__.get("_noise_cache")
         if hit is None or hit[0] != key or not memo.enabled():
-            hit = (key, (self.noise_const * self.noise_strength.detach()).contiguous())
+            hit = (key, (nc * ns.detach()).contiguous())
             self._noise_cache = hit
         return hit[1]
 
-    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None, next_styles=None):
+    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None, next_styles=None, noise_pool=None):
         """pre: (styles [N,I], demodulation coefficients [N,O]) already computed by a StylePlan for this layer, or None.
         x: fp32 [N,I,H,W], or the ops.ActImage the previous layer prepared for this one (its styles are in it).
-        next_styles (up-sampling layers): return the ops.ActImage of the following layer, whose styles these are."""
+        next_styles (up-sampling layers): return the ops.ActImage of the following layer, whose styles these are.
+        noise_pool: a NoisePool of the enclosing network — this layer's random noise is its next slice of ONE draw per pass."""
         assert noise_mode in ["random", "const", "none"]
         styles, dcoef = pre if pre is not None else (self.affine(w), None)
         noise = None
         if self.use_noise and noise_mode == "random":
-            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+            if noise_pool is not None:
+                noise = noise_pool.take(self, x.shape[0])
+            else:  # networks_stylegan2.py:342, call for call
+                noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == "const":
             noise = self._const_noise()
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return ops.modulated_conv2d(x, self.weight, styles, noise=noise, up=self.up, padding=self.padding,
-                                    resample_filter=self.resample_filter, demodulate=True, bias=self.bias,
+        prm = self._parameters
+        return ops.modulated_conv2d(x, prm["weight"], styles, noise=noise, up=self.up, padding=self.padding,
+                                    resample_filter=self._buffers["resample_filter"], demodulate=True, bias=prm["bias"],
                                     act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self),
                                     saturated=_domain_flag(self, x.device), dcoef=dcoef, next_styles=next_styles)
+
+
+class NoisePool:
+    """noise_mode='random' for a whole pass in two launches.  The reference draws `randn([N,1,res,res]) * noise_strength` inside every
+    SynthesisLayer.forward (networks_stylegan2.py:342): 2 launches x 15 layers that a batch-1 backbone pass cannot issue as fast as the
+    GPU runs them (tools/host_profile.py: 0.85 ms of a 4.1 ms view of generate.py, whose G.f calls leave noise_mode at 'random').
+    Here ONE randn call draws the values of all layers of the pass, in the layers' execution order, and ONE multiply applies every
+    layer's strength (a per-element vector cached per parameter version); each layer then takes its slice.  Same distribution, same
+    per-layer independence; the stream of the device generator is consumed in one call instead of fifteen, so the values differ from
+    a call-for-call run under the same seed (the reference's own GPU and CPU streams differ from each other in the same way)."""
+
+    def __init__(self, layers):
+        self.layers = [l for l in layers if l.use_noise]
+        self._scale = {}  # (N, device) -> (key, per-element strengths, offsets)
+        self._cur = None
+
+    def _scales(self, N, dev):
+        key = tuple([(l._parameters["noise_strength"].data_ptr(), l._parameters["noise_strength"]._version) for l in self.layers])
+        hit = self._scale.get((N, dev))
+        if hit is None or hit[0] != key or not memo.enabled():
+            offs, o = {}, 0
+            for l in self.layers:
+                offs[id(l)] = o
+                o += N * l.resolution * l.resolution
+            sc = torch.cat([l.noise_strength.detach().to(torch.float32).reshape(1).expand(N * l.resolution * l.resolution) for l in self.layers])
+            hit = self._scale[(N, dev)] = (key, sc.contiguous(), offs, o)
+        return hit
+
+    def draw(self, N, dev):
+        """Start a pass: draw and scale the noise of every layer for batch size N."""
+        _, sc, offs, total = self._scales(N, dev)
+        self._cur = (torch.randn([total], device=dev).mul_(sc), offs, N)
+        return self
+
+    def take(self, layer, N):
+        buf, offs, n = self._cur
+        assert n == N, "NoisePool: batch size changed inside a pass"
+        o = offs[id(layer)]
+        r = layer.resolution
+        return buf[o:o + N * r * r].view(N, 1, r, r)
 
 
 class ToRGBLayer(_CacheFree):
@@ -243,14 +294,14 @@ class ToRGBLayer(_CacheFree):
         """skip / skip_filter: the previous block's image and the block's resample filter -> `upsample2d(skip) + torgb(x)`, the
         skip connection of SynthesisBlock.forward (networks_stylegan2.py:476-478), from the same launch."""
         styles = pre[0] if pre is not None else self.affine(w) * self.weight_gain
-        if self.weight.shape[0] <= 96 and self.weight.shape[-1] == 1 and not getattr(self, "mma_f16", None) and x.shape[-1] % 2 == 0 \
-                and x.shape[-2] % 2 == 0:
+        weight, bias, d = self._parameters["weight"], self._parameters["bias"], self.__dict__
+        if weight.shape[0] <= 96 and weight.shape[-1] == 1 and not d.get("mma_f16") and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
             # the dedicated GEMM kernel (p3d_torgb_f32): the activation is read once, the skip image is added in the same launch
-            key = (self.weight.data_ptr(), self.weight._version)
-            if getattr(self, "_wt_key", None) != key or not memo.enabled():
-                self._wt, self._wt_key = ops.torgb_weights(self.weight.detach()), key
-            return ops.torgb(x, self._wt, self.weight.shape[0], styles, bias=self.bias, clamp=self.conv_clamp, skip=skip, skip_filter=skip_filter)
-        y = ops.modulated_conv2d(x, self.weight, styles, demodulate=False, bias=self.bias, act="linear", gain=1.0,
+            key = (weight.data_ptr(), weight._version)
+            if d.get("_wt_key") != key or not memo.enabled():
+                self._wt, self._wt_key = ops.torgb_weights(weight.detach()), key
+            return ops.torgb(x, d["_wt"], weight.shape[0], styles, bias=bias, clamp=self.conv_clamp, skip=skip, skip_filter=skip_filter)
+        y = ops.modulated_conv2d(x, weight, styles, demodulate=False, bias=bias, act="linear", gain=1.0,
                                  clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=_domain_flag(self, x.device))
         return ops.upsample2d_add(skip, skip_filter, y) if skip is not None else y
 
@@ -327,8 +378,14 @@ class StylePlan:
         is the same object at the same version and no parameter changed: the views of one subject share their ws
         (TriPlaneGenerator.f), and these five launches sit in the launch-bound head of a call."""
         dev = ws.device
-        key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias.data_ptr(), l.affine.bias._version,
-                     l.weight.data_ptr(), l.weight._version) for _, _, l, _ in self.entries) + (str(dev),)
+        # the parameters the plan's tables derive from, read through the modules' own `_parameters` dicts (the dict objects live
+        # as long as the modules; `layer.affine.weight` goes through nn.Module.__getattr__ twice — 224 such lookups per call were
+        # 0.15 ms of the launch-bound head of a G.f call, tools/host_profile.py)
+        pd = self.__dict__.get("_param_dicts")
+        if pd is None:
+            pd = self._param_dicts = [(l.affine._parameters, l._parameters) for _, _, l, _ in self.entries]
+        key = tuple([(a["weight"].data_ptr(), a["weight"]._version, a["bias"].data_ptr(), a["bias"]._version,
+                      w["weight"].data_ptr(), w["weight"]._version) for a, w in pd]) + (dev,)
         if key != self._key or not memo.enabled():
             self._build(dev)
             self._key = key
@@ -476,6 +533,7 @@ class SynthesisNetwork(_CacheFree):
     def _apply(self, fn):  # .to() / .cuda() / .float(): prepared terms live on the old device
         self.clear_cond_cache()
         self.__dict__.pop("_style_plan", None)
+        self.__dict__.pop("_noise_pool", None)
         return super()._apply(fn)
 
     def _condition(self, lvl, res, x, img, cond, cm, chonkadd):
@@ -569,6 +627,12 @@ class SynthesisNetwork(_CacheFree):
             plan = StylePlan(plan_entries([(f"b{res}", getattr(self, f"b{res}")) for res in self.block_resolutions], starts))
             self.__dict__["_style_plan"] = plan
         pre = plan(ws, memo_of=ws)  # every layer's styles + demodulation coefficients: one GEMM + three small launches
+        if block_kwargs.get("noise_mode", "random") == "random" and NOISE_POOL:  # all layers' random noise of this pass: two launches
+            pool = self.__dict__.get("_noise_pool")
+            if pool is None:
+                blocks = [getattr(self, f"b{res}") for res in self.block_resolutions]
+                pool = self.__dict__["_noise_pool"] = NoisePool([l for b in blocks for l in ([b.conv1] if b.in_channels == 0 else [b.conv0, b.conv1])])
+            block_kwargs["noise_pool"] = pool.draw(ws.shape[0], ws.device)
         x_image = None
         for lvl, (res, cur_ws) in enumerate(zip(self.block_resolutions, block_ws)):
             # conv1 of this block writes its result also as the image the next block's conv0 stages from (no conversion pass in

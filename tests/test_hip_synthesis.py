@@ -704,6 +704,48 @@ def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
     assert sum(seen) == 0 and torch.equal(a, b)
 
 
+def test_random_noise_from_one_draw_per_pass(hip, monkeypatch):
+    """noise_mode='random' (what generate.py's G.f calls run): the pass draws all layers' noise in one randn call (NoisePool).  With
+    the layers' noise_const buffers set to the SAME draws, noise_mode='const' must give the same planes bit for bit; the
+    call-for-call path (P3D_NOISE_POOL=0, the reference's sequence of randn calls) still runs and differs only in its random values."""
+    sg = hip.stylegan2
+    torch.manual_seed(11)
+    net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="none", channel_base=8192, channel_max=128, num_fp16_res=0).cuda()
+    blocks = [getattr(net, f"b{r}") for r in net.block_resolutions]
+    layers = [l for b in blocks for l in ([b.conv1] if b.in_channels == 0 else [b.conv0, b.conv1])]
+    with torch.no_grad():
+        for k, l in enumerate(layers):
+            l.noise_strength.fill_(0.05 * (k + 1))
+    ws = torch.randn(1, net.num_ws, 512, device="cuda")
+    total = sum(l.resolution ** 2 for l in layers)
+    with torch.no_grad():
+        torch.manual_seed(3)
+        y_rand = net(ws, {}, noise_mode="random")
+        torch.manual_seed(3)
+        raw = torch.randn([total], device="cuda")
+        o = 0
+        for l in layers:
+            l.noise_const.copy_(raw[o:o + l.resolution ** 2].view(l.resolution, l.resolution))
+            o += l.resolution ** 2
+        y_const = net(ws, {}, noise_mode="const")
+        assert torch.equal(y_rand, y_const)
+        y_none = net(ws, {}, noise_mode="none")
+        assert not torch.equal(y_rand, y_none)  # (the noise is really applied)
+        torch.manual_seed(3)
+        y_again = net(ws, {}, noise_mode="random")
+        assert torch.equal(y_again, y_rand)
+        monkeypatch.setattr(sg, "NOISE_POOL", False)
+        torch.manual_seed(3)
+        y_calls = net(ws, {}, noise_mode="random")  # one randn per layer, as networks_stylegan2.py:342
+        assert torch.isfinite(y_calls).all() and not torch.equal(y_calls, y_none)
+        assert float((y_calls - y_none).abs().mean()) == pytest.approx(float((y_rand - y_none).abs().mean()), rel=0.5)
+        # batch 2: per-sample noise, every sample its own slice
+        ws2 = torch.randn(2, net.num_ws, 512, device="cuda")
+        monkeypatch.setattr(sg, "NOISE_POOL", True)
+        y2 = net(ws2, {}, noise_mode="random")
+        assert torch.isfinite(y2).all() and y2.shape[0] == 2
+
+
 def test_prepared_conditioning_follows_the_conditioning_tensors(hip):
     """SynthesisNetwork prepares what each level adds from the conditioning images once per set of tensor OBJECTS (and versions) and
     applies it in place.  A second call with the same tensors reuses it; other tensors of the same shape — also ones that could

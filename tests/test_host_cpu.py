@@ -373,3 +373,37 @@ def test_sobel_restatement_against_a_dense_convolution_with_the_published_kernel
     r = F.conv2d(F.pad(ramp, [1, 1, 1, 1], mode="replicate"), k)
     assert float(r[0, 0, 4, 4]) == 1.0 and float(r[0, 1, 4, 4]) == 0.0  # d/dx of a unit ramp = 1 after the /8 normalisation
     assert abs(float(paste.sobel_magnitude(ramp)[0, 0, 4, 4]) - float(np.sqrt(1 + 1e-6))) < 1e-6
+
+
+def test_noise_pool_is_one_draw_sliced_per_layer(P):
+    """noise_mode='random' for a whole pass: NoisePool draws every layer's noise in ONE randn call (the layers' execution order),
+    applies every layer's strength in one multiply and hands each layer its slice — the values are randn(total) under the same
+    seed, each layer's slice scaled by ITS strength, and a changed strength is noticed (host logic, CPU tensors)."""
+    sg = P.stylegan2
+    torch.manual_seed(0)
+    net = sg.SynthesisNetwork(w_dim=32, img_resolution=32, img_channels=3, cond_mode="none", channel_base=256, channel_max=16, num_fp16_res=0)
+    blocks = [getattr(net, f"b{r}") for r in net.block_resolutions]
+    layers = [l for b in blocks for l in ([b.conv1] if b.in_channels == 0 else [b.conv0, b.conv1])]
+    assert [l.resolution for l in layers] == [4, 8, 8, 16, 16, 32, 32]
+    with torch.no_grad():
+        for k, l in enumerate(layers):
+            l.noise_strength.fill_(0.5 + k)
+    pool = sg.NoisePool(layers)
+    for N in (1, 2):
+        total = sum(N * l.resolution ** 2 for l in layers)
+        torch.manual_seed(7)
+        raw = torch.randn(total)
+        torch.manual_seed(7)
+        pool.draw(N, torch.device("cpu"))
+        o = 0
+        for k, l in enumerate(layers):
+            got = pool.take(l, N)
+            n = N * l.resolution ** 2
+            assert got.shape == (N, 1, l.resolution, l.resolution)
+            assert torch.equal(got.reshape(-1), raw[o:o + n] * (0.5 + k))
+            o += n
+    with torch.no_grad():
+        layers[2].noise_strength.fill_(100.0)  # (in-place: the version counter moves, the cached strengths are rebuilt)
+    torch.manual_seed(7)
+    pool.draw(1, torch.device("cpu"))
+    assert float(pool.take(layers[2], 1).std()) > 50 and float(pool.take(layers[1], 1).std()) < 5
