@@ -120,26 +120,30 @@ import functools
 
 
 # generate.py renders 16 fixed poses per subject (4 ortho + 12 perspective): 32 entries hold that set at two resolutions.  The
-# entries are device tensors (2 x [3,res,res] fp32: 6 MB per view at 512^2), so the cache is kept SMALL — a 360-degree sweep or
+# entries are device tensors (4 x 3 x res^2 fp32 — the rays in image layout and in the renderer's layout: 12 MB per view at 512^2, 0.8 MB
+# at the pipeline's 128^2), so the cache is kept SMALL — a 360-degree sweep or
 # random evaluation poses would otherwise pin one entry per unique pose (3 GB at 512^2 with the old 512 entries) — and is
 # dropped by cached_view_clear() (e.g. after moving a generator to another device).
 def make_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.float32):
-    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res]) of one view, computed now."""
+    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res], and the same rays as [res^2,3] — the layout the
+    renderer consumes, training/triplane.py:181-182) of one view, computed now."""
     elev, azim, dist, fov, resolution, boxwarp = float(elev), float(azim), float(dist), float(fov), int(resolution), float(boxwarp)
     label = camera_label(elev, azim, dist, fov).to(dtype).to(device)
     if fov < 0:  # negative fov = orthographic view (training/triplane.py:402-414)
         r = ortho_rays(elev, azim, dist, boxwarp, resolution, device=device)
-        return label, r["ray_origins"][0], r["ray_directions"][0]
+        o, d = r["ray_origins"][0].contiguous(), r["ray_directions"][0].contiguous()
+        flat = lambda t: t.permute(1, 2, 0).reshape(resolution * resolution, 3).contiguous()
+        return label, o, d, flat(o), flat(d)
     ro, rd = perspective_rays(label[:16].view(1, 4, 4), label[16:25].view(1, 3, 3), resolution)
     chw = lambda t: t.reshape(resolution, resolution, 3).permute(2, 0, 1).contiguous()
-    return label, chw(ro), chw(rd)
+    return label, chw(ro), chw(rd), ro.reshape(resolution * resolution, 3).contiguous(), rd.reshape(resolution * resolution, 3).contiguous()
 
 
 _cached_view = functools.lru_cache(maxsize=32)(make_view)
 
 
 def cached_view(elev, azim, dist, fov, resolution, boxwarp, device, dtype=torch.float32):
-    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res]) of one view, memoised on the view's parameters:
+    """(camera label [25], ray origins [3,res,res], ray directions [3,res,res], both again as [res^2,3]) of one view, memoised on the view's parameters:
     generate.py renders the same 16 poses for every subject, and the ray generation is a dozen small launches plus host maths.
     The tensors are shared between calls: callers stack / copy them, they never write into them."""
     return _cached_view(float(elev), float(azim), float(dist), float(fov), int(resolution), float(boxwarp), torch.device(device), dtype)

@@ -124,14 +124,15 @@ class TriPlaneGenerator(torch.nn.Module):
                 state[k] = None
         return state
 
-    def _sign(self, device):
-        """(-1, 1, -1) on `device`, created once (a host->device copy is not allowed inside a hipGraph capture); a plain
-        attribute, not a buffer: the module's state_dict must stay identical to the reference's."""
-        t = self.__dict__.get("_sign_cache")
-        if t is None or t.device != device:
+    def _sign(self, device, scale=1.0):
+        """scale * (-1, 1, -1) as [1,3,1,1] on `device`, created once (a host->device copy waits for everything queued on the stream
+        and is not allowed inside a hipGraph capture); a plain attribute, not a buffer: the module's state_dict must stay identical
+        to the reference's."""
+        c = self.__dict__.get("_sign_cache")
+        if c is None or c[0] != device:
             t = torch.tensor([-1.0, 1.0, -1.0], device=device)[None, :, None, None]
-            self.__dict__["_sign_cache"] = t
-        return t
+            c = self.__dict__["_sign_cache"] = (device, {1.0: t, 0.5: t * 0.5})
+        return c[1][scale]
 
     # ---- latents ------------------------------------------------------------------------------------------------
     def mapping(self, z, c, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False):
@@ -165,7 +166,7 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def synthesis(self, ws, c, cond, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
                   use_cached_backbone=False, latent_injection=None, stop_level=None, force_rays=None, triplane_crop=None,
-                  cull_clouds=None, binarize_clouds=None, normalize_images=True, return_more=False, **synthesis_kwargs):
+                  cull_clouds=None, binarize_clouds=None, normalize_images=True, return_more=False, _rays_flat=None, **synthesis_kwargs):
         if neural_rendering_resolution is None:
             neural_rendering_resolution = self.neural_rendering_resolution
         else:
@@ -176,8 +177,11 @@ class TriPlaneGenerator(torch.nn.Module):
         elif isinstance(force_rays, dict):
             ro, rd = force_rays["ray_origins"], force_rays["ray_directions"]
             assert ro.shape == rd.shape and ro.shape[1:] == (3, res, res) and (len(ro) == len(ws) or len(ws) == 1)
-            ray_origins = ro.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
-            ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
+            if _rays_flat is not None and _rays_flat[0].shape == (len(ro), res * res, 3):  # f(): the view cache's own [N,R,3] copies of these rays
+                ray_origins, ray_directions = _rays_flat
+            else:
+                ray_origins = ro.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
+                ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
         else:
             assert False, "force_rays not understood"
         N = ray_origins.shape[0]
@@ -207,7 +211,10 @@ class TriPlaneGenerator(torch.nn.Module):
         xyz_image = xyz.permute(0, 2, 1).reshape(N, 3, H, W).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(N, 1, H, W)
         weights_image = wsum.permute(0, 2, 1).reshape(N, 1, H, W)
-        xyz_image = 0.5 * (xyz_image + 1) * self._sign(xyz_image.device)
+        # 0.5 * (xyz + 1) * (-1, 1, -1)  (triplane.py:229) in one launch: h + xyz * h with h = (-0.5, 0.5, -0.5) — xyz * h is exact, so
+        # the single rounding is the reference's (x + 1) rounded, then halved and signed exactly: the same bits
+        half_sign = self._sign(xyz_image.device, 0.5)
+        xyz_image = torch.addcmul(half_sign, xyz_image, half_sign)
         rgb_image = feature_image[:, :3]
         sr_kw = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
         sr_image = self.superresolution(rgb_image, feature_image, ws,
@@ -216,8 +223,9 @@ class TriPlaneGenerator(torch.nn.Module):
                "image_weights": weights_image, "image_xyz": xyz_image}
         if self.rendering_kwargs.get("tanh_rgb_output", False):
             ans["image"], ans["image_raw"] = torch.tanh(ans["image"]), torch.tanh(ans["image_raw"])
-        if not normalize_images:
-            ans["image"], ans["image_raw"] = 0.5 * ans["image"] + 0.5, 0.5 * ans["image_raw"] + 0.5
+        if not normalize_images:  # 0.5 * image + 0.5, one launch each (0.5 * image is exact: the same single rounding)
+            half = self._sign(sr_image.device, 0.5)[0, 1, 0, 0]
+            ans["image"], ans["image_raw"] = torch.add(half, ans["image"], alpha=0.5), torch.add(half, ans["image_raw"], alpha=0.5)
         return ans
 
     def sample_mixed(self, coordinates, directions, ws, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False,
@@ -281,6 +289,7 @@ class TriPlaneGenerator(torch.nn.Module):
                                           device=device, dtype=dtype)
             x["zs"] = x["z"][:, None, :].expand(-1, self.backbone.num_ws, -1)
         force_rays = (x["force_rays"] if "force_rays" in x else None) or force_rays
+        rays_flat = None
         res = x["neural_rendering_resolution"] if "neural_rendering_resolution" in x else self.neural_rendering_resolution
         if "camera_params" not in x:
             # one device -> host copy for the view parameters the caller gave (the defaults — distance 1, fov 30, triplane.py:360-363 —
@@ -302,6 +311,10 @@ class TriPlaneGenerator(torch.nn.Module):
             if force_rays is None:
                 x["force_rays"] = force_rays = {"ray_origins": torch.stack([v[1] for v in views]),
                                                 "ray_directions": torch.stack([v[2] for v in views])}
+                # the same rays in the renderer's [N,R,3] layout, straight from the view cache (never handed to the caller, never
+                # written: for one view a plain view of the cached tensor) — synthesis() would permute + copy the dict's tensors
+                rays_flat = (views[0][3][None], views[0][4][None]) if len(views) == 1 else \
+                            (torch.stack([v[3] for v in views]), torch.stack([v[4] for v in views]))
         if force_rays is None:
             cp = x["camera_params"]
             intr = cp[:, 16:25].view(-1, 3, 3)
@@ -339,7 +352,7 @@ class TriPlaneGenerator(torch.nn.Module):
                                # extensions of the dict API (absent keys = the reference's behaviour): reuse the planes of
                                # the previous call for further views of the same subject, deterministic backbone noise
                                cache_backbone=bool(x.get("cache_backbone", False)),
-                               use_cached_backbone=bool(x.get("use_cached_backbone", False)),
+                               use_cached_backbone=bool(x.get("use_cached_backbone", False)), _rays_flat=rays_flat,
                                **({"noise_mode": x["noise_mode"]} if "noise_mode" in x else {}))
         ret = {k: synth[k] for k in ("image", "image_raw", "image_depth", "image_weights", "triplane", "image_xyz")}
         ret["normalize_images"] = normalize_images

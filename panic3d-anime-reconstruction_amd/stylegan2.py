@@ -460,7 +460,9 @@ class SynthesisBlock(torch.nn.Module):
         w_iter = iter(ws.unbind(dim=1))
         pre = pre or {}
         if self.in_channels == 0:
-            x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self._parameters["const"].to(torch.float32).unsqueeze(0)
+            if ws.shape[0] != 1:  # (batch 1: the convolution only reads x — no copy of the constant, networks_stylegan2.py:456-457)
+                x = x.repeat([ws.shape[0], 1, 1, 1])
             x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
         else:
             # conv0 hands conv1 its operand (activation image) when conv1 can stage from one and its styles / demodulation
