@@ -453,6 +453,48 @@ def test_sr_f16_operands_image_quality(hip):
     assert mse > 0 and 10 * np.log10(4.0 / mse) > 50.0, 10 * np.log10(4.0 / max(mse, 1e-30))
 
 
+def test_f_rays_from_the_view_cache_equal_caller_given_rays(hip):
+    """G.f hands synthesis() the cached view's rays already in the renderer's [N,R,3] layout; a caller who passes the same rays as
+    x['force_rays'] ([N,3,res,res], the reference's layout) goes through the permute + copy — both must render the same bits, for one
+    view (a plain view of the cached tensor) and for several views in one call (stacked), perspective and orthographic."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    g = T.load_golden("syn_triplane_f.npz")
+    G = load_sd(TriPlaneGenerator(**dict(TRI_KW, rendering_kwargs=dict(TRI_RK, c_gen_conditioning_zero=True))), g, "sd_")
+    G.set_force_sigmoid(True)
+    for elev, azim, fov in (([0.0], [20.0], [30.0]), ([0.0], [90.0], [-1.0]), ([0.0, 10.0], [20.0, -40.0], [30.0, 30.0])):
+        V = len(elev)
+        x = dict(elevations=torch.tensor(elev).cuda(), azimuths=torch.tensor(azim).cuda(), fovs=torch.tensor(fov).cuda(), seeds=[3], cond={},
+                 triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+        draws = lambda: (torch.rand(V, 256, TRI_RK["depth_resolution"], 1, generator=torch.Generator().manual_seed(1)).cuda(),
+                         torch.rand(V * 256, TRI_RK["depth_resolution_importance"], generator=torch.Generator().manual_seed(2)).cuda())
+        with torch.no_grad():
+            G._inject_draws = draws()
+            xa = dict(x)
+            a = G.f(xa)
+            G._inject_draws = draws()
+            xb = dict(x, force_rays={k: v.clone() for k, v in xa["force_rays"].items()}, camera_params=xa["camera_params"].clone())
+            b = G.f(xb)
+        G._inject_draws = None
+        for k in ("image", "image_raw", "image_depth", "image_weights", "image_xyz"):
+            assert torch.equal(a[k], b[k]), (k, fov)
+        assert a["image_xyz"].shape == (V, 3, 16, 16) and a["image"].shape == (V, 3, 512, 512)
+
+
+def test_raw_stream_handle_follows_the_current_stream(hip):
+    """ops._stream() (torch._C._cuda_getCurrentRawStream: the C entry point torch.cuda.current_stream() ends in) is the stream the
+    C ABI launches on: it must follow torch.cuda.stream(...) contexts, and work issued under one must be ordered on that stream."""
+    ops = hip.ops
+    s = torch.cuda.Stream()
+    assert (ops._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(s):
+        assert (ops._stream().value or 0) == s.cuda_stream
+        x = torch.randn(1, 16, 8, 8, device="cuda")
+        y = ops.bias_act(x, torch.ones(16, device="cuda"), act="lrelu")
+    assert (ops._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+    s.synchronize()
+    assert torch.allclose(y, torch.nn.functional.leaky_relu(x + 1, 0.2) * np.sqrt(2), atol=1e-6)
+
+
 def test_triplane_generator_f_conditioned_vs_reference(hip):
     """G.f of a conditioned generator (front illustration + resnet features + resnet 'chonk', pose conditioning zeroed: what
     _scripts/eval/generate.py:88-96 feeds the released model) against the reference's own G.f on CPU: mapping_zplus with

@@ -407,3 +407,30 @@ def test_noise_pool_is_one_draw_sliced_per_layer(P):
     torch.manual_seed(7)
     pool.draw(1, torch.device("cpu"))
     assert float(pool.take(layers[2], 1).std()) > 50 and float(pool.take(layers[1], 1).std()) < 5
+
+
+def test_cached_view_holds_the_rays_in_both_layouts(P):
+    """make_view returns the rays of a view as [3,res,res] (the reference's force_rays layout) AND as [res^2,3] (what the renderer
+    consumes, training/triplane.py:181-182 'b c h w -> b (h w) c'): the second must be exactly the rearranged first, for perspective
+    and orthographic views."""
+    cams = P.cameras
+    for fov in (30.0, -1.0):
+        label, o, d, of, df = cams.make_view(10.0, 35.0, 1.0, fov, 16, 0.7, torch.device("cpu"))
+        assert label.shape == (25,) and o.shape == d.shape == (3, 16, 16) and of.shape == df.shape == (256, 3)
+        assert torch.equal(o.permute(1, 2, 0).reshape(256, 3), of) and torch.equal(d.permute(1, 2, 0).reshape(256, 3), df)
+        assert of.is_contiguous() and df.is_contiguous() and o.is_contiguous()
+
+
+def test_one_launch_forms_of_the_view_glue_round_like_the_reference():
+    """TriPlaneGenerator.synthesis writes `0.5 * (xyz + 1) * (-1, 1, -1)` (triplane.py:229) as addcmul(h, xyz, h), h = (-0.5, 0.5, -0.5),
+    and `0.5 * image + 0.5` as add(0.5, image, alpha=0.5): one launch each.  x * 0.5 is exact, so each form rounds once, where the
+    reference's rounds — the same bits for every finite float (checked here on values around the rounding-sensitive points)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(200000, generator=g), torch.randn(100000, generator=g) * 1e-4 - 1.0, torch.randn(100000, generator=g) * 1e3,
+                   torch.tensor([0.0, -1.0, 1.0, -1.0 + 2 ** -24, 1.0 - 2 ** -24, 3.4e38, -3.4e38, 1e-45, -1e-45, 1e-38])]).float()
+    x = x[: (len(x) // 3) * 3].reshape(1, 3, -1, 1)
+    sign = torch.tensor([-1.0, 1.0, -1.0])[None, :, None, None]
+    ref = 0.5 * (x + 1) * sign
+    h = sign * 0.5
+    assert torch.equal(torch.addcmul(h, x, h), ref)
+    assert torch.equal(torch.add(torch.tensor(0.5), x, alpha=0.5), 0.5 * x + 0.5)
