@@ -21,13 +21,8 @@ __all__ = ["make_opts", "prescale_mlp", "planes_to_nhwc", "triplane_decode", "re
 # torch.cuda.current_stream() builds a Stream object through three layers of Python (~7 us) and torch.cuda.current_device() goes
 # through _lazy_init (~1 us); a G.f call asks ~45 times for each while the GPU waits for the launches of its 4^2 .. 32^2 layers
 # (tools/host_profile.py: 0.3 ms of a 2.5 ms call).  The two C entry points below are what those wrappers end in.
-_raw_stream = torch._C._cuda_getCurrentRawStream
-_cur_device = torch._C._cuda_getDevice
-
-
-def _stream_id(index=None):
-    """The current HIP stream of device `index` (default: the current device) as an integer handle."""
-    return _raw_stream(_cur_device() if index is None else index)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda index: torch.cuda.current_stream(index).cuda_stream)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def _stream():
