@@ -60,7 +60,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
 
     def forward(self, rgb, x, ws, **block_kwargs):
         ws_in = ws
-        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        ws = ws[:, -1:, :].expand(-1, 3, -1)  # (`.repeat(1, 3, 1)` of superresolution.py:283 without the copy: the layers only read it)
         if x.shape[-1] != self.input_resolution:
             size = (self.input_resolution, self.input_resolution)
             x = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False, antialias=self.sr_antialias)

@@ -32,6 +32,11 @@ DEFAULT_FAST_COLOR = os.environ.get("P3D_EXACT", "0") != "1"
 def decoder_params(decoder):
     """(w0, b0, w1, b1) pre-scaled exactly like FullyConnectedLayer.forward (networks_stylegan2.py:121-127)."""
     l0, l2 = decoder.net[0], decoder.net[2]
+    if hasattr(l0, "_scaled") and hasattr(l2, "_scaled"):
+        # this package's FullyConnectedLayer keeps `w * weight_gain`, `b * bias_gain` per parameter version (the same two
+        # multiplications, so the same bits): two launches and ~20 us of host time less per render
+        (w0, b0), (w1, b1) = l0._scaled(torch.float32), l2._scaled(torch.float32)
+        return w0, b0, w1, b1
     return ops.prescale_mlp(l0.weight, l0.bias, l2.weight, l2.bias, l0.weight_gain, l0.bias_gain, l2.weight_gain,
                             l2.bias_gain)
 
