@@ -48,6 +48,8 @@ def _check_line(d, steps):
     if r["traffic"]:
         assert abs(r["hbm_measured_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and r["hbm_measured_frac"] < 1.0
         assert abs(r["traffic_over_compulsory"] - r["traffic"] / r["compulsory_bytes_per_launch"]) < 1e-9
+        assert r["compulsory_bytes_incl_draws"] == r["compulsory_bytes_per_launch"] + 512 * 512 * 96 * 4
+        assert abs(r["traffic_over_compulsory_incl_draws"] - r["traffic"] / r["compulsory_bytes_incl_draws"]) < 1e-9
     else:
         assert r["hbm_measured_frac"] is None and r["traffic_over_compulsory"] is None
     assert "checkpoint ecrutileE_eclustrousC_n120" in d["config"]["workload"] and "absent" in d["config"]["workload"]
