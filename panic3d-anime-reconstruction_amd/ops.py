@@ -76,8 +76,8 @@ def make_opts(rendering_options, triplane_crop=None, cull_clouds=None, binarize_
         raise NotImplementedError("disparity_space_sampling together with ray_start = ray_end = 'auto'")
     if ro.get("clamp_mode", "softplus") != "softplus":
         raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")  # ray_marcher.py:35
-    if ro.get("density_noise", 0) > 0:
-        raise NotImplementedError("density_noise > 0 (renderer.py:276-277) is a training-time option")
+    if (ro.get("density_noise", 0) or 0) > 0:  # (ImportanceRenderer.forward routes such calls to forward_staged)
+        raise NotImplementedError("density_noise > 0 (renderer.py:276-277) is not an option of the fused kernel: ImportanceRenderer.forward_staged")
     if ro.get("triplane_depth", 1) != 1:
         raise NotImplementedError("triplane_depth != 1")
     bw = float(ro["box_warp"])

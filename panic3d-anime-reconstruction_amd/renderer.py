@@ -82,7 +82,13 @@ class ImportanceRenderer(torch.nn.Module):
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None,
                 cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False,
-                per_view_clamp=False, exact=None):
+                per_view_clamp=False, exact=None, density_noise_draws=None):
+        if (rendering_options.get("density_noise", 0) or 0) > 0:  # renderer.py:276-277 (a training-time option): the staged path
+            if return_dumps or per_view_clamp:
+                raise NotImplementedError("density_noise > 0 runs the staged path: no per-stage dumps, no per-view clamp")
+            return self.forward_staged(planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=triplane_crop,
+                                       cull_clouds=cull_clouds, binarize_clouds=binarize_clouds, jitter=jitter, u=u,
+                                       density_noise_draws=density_noise_draws)
         if exact is None:
             exact = getattr(self, "exact", None)
         fast = DEFAULT_FAST_COLOR if exact is None else not exact
@@ -108,6 +114,71 @@ class ImportanceRenderer(torch.nn.Module):
                          decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps, per_view_clamp=per_view_clamp,
                          ray_limits=limits)
         return out  # rgb_final, depth_final, weights.sum(2), xyz_final  (renderer.py:264)
+
+    # ---- the reference's own structure, stage by stage ---------------------------------------------------------------------
+    def forward_staged(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None, cull_clouds=None,
+                       binarize_clouds=None, jitter=None, u=None, density_noise_draws=None):
+        """ImportanceRenderer.forward (renderer.py:162-264) as the reference structures it — stratified depths, run_model, masks, ray
+        marcher, importance resampling, run_model, masks, unify, ray marcher — with every stage on its stand-alone HIP kernel
+        (p3d_sample_stratified_f32, p3d_triplane_decode_f32, p3d_composite_f32, p3d_importance_f32, p3d_unify_perm_f32) and the
+        reference's element-wise glue (sample points, masks, gathers) as torch ops on the device; intermediates ([N,R*S,32] colours)
+        are materialised like the reference's.  It exists for the one option the fused kernel does not take: `density_noise > 0`
+        (renderer.py:276-277, `sigma += randn_like(sigma) * density_noise` inside run_model, i.e. BEFORE the crop / cull masks), which
+        needs a value per decoded sample that the final pass of the fused kernel, re-decoding the coarse samples, would have to see
+        twice.  Without noise it computes what forward() computes (tested), far slower.  Fixed ray limits, linear depth spacing.
+        density_noise_draws: (noise of the coarse pass [N,R*Sc,1], of the fine pass [N,R*Sf,1]) — parity tests; default: torch.randn
+        on the device, drawn in the reference's order (jitter, coarse noise, u, fine noise)."""
+        ro = dict(rendering_options)
+        dn = float(ro.pop("density_noise", 0) or 0)
+        if ro.get("ray_start") == "auto" or ro.get("ray_end") == "auto" or ro.get("disparity_space_sampling", False):
+            raise NotImplementedError("forward_staged: fixed ray limits and linear depth spacing only")
+        opts = self._opts(ro, decoder)  # run_model's options: no masks inside the decode (they follow the noise)
+        N, R, _ = ray_origins.shape
+        dev = ray_origins.device
+        Sc, Sf = opts.Sc, opts.Sf
+        o, d = ray_origins.float().contiguous(), ray_directions.float().contiguous()
+        planes_nhwc, mlp = self._nhwc(planes), decoder_params(decoder)
+        bw = float(ro["box_warp"])
+        nc, nf = density_noise_draws if density_noise_draws is not None else (None, None)
+
+        def masks(sigma, xyz):  # renderer.py:187-198 with triplane_crop_mask / cull_clouds_mask (:138-153), same torch ops
+            if triplane_crop:
+                inside = (xyz[:, :, [0, 2]].abs() <= (bw / 2 - triplane_crop)).all(dim=-1, keepdim=True)
+                sigma = torch.where(inside, sigma, torch.full_like(sigma, -1e3))  # (the 'bottom' clause never changes the result)
+            thr = binarize_clouds or cull_clouds
+            if thr:
+                alpha = 1 - torch.exp(-torch.nn.functional.softplus(sigma - 1))
+                low = alpha < thr
+                sigma = torch.where(low, torch.full_like(sigma, -1e3), torch.full_like(sigma, 1e3) if binarize_clouds else sigma)
+            return sigma
+
+        def decode(depths, S, noise):  # run_model on the sample points of `depths` [N,R,S,1] (renderer.py:179-183, 266-280)
+            xyz = (o.unsqueeze(-2) + depths * d.unsqueeze(-2)).reshape(N, R * S, 3)
+            sigma, rgb = ops.triplane_decode(planes_nhwc, xyz, mlp, opts)
+            if dn > 0:
+                noise = torch.randn_like(sigma) if noise is None else noise.to(dev, torch.float32).reshape(sigma.shape)
+                sigma = sigma + noise * dn
+            sigma = masks(sigma, xyz)
+            return rgb.reshape(N, R, S, 32), sigma.reshape(N, R, S, 1), xyz.reshape(N, R, S, 3)
+
+        if jitter is None:  # renderer.py:324
+            jitter = torch.rand((N, R, Sc, 1), dtype=torch.float32, device=dev)
+        depths_c = ops.sample_stratified(float(ro["ray_start"]), float(ro["ray_end"]), Sc, jitter.to(dev, torch.float32).reshape(N, R, Sc, 1))
+        rgb_c, sig_c, xyz_c = decode(depths_c, Sc, nc)
+        wb = bool(ro.get("white_back", False))
+        if Sf > 0:
+            _, _, w = ops.composite(rgb_c, sig_c, depths_c, white_back=wb)
+            if u is None:  # renderer.py:371
+                u = torch.rand((N * R, Sf), dtype=torch.float32, device=dev)
+            depths_f = ops.importance(depths_c, w, u.to(dev, torch.float32))
+            rgb_f, sig_f, xyz_f = decode(depths_f, Sf, nf)
+            perm = ops.unify_perm(depths_c.reshape(N * R, Sc), depths_f.reshape(N * R, Sf)).to(torch.int64).reshape(N, R, Sc + Sf, 1)
+            take = lambda a, b: torch.gather(torch.cat([a, b], dim=-2), -2, perm.expand(-1, -1, -1, a.shape[-1]))
+            depths, colors, sigma = take(depths_c, depths_f), take(torch.cat([rgb_c, xyz_c], -1), torch.cat([rgb_f, xyz_f], -1)), take(sig_c, sig_f)
+        else:
+            depths, colors, sigma = depths_c, torch.cat([rgb_c, xyz_c], -1), sig_c
+        out, depth, w = ops.composite(colors.contiguous(), sigma.contiguous(), depths.contiguous(), white_back=wb)
+        return out[..., :-3].contiguous(), depth, w.sum(2), out[..., -3:].contiguous()
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
         """renderer.py:266-280 — sample_directions are ignored, as the reference's decoder ignores them

@@ -290,6 +290,7 @@ def main():
     stage_cases()
     ray_cases()
     auto_case()
+    density_noise_case()
 
 
 def auto_case():
@@ -304,8 +305,53 @@ def auto_case():
                 keep=("feat", "depth", "wsum", "xyz", "inds", "perm", "depths_fine", "depths_coarse", "weights_coarse"))
 
 
+def density_noise_case():
+    """rendering_options['density_noise'] > 0 (renderer.py:276-277): run_model adds randn_like(sigma) * density_noise BEFORE the crop /
+    cull masks, in both passes.  The reference's draws in call order — rand_like (jitter), randn_like (coarse noise), rand (u), randn_like
+    (fine noise) — are captured and stored (the two uniform draws no longer follow each other in the generator's stream, so
+    make_random_draws(seed) does not reproduce u).  Also stored: the same view WITHOUT noise through the same fixture planes."""
+    seed, res, Sc, Sf, dn = 720, 16, 16, 12, 0.75
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, density_noise=dn)
+    planes = T.make_planes(seed, 1, 256, 256, scale=4.0, smooth=8)
+    dec = ref_decoder(seed + 1, 1.0, True, 40.0)
+    o, d, _ = persp_rays(5.0, 25.0, 30.0, res)
+    rend = ImportanceRenderer(use_triplane=True)
+    rec = {"noise": []}
+    orig = dict(rand_like=torch.rand_like, rand=torch.rand, randn_like=torch.randn_like)
+
+    def rand_like(x, *a, **k):
+        r = orig["rand_like"](x, *a, **k)
+        rec.setdefault("jitter", r.clone())
+        return r
+
+    def rand(*a, **k):
+        r = orig["rand"](*a, **k)
+        rec.setdefault("u", r.clone())
+        return r
+
+    def randn_like(x, *a, **k):
+        r = orig["randn_like"](x, *a, **k)
+        rec["noise"].append(r.clone())
+        return r
+
+    torch.rand_like, torch.rand, torch.randn_like = rand_like, rand, randn_like
+    try:
+        torch.manual_seed(seed + 2)
+        feat, depth, wsum, xyz = rend(torch.from_numpy(planes), dec, o, d, ro, triplane_crop=0.1, cull_clouds=0.5)
+    finally:
+        torch.rand_like, torch.rand, torch.randn_like = orig["rand_like"], orig["rand"], orig["randn_like"]
+    assert len(rec["noise"]) == 2 and rec["noise"][0].shape == (1, res * res * Sc, 1) and rec["noise"][1].shape == (1, res * res * Sf, 1)
+    save("render_density_noise.npz", feat=feat.numpy(), depth=depth.numpy(), wsum=wsum.numpy(), xyz=xyz.numpy(),
+         jitter=rec["jitter"].numpy(), u=rec["u"].numpy(), noise_coarse=rec["noise"][0].numpy(), noise_fine=rec["noise"][1].numpy(),
+         rays_o=o.numpy(), rays_d=d.numpy(), planes_checksum=np.array(T.checksum(planes)), meta_seed=np.array(seed), meta_res=np.array(res),
+         meta_Sc=np.array(Sc), meta_Sf=np.array(Sf), meta_density_noise=np.array(dn), meta_sigma_gain=np.array(40.0))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "auto":  # only the fixture added in round 2 (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] == "density_noise":  # only the fixture added at the end of round 4
+        torch.set_num_threads(8)
+        density_noise_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "auto":  # only the fixture added in round 2 (the others are unchanged)
         torch.set_num_threads(8)
         auto_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "decoder":  # only the fixtures added in round 4

@@ -648,3 +648,76 @@ def test_stratified_depths_out_of_order_are_sorted_like_the_reference(hip, oracl
                           hip.ops.make_opts(ro, small_launch_kernel=False, fast_color=True, **kw), ray_tile_w=res)
     for nm, a, b in zip(("feat", "depth", "wsum", "xyz"), fast, ref):
         assert float(np.abs(a.cpu().numpy() - b).max()) <= FAST_MAX[nm], nm
+
+
+# ---- the staged path (ImportanceRenderer.forward_staged): the reference's structure on the stand-alone stage kernels ------------
+def _stub_decoder(raw, lr_mul, force_sigmoid):
+    class FC:
+        def __init__(self, w, b, i):
+            self.weight, self.bias, self.weight_gain, self.bias_gain = w, b, lr_mul / np.sqrt(i), lr_mul
+
+    class Dec:
+        pass
+    d = Dec()
+    d.force_sigmoid = bool(force_sigmoid)
+    r = [dev(x) for x in raw]
+    d.net = [FC(r[0], r[1], 32), None, FC(r[2], r[3], 64)]
+    return d
+
+
+def _within(a, b, tol):
+    """fraction of rays whose every component is within tol, and the largest difference"""
+    diff = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).reshape(-1, a.shape[-1]).max(axis=1)
+    return float((diff <= tol).mean()), float(diff.max())
+
+
+@pytest.mark.parametrize("name", ["render_32x32_16p16", "render_variant_b", "render_c1_64x64_s32", "render_12x12_96p96"])
+def test_staged_path_equals_the_fused_kernel_without_noise(hip, name):
+    """forward_staged — stratified depths, decode, masks, marcher, importance, decode, masks, unify, marcher as separate launches with
+    the reference's torch glue in between — computes what the fused kernel computes: against the fused exact render and against the
+    REFERENCE's outputs of the fixture, within the fp32 tolerances (the masks are torch's softplus / exp here, the contract's
+    polynomials there: a sample within rounding of the cull threshold may flip, so a 0.5 % allowance on the rays)."""
+    g = T.load_golden(name + ".npz")
+    inp = T.golden_render_inputs(g)
+    rend = hip.ImportanceRenderer(use_triplane=bool(inp["ro"]["use_triplane"]))
+    dec = _stub_decoder(inp["raw_mlp"], inp["lr_mul"], inp["kw"]["force_sigmoid"])
+    kw = {k: v for k, v in inp["kw"].items() if k != "force_sigmoid"}
+    args = (dev(inp["planes"]), dec, dev(inp["rays_o"]), dev(inp["rays_d"]), inp["ro"])
+    common = dict(jitter=dev(inp["jitter"]), u=dev(inp["u"]) if inp["ro"]["depth_resolution_importance"] > 0 else None, **kw)
+    with torch.no_grad():
+        fused = rend(*args, exact=True, **common)
+        staged = rend.forward_staged(*args, **common)
+    for key, a, b, tol in zip(("feat", "depth", "wsum", "xyz"), staged, fused, (TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ)):
+        assert a.shape == b.shape, key
+        frac, worst = _within(a.cpu().numpy(), b.cpu().numpy(), tol)
+        assert frac >= 0.995, (key, "vs fused", frac, worst)
+        frac, worst = _within(a.cpu().numpy(), g[key], tol)
+        assert frac >= 0.995, (key, "vs reference", frac, worst)
+
+
+def test_density_noise_vs_reference(hip):
+    """rendering_options['density_noise'] > 0 (renderer.py:276-277: `sigma += randn_like(sigma) * density_noise` inside run_model, before
+    the masks, in both passes) — ImportanceRenderer.forward routes it to the staged path.  Against the REFERENCE's own render with its
+    four draws (jitter, coarse noise, u, fine noise) captured by tests/golden/make_golden.py; the noise really changes the frame; and
+    with no draws given the renderer makes its own on the device."""
+    g = T.load_golden("render_density_noise.npz")
+    seed, res, Sc, Sf, dn = int(g["meta_seed"]), int(g["meta_res"]), int(g["meta_Sc"]), int(g["meta_Sf"]), float(g["meta_density_noise"])
+    planes = T.make_planes(seed, 1, 256, 256, scale=4.0, smooth=8)
+    assert T.checksum(planes) == str(g["planes_checksum"])
+    raw = T.make_decoder_params(seed + 1, 1.0, float(g["meta_sigma_gain"]))
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, density_noise=dn)
+    rend = hip.ImportanceRenderer(use_triplane=True)
+    dec = _stub_decoder(raw, 1.0, True)
+    args = (dev(planes), dec, dev(g["rays_o"]), dev(g["rays_d"]))
+    kw = dict(triplane_crop=0.1, cull_clouds=0.5, jitter=dev(g["jitter"]), u=dev(g["u"]))
+    with torch.no_grad():
+        out = rend(*args, ro, density_noise_draws=(dev(g["noise_coarse"]), dev(g["noise_fine"])), **kw)
+        quiet = rend.forward_staged(*args, dict(ro, density_noise=0), **kw)
+        own = rend(*args, ro, triplane_crop=0.1, cull_clouds=0.5)
+    for key, a, tol in zip(("feat", "depth", "wsum", "xyz"), out, (TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ)):
+        frac, worst = _within(a.cpu().numpy(), g[key], tol)
+        assert frac >= 0.995, (key, frac, worst)
+    assert float((out[0] - quiet[0]).abs().max()) > 1e-2  # the noise matters in this fixture
+    assert all(torch.isfinite(t).all() for t in own) and own[0].shape == (1, res * res, 32)
+    with pytest.raises(NotImplementedError):
+        hip.ops.make_opts(ro)  # the fused kernel itself does not take the option
