@@ -119,7 +119,7 @@ class TriPlaneGenerator(torch.nn.Module):
     def __getstate__(self):
         """Pickling / deep copies (the reference snapshots G): derived tensors and per-call state stay out."""
         state = dict(self.__dict__)
-        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo", "_conv_domain_flag", "_mapping_dicts"):
+        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo", "_conv_domain_flag", "_mapping_dicts", "_occ_consts"):
             if k in state:
                 state[k] = None
         return state
@@ -397,6 +397,7 @@ class TriPlaneGenerator(torch.nn.Module):
         version counter (`.data`, DLPack aliases; memo.py), and for servers that want the last subject's tensors released."""
         self.__dict__["_ws_memo"] = None
         self.__dict__["_mapping_dicts"] = None
+        self.__dict__["_occ_consts"] = None
         self._last_planes = None
         self.renderer._planes_cache = (None, None, None)
         for m in self.modules():

@@ -42,16 +42,25 @@ def front_occlusion(G, x, out, offset=0.01):
     (`out['triplane']`) once more through the fused renderer and skips the rest."""
     # (G._sign: the (-1, 1, -1) tensor kept on the device — a torch.tensor(..., device=...) here is a pageable host->device copy
     # that waits for everything queued on the stream, i.e. for the whole view: ~1 ms of idle GPU per pasted view, tools/host_profile.py)
-    ro = out["image_xyz"] * G._sign(out["image_xyz"].device)
-    ro[:, 2, :, :] -= G.rendering_kwargs["ray_start"] - offset
-    rd = torch.zeros_like(out["image_xyz"])
-    rd[:, 2, :, :] = 1
-    N, _, H, W = ro.shape
+    # ro = xyz * (-1, 1, -1); ro.z -= ray_start - offset   (triplane.py:568-570) as ONE launch: fma(xyz, sign, shift) — xyz * sign is
+    # exact, so the single rounding is the reference's subtraction; rd = (0, 0, 1) everywhere is a constant kept per shape
+    xyz = out["image_xyz"]
+    N, _, H, W = xyz.shape
+    dev = xyz.device
+    consts = G.__dict__.get("_occ_consts")
+    key = (dev, N, H, W, float(G.rendering_kwargs["ray_start"]), float(offset))
+    if consts is None or consts[0] != key:
+        shift = torch.zeros((1, 3, 1, 1), dtype=torch.float32, device=dev)
+        shift[0, 2] = -(G.rendering_kwargs["ray_start"] - offset)
+        rd_flat = torch.zeros((N, H * W, 3), dtype=torch.float32, device=dev)
+        rd_flat[..., 2] = 1
+        consts = G.__dict__["_occ_consts"] = (key, shift, rd_flat)
+    ro = torch.addcmul(consts[1], xyz, G._sign(dev))
     flat = lambda t: t.permute(0, 2, 3, 1).reshape(N, H * W, 3).contiguous()
     draws = G._inject_draws or (None, None)
     if isinstance(draws, list):
         draws = draws.pop(0)
-    _, _, wsum, _ = G.renderer(out["triplane"], G.decoder, flat(ro), flat(rd), G.rendering_kwargs,
+    _, _, wsum, _ = G.renderer(out["triplane"], G.decoder, flat(ro), consts[2], G.rendering_kwargs,
                                triplane_crop=x.get("triplane_crop"), cull_clouds=x.get("cull_clouds"),
                                binarize_clouds=x.get("binarize_clouds"), jitter=draws[0], u=draws[1])
     return wsum.permute(0, 2, 1).reshape(N, 1, H, W)
