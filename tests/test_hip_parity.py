@@ -721,3 +721,27 @@ def test_density_noise_vs_reference(hip):
     assert all(torch.isfinite(t).all() for t in own) and own[0].shape == (1, res * res, 32)
     with pytest.raises(NotImplementedError):
         hip.ops.make_opts(ro)  # the fused kernel itself does not take the option
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_staged_path_random_configs(hip, seed):
+    """The staged path against the fused kernel over the randomised sweep of test_render_random_configs_bit_exact (batches, non-square
+    planes, ragged ray lists, 4..70 coarse samples, 0 / 1..70 / 129..149 fine samples, every mask mode, both plane conventions, both
+    backgrounds, rays that miss the volume): two implementations of the same forward() that share no kernel except the decoder's
+    arithmetic.  fp32 tolerances on >= 99 % of the rays (torch's softplus / exp decide the cull mask in the staged path)."""
+    c = _random_config(seed)
+    rend = hip.ImportanceRenderer(use_triplane=bool(c["ro"]["use_triplane"]))
+    dec = _stub_decoder(c["raw"], c["lr_mul"], c["kw"]["force_sigmoid"])
+    kw = {k: v for k, v in c["kw"].items() if k != "force_sigmoid"}
+    Sf = c["ro"]["depth_resolution_importance"]
+    args = (dev(c["planes"]), dec, dev(c["o"]), dev(c["d"]), c["ro"])
+    common = dict(jitter=dev(c["jit"]), u=dev(c["u"]) if Sf > 0 else None, **kw)
+    with torch.no_grad():
+        fused = rend(*args, exact=True, ray_tile_w=c["tile_w"], **common)
+        staged = rend.forward_staged(*args, **common)
+    for key, a, b, tol in zip(("feat", "depth", "wsum", "xyz"), staged, fused, (TOL_FEAT, TOL_DEPTH, TOL_WEIGHT, TOL_XYZ)):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert a.shape == b.shape and np.isfinite(a).all() == np.isfinite(b).all(), key
+        ok = np.isfinite(a) & np.isfinite(b)
+        frac, worst = _within(np.where(ok, a, 0), np.where(ok, b, 0), tol)
+        assert frac >= 0.99, (key, seed, frac, worst)
