@@ -12,7 +12,8 @@ views and `detach()`), not for those.  Such writes are UNSUPPORTED while memoisa
 (`t.copy_`, `load_state_dict`, `misc.copy_params_and_buffers` all do), or call `TriPlaneGenerator.clear_memo()` after the write,
 or turn the layers off: `P3D_NO_MEMO=1` in the environment, or `panic3d_amd.memo.set_enabled(False)`.
 The switch also turns off the parameter-derived caches, which are keyed the same way — pre-scaled weights, f16 operand copies,
-transposed ToRGB weights, `noise_const * strength`, the StylePlan's concatenated affine weights, flipped FIR filters — so with it
+transposed ToRGB weights, `noise_const * strength`, the per-element strengths of a NoisePool, the StylePlan's concatenated affine
+weights, flipped FIR filters — so with it
 off EVERY call works from the tensors as they are in memory (and pays for it: a pass re-derives 30 M parameters); `clear_memo()`
 drops them once.
 """
