@@ -243,9 +243,8 @@ class SynthesisLayer(_CacheFree):
 
 class NoisePool:
     """noise_mode='random' for a whole pass in two launches.  The reference draws `randn([N,1,res,res]) * noise_strength` inside every
-    SynthesisLayer.forward (networks_stylegan2.py:342): 2 launches x 15 layers that a batch-1 backbone pass cannot issue as fast as the
-    GPU runs them (tools/host_profile.py: 0.85 ms of a 4.1 ms view of generate.py, whose G.f calls leave noise_mode at 'random').
-    Here ONE randn call draws the values of all layers of the pass, in the layers' execution order, and ONE multiply applies every
+    SynthesisLayer.forward (networks_stylegan2.py:342): 2 launches x 15 layers in the launch-bound head of a batch-1 backbone pass
+    (generate.py's G.f calls leave noise_mode at 'random').  Here ONE randn call draws the values of all layers of the pass, in the layers' execution order, and ONE multiply applies every
     layer's strength (a per-element vector cached per parameter version); each layer then takes its slice.  Same distribution, same
     per-layer independence; the stream of the device generator is consumed in one call instead of fifteen, so the values differ from
     a call-for-call run under the same seed (the reference's own GPU and CPU streams differ from each other in the same way)."""
