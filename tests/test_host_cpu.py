@@ -434,3 +434,81 @@ def test_one_launch_forms_of_the_view_glue_round_like_the_reference():
     h = sign * 0.5
     assert torch.equal(torch.addcmul(h, x, h), ref)
     assert torch.equal(torch.add(torch.tensor(0.5), x, alpha=0.5), 0.5 * x + 0.5)
+
+
+def _oracle_stage_ops(monkeypatch, P, oracle, box_warp):
+    """Replace the stand-alone stage operators of panic3d_amd.ops (each one HIP kernel) by the CPU oracle's restatement of the same
+    stage, on CPU tensors: what is left of ImportanceRenderer.forward_staged is its HOST logic — the order of the stages, the sample
+    points, where the noise goes, the masks, the merge — which can then run without a GPU."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    n = lambda x: x.detach().cpu().numpy()
+    ops = P.ops
+
+    def triplane_decode(planes, coords, mlp, opts, density_only=False):
+        sigma, rgb = oracle.decode(n(planes), n(coords), tuple(n(m) for m in mlp), box_warp, plane_mode=int(opts.plane_mode),
+                                   flags=int(opts.flags) & oracle.FLAG_FORCE_SIGMOID)
+        return t(sigma), t(rgb)
+
+    def composite(colors, densities, depths, white_back=True):
+        rgb, depth, w = oracle.composite(n(colors), n(densities), n(depths), white_back=white_back)
+        lead = tuple(colors.shape[:-2])
+        return t(rgb).reshape(lead + (colors.shape[-1],)), t(depth).reshape(lead + (1,)), t(w).reshape(lead + (colors.shape[-2] - 1, 1))
+
+    monkeypatch.setattr(ops, "planes_to_nhwc", lambda planes: planes)
+    monkeypatch.setattr(ops, "triplane_decode", triplane_decode)
+    monkeypatch.setattr(ops, "sample_stratified", lambda a, b, S, jit: t(oracle.sample_stratified(a, b, S, n(jit))))
+    monkeypatch.setattr(ops, "composite", composite)
+    monkeypatch.setattr(ops, "importance", lambda d, w, u: t(oracle.importance(n(d), n(w), n(u))[0]).reshape(tuple(d.shape[:2]) + (u.shape[-1], 1)))
+    monkeypatch.setattr(ops, "unify_perm", lambda dc, df: t(oracle.unify_perm(n(dc), n(df))))
+
+
+class _FC:
+    def __init__(self, w, b, i, lr_mul=1.0):
+        self.weight, self.bias, self.weight_gain, self.bias_gain = torch.from_numpy(w), torch.from_numpy(b), lr_mul / np.sqrt(i), lr_mul
+
+
+def _cpu_decoder(raw, force_sigmoid=True, lr_mul=1.0):
+    class Dec:
+        pass
+    d = Dec()
+    d.force_sigmoid = force_sigmoid
+    d.net = [_FC(raw[0], raw[1], 32, lr_mul), None, _FC(raw[2], raw[3], 64, lr_mul)]
+    return d
+
+
+def test_staged_path_host_logic_with_density_noise_vs_reference(P, oracle, monkeypatch):
+    """The HOST side of ImportanceRenderer.forward_staged — which ImportanceRenderer.forward takes for rendering_options['density_noise']
+    > 0 (renderer.py:276-277) — with every stage kernel replaced by the CPU oracle's restatement of that stage: against the REFERENCE's
+    own render with its four draws captured (tests/golden/render_density_noise.npz), and without noise against the oracle's fused
+    render of a fixture.  (The same path on the HIP kernels: tests/test_hip_parity.py.)"""
+    g = T.load_golden("render_density_noise.npz")
+    seed, res, Sc, Sf, dn = int(g["meta_seed"]), int(g["meta_res"]), int(g["meta_Sc"]), int(g["meta_Sf"]), float(g["meta_density_noise"])
+    planes = T.make_planes(seed, 1, 256, 256, scale=4.0, smooth=8)
+    assert T.checksum(planes) == str(g["planes_checksum"])
+    raw = T.make_decoder_params(seed + 1, 1.0, float(g["meta_sigma_gain"]))
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf, density_noise=dn)
+    _oracle_stage_ops(monkeypatch, P, oracle, ro["box_warp"])
+    rend = P.ImportanceRenderer(use_triplane=True)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    out = rend(tt(planes), _cpu_decoder(raw), tt(g["rays_o"]), tt(g["rays_d"]), ro, triplane_crop=0.1, cull_clouds=0.5,
+               jitter=tt(g["jitter"]), u=tt(g["u"]), density_noise_draws=(tt(g["noise_coarse"]), tt(g["noise_fine"])))
+    for key, a, tol in zip(("feat", "depth", "wsum", "xyz"), out, (1e-4, 2e-5, 3e-5, 1e-4)):
+        diff = np.abs(a.numpy().astype(np.float64) - g[key]).reshape(-1, a.shape[-1]).max(axis=1)
+        assert (diff <= tol).mean() >= 0.995, (key, float(diff.max()))
+    quiet = rend.forward_staged(tt(planes), _cpu_decoder(raw), tt(g["rays_o"]), tt(g["rays_d"]), dict(ro, density_noise=0),
+                                triplane_crop=0.1, cull_clouds=0.5, jitter=tt(g["jitter"]), u=tt(g["u"]))
+    assert float((out[0] - quiet[0]).abs().max()) > 1e-2  # the noise matters in this fixture
+    # ... and without noise, a fixture with two views, binarised clouds and non-default limits: the oracle's fused render
+    g2 = T.load_golden("render_variant_b.npz")
+    inp = T.golden_render_inputs(g2)
+    monkeypatch.undo()
+    _oracle_stage_ops(monkeypatch, P, oracle, inp["ro"]["box_warp"])
+    rend2 = P.ImportanceRenderer(use_triplane=bool(inp["ro"]["use_triplane"]))
+    kw = {k: v for k, v in inp["kw"].items() if k != "force_sigmoid"}
+    st = rend2.forward_staged(tt(inp["planes"]), _cpu_decoder(inp["raw_mlp"], inp["kw"]["force_sigmoid"], inp["lr_mul"]), tt(inp["rays_o"]),
+                              tt(inp["rays_d"]), inp["ro"], jitter=tt(inp["jitter"]), u=tt(inp["u"]), **kw)
+    ref = oracle.render(inp["planes"], inp["rays_o"], inp["rays_d"], inp["jitter"], inp["u"],
+                        oracle.prescale_mlp(*inp["raw_mlp"], lr_mul=inp["lr_mul"]), oracle.make_opts(inp["ro"], **inp["kw"]))
+    for key, a, b, tol in zip(("feat", "depth", "wsum", "xyz"), st, ref, (1e-4, 2e-5, 3e-5, 1e-4)):
+        diff = np.abs(a.numpy().astype(np.float64) - b).reshape(-1, a.shape[-1]).max(axis=1)
+        assert (diff <= tol).mean() >= 0.995, (key, float(diff.max()))
