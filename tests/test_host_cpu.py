@@ -462,7 +462,7 @@ def _oracle_stage_ops(monkeypatch, P, oracle, box_warp):
     monkeypatch.setattr(ops, "unify_perm", lambda dc, df: t(oracle.unify_perm(n(dc), n(df))))
 
 
-class _FC:
+class _StageFC:
     def __init__(self, w, b, i, lr_mul=1.0):
         self.weight, self.bias, self.weight_gain, self.bias_gain = torch.from_numpy(w), torch.from_numpy(b), lr_mul / np.sqrt(i), lr_mul
 
@@ -472,7 +472,7 @@ def _cpu_decoder(raw, force_sigmoid=True, lr_mul=1.0):
         pass
     d = Dec()
     d.force_sigmoid = force_sigmoid
-    d.net = [_FC(raw[0], raw[1], 32, lr_mul), None, _FC(raw[2], raw[3], 64, lr_mul)]
+    d.net = [_StageFC(raw[0], raw[1], 32, lr_mul), None, _StageFC(raw[2], raw[3], 64, lr_mul)]
     return d
 
 
