@@ -512,3 +512,119 @@ def test_staged_path_host_logic_with_density_noise_vs_reference(P, oracle, monke
     for key, a, b, tol in zip(("feat", "depth", "wsum", "xyz"), st, ref, (1e-4, 2e-5, 3e-5, 1e-4)):
         diff = np.abs(a.numpy().astype(np.float64) - b).reshape(-1, a.shape[-1]).max(axis=1)
         assert (diff <= tol).mean() >= 0.995, (key, float(diff.max()))
+
+
+@pytest.mark.parametrize("tag", ["none", "cond", "cond2", "cond3", "cond4"])  # cond*: every branch of the conditioning glue
+def test_generator_host_logic_vs_reference(P, monkeypatch, tag):
+    """The HOST side of the StyleGAN2 backbone (stylegan2.py: mapping network, StylePlan, block wiring with the activation-image
+    hand-overs, the PAniC-3D conditioning between blocks, constant noise) with every operator of panic3d_amd.ops replaced by its
+    plain-PyTorch restatement (tests/p3d_torch_ops.py), on CPU: against the REFERENCE's own outputs for the five generator fixtures
+    (tests/golden/make_golden_synthesis.py).  The same modules on the HIP kernels: tests/test_hip_synthesis.py."""
+    import p3d_torch_ops
+    sg = P.stylegan2
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    g = T.load_golden(f"syn_generator_{tag}.npz")
+    kw = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+    G = sg.Generator(cond_mode=str(g["cond_mode"]), **kw)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G.eval()
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cond = {k[5:]: tt(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    with torch.no_grad():
+        ws = G.mapping(tt(g["z"]), tt(g["c"]), cond, truncation_psi=0.7, truncation_cutoff=4)
+        assert np.abs(ws.numpy() - g["ws"]).max() < 1e-5
+        assert np.abs(G.mapping(tt(g["z"]), tt(g["c"]), cond).numpy() - g["ws_psi1"]).max() < 1e-5
+        img = G.synthesis(tt(g["ws"]), cond, noise_mode="const").numpy()
+        assert img.shape == g["img"].shape and rel(img, g["img"]) < 1e-4, rel(img, g["img"])
+        # the activation-image hand-overs are part of the wiring under test: without them the planes must not change
+        monkeypatch.setattr(sg, "CONV_IMG", False)
+        img2 = G.synthesis(tt(g["ws"]), cond, noise_mode="const").numpy()
+        assert rel(img2, g["img"]) < 1e-4 and rel(img2, img) < 1e-5
+        # random noise through the NoisePool: zero strengths in these fixtures? then the planes equal the constant-noise ones
+        strengths = [float(m.noise_strength) for m in G.synthesis.modules() if isinstance(m, sg.SynthesisLayer)]
+        img3 = G.synthesis(tt(g["ws"]), cond, noise_mode="random").numpy()
+        assert np.isfinite(img3).all() and (any(strengths) or rel(img3, img2) < 1e-6)
+
+
+def _oracle_render_op(monkeypatch, P, oracle):
+    """ops.render (the fused renderer launch) replaced by the CPU oracle's render on CPU tensors — with shared planes (V views of one
+    subject) and the per-view depth clamp handled the way the kernel's flags define them."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    n = lambda x: x.detach().cpu().numpy()
+
+    def render(planes, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False, ray_limits=None,
+               rng_seed=None):
+        assert not dumps and rng_seed is None and ray_limits is None
+        oo = oracle.Opts(opts.coord_scale, opts.ray_start, opts.ray_end, opts.depth_delta, opts.crop_limit, opts.cull_thresh, opts.Sc, opts.Sf,
+                         opts.plane_mode, int(opts.flags) & 31)
+        N, R = rays_o.shape[0], rays_o.shape[1]
+        pl, m = n(planes), tuple(n(x) for x in mlp)
+        jit, uu = n(jitter).reshape(N, R, opts.Sc), (n(u).reshape(N, R, opts.Sf) if opts.Sf > 0 else None)
+        if N > 1 and (per_view_clamp or pl.shape[0] == 1):  # every view its own call (= its own depth-clamp range), planes shared or not
+            outs = [oracle.render(pl[min(i, pl.shape[0] - 1)][None], n(rays_o)[i][None], n(rays_d)[i][None], jit[i][None],
+                                  None if uu is None else uu[i], m, oo) for i in range(N)]
+            return tuple(t(np.concatenate([o[k] for o in outs])) for k in range(4))
+        return tuple(t(a) for a in oracle.render(pl, n(rays_o), n(rays_d), jit, None if uu is None else uu.reshape(N * R, -1), m, oo))
+
+    monkeypatch.setattr(P.ops, "render", render)
+
+
+_TRI_RK = {"image_resolution": 512, "disparity_space_sampling": False, "clamp_mode": "softplus",
+           "superresolution_module": "training.superresolution.SuperresolutionHybrid8XDC", "c_gen_conditioning_zero": False,
+           "gpc_reg_prob": 0.5, "c_scale": 1.0, "superresolution_noise_mode": "none", "density_reg": 0.25,
+           "density_reg_p_dist": 0.004, "reg_type": "l1", "decoder_lr_mul": 1.0, "sr_antialias": True, "white_back": True,
+           "triplane_depth": 1, "use_triplane": 1, "tanh_rgb_output": False, "box_warp": 0.7, "ray_start": 0.5, "ray_end": 1.5,
+           "depth_resolution": 12, "depth_resolution_importance": 12, "avg_camera_radius": 1.0, "avg_camera_pivot": [0, 0, 0]}
+_TRI_KW = dict(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, sr_num_fp16_res=0,
+               mapping_kwargs={"num_layers": 2}, rendering_kwargs=_TRI_RK,
+               sr_kwargs={"channel_base": 32768, "channel_max": 512, "fused_modconv_default": "inference_only"},
+               cond_mode="none", triplane_width=32, sr_channels_hidden=16, backbone_resolution=32, channel_base=1024,
+               channel_max=32, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+
+
+@pytest.mark.parametrize("fixture", ["syn_triplane_f", "syn_triplane_f_cond"])
+def test_triplane_generator_f_host_logic_vs_reference(P, oracle, monkeypatch, fixture):
+    """TriPlaneGenerator.f END TO END on CPU — seeds -> z -> ws -> planes -> renderer -> super-resolution, the dict-in / dict-out API of
+    PAniC-3D (triplane.py:313-508) — with the synthesis operators replaced by their PyTorch restatements and the renderer launch by the
+    CPU oracle: everything that is host logic in generator.py / stylegan2.py / cameras.py / renderer.py runs as shipped, against the
+    REFERENCE's own G.f outputs (perspective + orthographic view; the conditioned generator that generate.py feeds).  The same call
+    on the HIP kernels: tests/test_hip_synthesis.py."""
+    import p3d_torch_ops
+    from panic3d_amd.generator import TriPlaneGenerator
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    _oracle_render_op(monkeypatch, P, oracle)
+    monkeypatch.setattr(P.ops, "planes_to_nhwc", lambda planes: planes)
+    g = T.load_golden(fixture + ".npz")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    cond_case = fixture.endswith("_cond")
+    kw = dict(_TRI_KW, cond_mode=str(g["cond_mode"]), rendering_kwargs=dict(_TRI_RK, c_gen_conditioning_zero=True)) if cond_case else dict(_TRI_KW)
+    G = TriPlaneGenerator(**kw)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G.eval()
+    G.set_force_sigmoid(True)
+    G.set_render_exact(True)
+    G._inject_draws = (tt(g["jitter"]), tt(g["u"]))
+    if cond_case:
+        cond = {k[5:]: tt(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+        x = dict(elevations=torch.tensor([5.0]), azimuths=torch.tensor([-30.0]), fovs=torch.tensor([30.0]), seeds=[7], cond=cond,
+                 triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16, noise_mode="const")
+    else:
+        x = dict(elevations=torch.tensor([0.0, 10.0]), azimuths=torch.tensor([20.0, 200.0]), fovs=torch.tensor([30.0, -1.0]), seeds=[3, 4],
+                 cond={}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    try:
+        with torch.no_grad():
+            out = G.f(x)
+    finally:
+        P.cameras.cached_view_clear()  # (CPU views must not stay in the process-wide cache)
+    if not cond_case:
+        assert np.abs(x["camera_params"].numpy() - g["camera_params"]).max() < 1e-6
+    assert np.abs(x["ws"].numpy() - g["ws"]).max() < 1e-5
+    assert rel(out["triplane"].numpy(), g["triplane"]) < 1e-4
+    for k, tol in (("image_raw", 2e-3), ("image_weights", 2e-3), ("image_xyz", 2e-3)):
+        d = np.abs(out[k].numpy() - g[k])
+        assert d.max() < 20 * tol and d.mean() < tol, (k, d.max(), d.mean())
+    d = np.abs(out["image"][..., ::4, ::4].numpy() - g["image_sub4"])
+    assert out["image"].shape[1:] == (3, 512, 512) and d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
