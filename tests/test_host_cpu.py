@@ -628,3 +628,127 @@ def test_triplane_generator_f_host_logic_vs_reference(P, oracle, monkeypatch, fi
         assert d.max() < 20 * tol and d.mean() < tol, (k, d.max(), d.mean())
     d = np.abs(out["image"][..., ::4, ::4].numpy() - g["image_sub4"])
     assert out["image"].shape[1:] == (3, 512, 512) and d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
+
+
+def test_density_grid_host_logic_vs_the_references_get_eg3d_volume(P, oracle, monkeypatch):
+    """volume.density_grid / to_volume / create_samples — the host side of `_util/eg3d_metrics3d.py:94-183 get_eg3d_volume` — on CPU
+    against the output of the reference's OWN get_eg3d_volume (tests/golden/volume_reference.npz): the grid query kernel is replaced
+    by create_samples + the oracle's decoder, the activation pass by the oracle's, the backbone operators by their PyTorch
+    restatements.  (On the HIP kernels: tests/test_hip_synthesis.py.)"""
+    import p3d_torch_ops
+    from panic3d_amd.generator import TriPlaneGenerator
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    _oracle_render_op(monkeypatch, P, oracle)
+    _oracle_stage_ops(monkeypatch, P, oracle, _TRI_RK["box_warp"])
+    vol = P.volume
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+    def grid_density(planes, grid_n, lo, hi, voxel_size, offsets, mlp, opts, crop_limit=None, skip_cropped=False, staged=None, fast=False):
+        pts = vol.create_samples(grid_n, cube_length=_TRI_RK["box_warp"], lo=lo, hi=hi)[0]
+        sigma, _ = oracle.decode(planes.numpy(), pts.numpy(), tuple(m.numpy() for m in mlp), _TRI_RK["box_warp"], plane_mode=int(opts.plane_mode),
+                                 flags=int(opts.flags) & oracle.FLAG_FORCE_SIGMOID, density_only=True)
+        if crop_limit is None:
+            return t(sigma)
+        lim = np.float32(crop_limit)
+        return t(sigma), ((pts[..., 0].abs() > float(lim)) | (pts[..., 2].abs() > float(lim))).reshape(1, -1, 1)
+
+    monkeypatch.setattr(P.ops, "grid_density", grid_density)
+    monkeypatch.setattr(P.ops, "sigma2density", lambda s, cropmask=None, cull=None: t(oracle.sigma2density(
+        s.numpy(), None if cropmask is None else cropmask.numpy(), cull)))
+    gv, gt = T.load_golden("volume_reference.npz"), T.load_golden("syn_triplane_f.npz")
+    G = TriPlaneGenerator(**_TRI_KW)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in gt.items() if k.startswith("sd_")}, strict=True)
+    G.eval()
+    G.set_force_sigmoid(True)
+    N = int(gv["resolution"])
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    try:
+        with torch.no_grad():
+            x = dict(elevations=torch.zeros(1), azimuths=torch.zeros(1), seeds=[3], cond={}, neural_rendering_resolution=8)
+            G.f(x)  # the reference obtains ws the same way (eg3d_metrics3d.py:101-109)
+            ws = x["ws"]
+            plain = vol.density_grid(G, ws, {}, resolution=N)
+            masked = vol.density_grid(G, ws, {}, resolution=N, triplane_crop=0.1, cull_clouds=0.5)
+            pts = vol.create_samples(N, cube_length=0.7)[0]
+            rgb = G.sample_mixed(pts.contiguous(), None, ws, {}, noise_mode="const")["rgb"]
+    finally:
+        P.cameras.cached_view_clear()
+    assert np.array_equal(vol.to_volume(pts, N).numpy(), gv["plain_coordinates"])
+    sig = vol.to_volume(plain["sigmas"], N).numpy()
+    assert sig.shape == gv["plain_sigmas"].shape == (1, 1, N, N, N) and rel(sig, gv["plain_sigmas"]) < 1e-3
+    assert np.abs(vol.to_volume(plain["densities"], N).numpy() - gv["plain_densities"]).max() < 2e-4
+    assert np.abs(vol.to_volume(rgb, N)[:, :3].numpy() - gv["plain_rgb3"]).max() < 2e-3
+    dm, ref = vol.to_volume(masked["densities"], N).numpy(), gv["masked_densities"]
+    same = (dm == -1e3) == (ref == -1e3)
+    assert same.mean() > 0.995 and (ref == -1e3).mean() > 0.5  # thresholded masks: only boundary voxels may flip
+    both = same & (ref != -1e3)
+    assert both.sum() > 10 and np.abs(dm[both] - ref[both]).max() < 2e-4
+
+
+def test_paste_front_host_logic_vs_reference(P, oracle, monkeypatch):
+    """f() with paste_params (generate.py:55-66) on CPU against the reference's paste_front (fixture syn_triplane_f.npz): the rays of
+    the front-occlusion pass (built in one fma from the cached sign / shift tensors), the second renderer pass, the wiring of the
+    masks — with the paste kernel replaced by the torch formulation of the same post-process, the renderer launch by the oracle and
+    the synthesis operators by their PyTorch restatements.  (On the HIP kernels: tests/test_hip_synthesis.py.)"""
+    import torch.nn.functional as F
+    import p3d_torch_ops
+    from panic3d_amd.generator import TriPlaneGenerator
+    from panic3d_amd import paste
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    _oracle_render_op(monkeypatch, P, oracle)
+    monkeypatch.setattr(P.ops, "planes_to_nhwc", lambda planes: planes)
+    seen = {}
+
+    def paste_front_op(weights, xyz, occ, rays_o, rays_d, front, image, tw, te, to, td, bw, normalize_images):
+        S = front.shape[-1]
+        up = lambda t, mode="bilinear": F.interpolate(t, S, mode=mode)
+        wmask = (up(weights) > tw).float()
+        smask = (paste.sobel_magnitude(up(xyz)).norm(2, dim=1, keepdim=True) < te).float()
+        fmask = up((occ < to).float())
+        dmask = (up(paste.xyz_discrepancy(xyz, {"ray_origins": rays_o, "ray_directions": rays_d}), "nearest") < td).float()
+        mask = wmask * smask * fmask * dmask
+        pst = paste.sample_orthofront(front * 2 - 1 if normalize_images else front, up(xyz), bw)
+        seen["occ"] = occ
+        return dict(image=torch.lerp(image, pst, mask), paste=pst, mask=mask, mask_weights=wmask, mask_edges=smask, mask_occ=fmask, mask_dxyz=dmask)
+
+    monkeypatch.setattr(P.ops, "paste_front", paste_front_op)
+    rays = {}
+    real_render = P.ops.render
+
+    def spy_render(planes, rays_o, rays_d, *a, **k):
+        rays.setdefault("calls", []).append((rays_o.clone(), rays_d.clone()))
+        return real_render(planes, rays_o, rays_d, *a, **k)
+
+    monkeypatch.setattr(P.ops, "render", spy_render)
+    g = T.load_golden("syn_triplane_f.npz")
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    G = TriPlaneGenerator(**_TRI_KW)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G.eval()
+    G.set_force_sigmoid(True)
+    G.set_render_exact(True)
+    G._inject_draws = [(tt(g["paste_draw0"]), tt(g["paste_draw1"])), (tt(g["paste_draw2"]), tt(g["paste_draw3"]))]
+    front = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(11))
+    xp = dict(elevations=torch.tensor([0.0]), azimuths=torch.tensor([0.0]), fovs=torch.tensor([-1.0]), seeds=[3],
+              cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16,
+              paste_params={"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5, "offset_occ": 0.01, "thresh_dxyz": 0.05})
+    try:
+        with torch.no_grad():
+            out = G.f(xp)
+    finally:
+        P.cameras.cached_view_clear()
+    assert G._inject_draws == [] and len(rays["calls"]) == 2  # both renderer passes ran
+    # the occlusion pass's rays, bit for bit the reference's construction (triplane.py:565-571)
+    ro = out["image_xyz"] * torch.tensor([-1, 1, -1])[None, :, None, None]
+    ro[:, 2, :, :] -= _TRI_RK["ray_start"] - 0.01
+    rd = torch.zeros_like(out["image_xyz"])
+    rd[:, 2, :, :] = 1
+    flat = lambda t_: t_.permute(0, 2, 3, 1).reshape(1, -1, 3)
+    assert torch.equal(rays["calls"][1][0], flat(ro)) and torch.equal(rays["calls"][1][1], flat(rd))
+    for k in ("mask", "mask_weights", "mask_edges", "mask_occ", "mask_dxyz"):
+        a, b = out["paste"][k].numpy(), g["paste_" + k]
+        assert a.shape == b.shape and (np.abs(a - b) > 1e-3).mean() < 0.01, k  # thresholded masks: <1 % boundary pixels
+    sub = lambda t_: t_[..., ::4, ::4].numpy()
+    assert np.abs(sub(out["paste"]["paste"]) - g["paste_paste_sub4"]).mean() < 2e-3
+    assert np.abs(sub(out["image_prepaste"]) - g["paste_prepaste_sub4"]).mean() < 2e-3
+    assert np.abs(sub(out["image"]) - g["paste_image_sub4"]).mean() < 5e-3
