@@ -685,6 +685,89 @@ def test_density_grid_host_logic_vs_the_references_get_eg3d_volume(P, oracle, mo
     assert both.sum() > 10 and np.abs(dm[both] - ref[both]).max() < 2e-4
 
 
+def _torch_paste_front_op():
+    """ops.paste_front (one fused kernel) as the torch formulation of the same post-process (triplane.py:607-691 with the
+    restated Sobel of paste.py): resizes, masks, sampling of the illustration, lerp."""
+    import torch.nn.functional as F
+    from panic3d_amd import paste
+
+    def paste_front_op(weights, xyz, occ, rays_o, rays_d, front, image, tw, te, to, td, bw, normalize_images):
+        S = front.shape[-1]
+        if len(front) == 1 and len(xyz) > 1:
+            front = front.expand(len(xyz), -1, -1, -1)
+        up = lambda t, mode="bilinear": F.interpolate(t, S, mode=mode)
+        wmask = (up(weights) > tw).float()
+        smask = (paste.sobel_magnitude(up(xyz)).norm(2, dim=1, keepdim=True) < te).float()
+        fmask = up((occ < to).float())
+        dmask = (up(paste.xyz_discrepancy(xyz, {"ray_origins": rays_o, "ray_directions": rays_d}), "nearest") < td).float()
+        mask = wmask * smask * fmask * dmask
+        pst = paste.sample_orthofront(front * 2 - 1 if normalize_images else front, up(xyz), bw)
+        return dict(image=torch.lerp(image, pst, mask), paste=pst, mask=mask, mask_weights=wmask, mask_edges=smask, mask_occ=fmask, mask_dxyz=dmask)
+
+    return paste_front_op
+
+
+def _cpu_generator_env(monkeypatch, P, oracle):
+    """Every device operator TriPlaneGenerator.f reaches, replaced by a CPU stand-in (PyTorch restatements of the synthesis operators,
+    the CPU oracle for the renderer launch and the point decoder, the torch formulation of the paste): what then runs is the host
+    logic of the package, as shipped."""
+    import p3d_torch_ops
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    _oracle_stage_ops(monkeypatch, P, oracle, _TRI_RK["box_warp"])
+    _oracle_render_op(monkeypatch, P, oracle)
+    monkeypatch.setattr(P.ops, "planes_to_nhwc", lambda planes: planes)
+    monkeypatch.setattr(P.ops, "paste_front", _torch_paste_front_op())
+
+
+def _cpu_fixture_generator(g, **over):
+    from panic3d_amd.generator import TriPlaneGenerator
+    G = TriPlaneGenerator(**dict(_TRI_KW, **over))
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G.eval()
+    G.set_force_sigmoid(True)
+    G.set_render_exact(True)
+    return G
+
+
+def test_f_many_views_of_one_subject_in_one_call_host_logic(P, oracle, monkeypatch):
+    """Extension of the dict API, host side: ws / cond of batch 1 with V cameras = ONE backbone pass, ONE renderer call on shared
+    planes with a depth clamp per view, batched super-resolution and paste.  Equal to V separate f() calls on the same ws and draws
+    (CPU stand-ins for every device operator; the same on the HIP kernels: tests/test_hip_synthesis.py)."""
+    _cpu_generator_env(monkeypatch, P, oracle)
+    g = T.load_golden("syn_triplane_f.npz")
+    G = _cpu_fixture_generator(g)
+    V, res, S = 3, 16, 12
+    R = res * res
+    gen = torch.Generator().manual_seed(5)
+    draws = [(torch.rand(V, R, S, 1, generator=gen), torch.rand(V * R, S, generator=gen)) for _ in range(2)]
+    front = torch.rand(1, 3, 512, 512, generator=gen)
+    el, az, fv = torch.tensor([0.0, 10.0, -5.0]), torch.tensor([0.0, 40.0, 200.0]), torch.tensor([-1.0, 30.0, 30.0])
+    common = dict(seeds=[3], cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=res,
+                  noise_mode="const", paste_params={"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5,
+                                                    "offset_occ": 0.01, "thresh_dxyz": 0.05})
+    try:
+        with torch.no_grad():
+            with pytest.raises(RuntimeError):  # this fixture's generator is pose-conditioned: ws would differ per view
+                G.f(dict(common, elevations=el, azimuths=az, fovs=fv))
+            x0 = dict(common, elevations=el[:1], azimuths=az[:1], fovs=fv[:1], paste_params=None)
+            G.f(x0)
+            common["ws"] = x0["ws"]  # one subject: the same ws for every view
+            G._inject_draws = [tuple(d) for d in draws]
+            both = G.f(dict(common, elevations=el, azimuths=az, fovs=fv))
+            assert G._inject_draws == [] and both["image"].shape == (V, 3, 512, 512) and both["triplane"].shape[0] == V
+            for v in range(V):
+                G._inject_draws = [(j[v:v + 1].contiguous(), u[v * R:(v + 1) * R].contiguous()) for j, u in draws]
+                one = G.f(dict(common, elevations=el[v:v + 1], azimuths=az[v:v + 1], fovs=fv[v:v + 1]))
+                for k in ("image_raw", "image_weights", "image_xyz", "image_depth"):  # depth too: one clamp range per view
+                    assert torch.equal(both[k][v:v + 1], one[k]), (k, v)
+                assert (both["image_prepaste"][v:v + 1] - one["image_prepaste"]).abs().max() < 1e-4
+                assert ((both["paste"]["mask"][v:v + 1] - one["paste"]["mask"]).abs() > 1e-3).float().mean() < 1e-3
+                assert (both["image"][v:v + 1] - one["image"]).abs().mean() < 1e-4
+    finally:
+        G._inject_draws = None
+        P.cameras.cached_view_clear()
+
+
 def test_paste_front_host_logic_vs_reference(P, oracle, monkeypatch):
     """f() with paste_params (generate.py:55-66) on CPU against the reference's paste_front (fixture syn_triplane_f.npz): the rays of
     the front-occlusion pass (built in one fma from the cached sign / shift tensors), the second renderer pass, the wiring of the
@@ -697,21 +780,7 @@ def test_paste_front_host_logic_vs_reference(P, oracle, monkeypatch):
     p3d_torch_ops.install(monkeypatch, P.ops)
     _oracle_render_op(monkeypatch, P, oracle)
     monkeypatch.setattr(P.ops, "planes_to_nhwc", lambda planes: planes)
-    seen = {}
-
-    def paste_front_op(weights, xyz, occ, rays_o, rays_d, front, image, tw, te, to, td, bw, normalize_images):
-        S = front.shape[-1]
-        up = lambda t, mode="bilinear": F.interpolate(t, S, mode=mode)
-        wmask = (up(weights) > tw).float()
-        smask = (paste.sobel_magnitude(up(xyz)).norm(2, dim=1, keepdim=True) < te).float()
-        fmask = up((occ < to).float())
-        dmask = (up(paste.xyz_discrepancy(xyz, {"ray_origins": rays_o, "ray_directions": rays_d}), "nearest") < td).float()
-        mask = wmask * smask * fmask * dmask
-        pst = paste.sample_orthofront(front * 2 - 1 if normalize_images else front, up(xyz), bw)
-        seen["occ"] = occ
-        return dict(image=torch.lerp(image, pst, mask), paste=pst, mask=mask, mask_weights=wmask, mask_edges=smask, mask_occ=fmask, mask_dxyz=dmask)
-
-    monkeypatch.setattr(P.ops, "paste_front", paste_front_op)
+    monkeypatch.setattr(P.ops, "paste_front", _torch_paste_front_op())
     rays = {}
     real_render = P.ops.render
 
