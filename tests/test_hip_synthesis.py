@@ -788,172 +788,34 @@ def test_random_noise_from_one_draw_per_pass(hip, monkeypatch):
         assert torch.isfinite(y2).all() and y2.shape[0] == 2
 
 
+# ---- the memo layers in front of a G.f call: the cases live in tests/p3d_memo_cases.py and run here on the HIP kernels, and in
+# tests/test_host_cpu.py on CPU stand-ins of the device operators
+import p3d_memo_cases as MC  # noqa: E402
+
+
 def test_prepared_conditioning_follows_the_conditioning_tensors(hip):
-    """SynthesisNetwork prepares what each level adds from the conditioning images once per set of tensor OBJECTS (and versions) and
-    applies it in place.  A second call with the same tensors reuses it; other tensors of the same shape — also ones that could
-    reuse a freed address — and in-place edits of the same tensors must be noticed: every result equals a network that has never
-    seen another conditioning image."""
-    import copy
-    sg = hip.stylegan2
-    torch.manual_seed(11)
-    net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.reschonk_add_16",
-                              channel_base=4096, channel_max=64, num_fp16_res=0).cuda()
-    ws = torch.randn(1, net.num_ws, 512, device="cuda")
-    mk = lambda: {"image_ortho_front": torch.rand(1, 3, 64, 64, device="cuda"), "resnet_chonk": torch.randn(1, 16, 8, 8, device="cuda")}
-    fresh = lambda cond: copy.deepcopy(net)(ws, cond, noise_mode="const")
-    with torch.no_grad():
-        assert "_cond_cache" not in copy.deepcopy(net).__dict__ or not copy.deepcopy(net).__dict__["_cond_cache"]
-        a = mk()
-        y1 = net(ws, a, noise_mode="const")
-        assert net.__dict__["_cond_cache"]  # something was prepared
-        assert torch.equal(net(ws, a, noise_mode="const"), y1) and torch.equal(fresh(a), y1)
-        for _ in range(3):  # new tensors, the old ones freed in between: addresses may repeat, objects do not
-            del a
-            a = mk()
-            assert torch.equal(net(ws, a, noise_mode="const"), fresh(a))
-        a["image_ortho_front"].mul_(0.5)  # same object, new version
-        y2 = net(ws, a, noise_mode="const")
-        assert torch.equal(y2, fresh(a)) and not torch.equal(y2, y1)
+    MC.prepared_conditioning_follows_the_conditioning_tensors(hip, "cuda")
 
 
 def test_f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed(hip):
-    """generate.py calls f() once per view with the same seeds and conditioning tensors; with a mapping that does not see the
-    camera (c_gen_conditioning_zero, PAniC-3D's default) the second call reuses the first call's ws.  Anything the mapping reads
-    invalidates it: other seeds, truncation, edited / replaced conditioning features, edited mapping weights, a write into the
-    memoised tensors.  A pose-conditioned generator never memoises."""
-    from panic3d_amd.generator import TriPlaneGenerator
-    torch.manual_seed(3)
-    kw = dict(TRI_KW, rendering_kwargs={**TRI_KW["rendering_kwargs"], "c_gen_conditioning_zero": True}, cond_mode="resnetcond_8")
-    G = TriPlaneGenerator(**kw).cuda().eval()
-    G.set_force_sigmoid(True)
-    feats = torch.randn(1, 16, device="cuda")
-    mk = lambda **o: dict(dict(seeds=[4], cond={"resnet_feats": feats}, elevations=torch.zeros(1).cuda(), azimuths=torch.zeros(1).cuda(),
-                               neural_rendering_resolution=16, noise_mode="const", triplane_crop=0.1, cull_clouds=0.5), **o)
-    direct = lambda x: G.mapping_zplus(x["zs"], x["camera_params"], x["cond"])
-    with torch.no_grad():
-        a = mk(); G.f(a)
-        b = mk(azimuths=torch.full((1,), 40.0).cuda()); G.f(b)
-        assert b["ws"] is a["ws"] and torch.equal(b["ws"], direct(b))  # another view of the same subject: reused, and right
-        c = mk(seeds=[5]); G.f(c)
-        assert c["ws"] is not a["ws"] and not torch.equal(c["ws"], a["ws"]) and torch.equal(c["ws"], direct(c))
-        d = mk(seeds=[5]); G.f(d, truncation_psi=0.7)
-        assert d["ws"] is not c["ws"]
-        e = mk(); G.f(e); e2 = mk(); G.f(e2)
-        assert e2["ws"] is e["ws"]
-        feats.add_(torch.randn_like(feats))  # same object, new version (not a pure rescale: the embedding is normalised)
-        f_ = mk(); G.f(f_)
-        assert f_["ws"] is not e["ws"] and torch.equal(f_["ws"], direct(f_)) and not torch.equal(f_["ws"], e["ws"])
-        G.backbone.mapping.fc1.weight.data.mul_(1.01)  # (a .data write does not bump the version: the memo must be dropped by hand ...)
-        G.__dict__.pop("_ws_memo", None)
-        g1 = mk(); G.f(g1)
-        G.backbone.mapping.fc1.weight.mul_(1.01)  # ... an in-place write does
-        g2 = mk(); G.f(g2)
-        assert g2["ws"] is not g1["ws"] and torch.equal(g2["ws"], direct(g2))
-        g2["ws"].add_(1.0)  # a caller scribbles on its ws
-        g3 = mk(); G.f(g3)
-        assert g3["ws"] is not g2["ws"] and torch.equal(g3["ws"], direct(g3))
-    Gp = TriPlaneGenerator(**dict(TRI_KW, cond_mode="resnetcond_8")).cuda().eval()  # pose-conditioned (the fixture's default)
-    with torch.no_grad():
-        p1 = mk(); Gp.f(p1); p2 = mk(); Gp.f(p2)
-    assert p2["ws"] is not p1["ws"] and "_ws_memo" not in Gp.__dict__
+    MC.f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed(hip, "cuda")
 
 
 def test_style_plan_memo_follows_ws_and_parameters(hip):
-    """StylePlan returns the previous call's styles / demodulation coefficients only for the same ws OBJECT at the same version
-    with unchanged parameters; the planes always equal those of a network that has never seen another ws."""
-    import copy
-    sg = hip.stylegan2
-    torch.manual_seed(21)
-    net = sg.SynthesisNetwork(w_dim=512, img_resolution=32, img_channels=96, cond_mode="none", channel_base=2048, channel_max=64, num_fp16_res=0).cuda()
-    fresh = lambda w: copy.deepcopy(net)(w, {}, noise_mode="const")
-    with torch.no_grad():
-        ws = torch.randn(1, net.num_ws, 512, device="cuda")
-        a = net(ws, {}, noise_mode="const")
-        plan = net.__dict__["_style_plan"]
-        m0 = plan._memo
-        assert m0 is not None and m0[0] is ws
-        assert torch.equal(net(ws, {}, noise_mode="const"), a) and plan._memo is m0  # reused
-        ws.mul_(0.5)  # same object, new version
-        b = net(ws, {}, noise_mode="const")
-        assert plan._memo is not m0 and torch.equal(b, fresh(ws)) and not torch.equal(a, b)
-        w2 = ws.clone()  # another object, same values
-        assert torch.equal(net(w2, {}, noise_mode="const"), b) and plan._memo[0] is w2
-        net.b16.conv1.affine.bias.add_(0.25)  # a parameter the plan reads
-        c = net(w2, {}, noise_mode="const")
-        assert torch.equal(c, fresh(w2)) and not torch.equal(c, b)
-        assert "_style_plan" not in copy.deepcopy(net).__dict__  # derived state stays out of copies / pickles
-
-
-def _memo_generator():
-    from panic3d_amd.generator import TriPlaneGenerator
-    torch.manual_seed(5)
-    kw = dict(TRI_KW, rendering_kwargs={**TRI_KW["rendering_kwargs"], "c_gen_conditioning_zero": True},
-              cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.resnetcond_8", channel_base=2048, channel_max=64)
-    G = TriPlaneGenerator(**kw).cuda().eval()
-    G.set_force_sigmoid(True)
-    G.set_render_exact(True)
-    return G
-
-
-def _memo_call(G, cond, seed=4, azim=0.0):
-    jit, u = T.make_random_draws(77, 1, 16 * 16, 12, 12)
-    G._inject_draws = (dev(jit), dev(u))
-    x = dict(seeds=[seed], cond=cond, elevations=torch.zeros(1).cuda(), azimuths=torch.full((1,), float(azim)).cuda(),
-             neural_rendering_resolution=16, noise_mode="const", triplane_crop=0.1, cull_clouds=0.5)
-    with torch.no_grad():
-        return G.f(x)["image"].clone()
+    MC.style_plan_memo_follows_ws_and_parameters(hip, "cuda")
 
 
 @pytest.mark.parametrize("how", ["data", "dlpack"])
 def test_one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(hip, how):
-    """VERDICT r03 item 8.  Five results are memoised in front of a G.f call (latents, StylePlan, prepared conditioning, view
-    cache, channels-last planes), keyed on tensor identity + `_version`.  A write BEHIND the version counter — `t.data.mul_()`, or
-    through a DLPack alias of the storage — is invisible to them: documented as unsupported while memoisation is on (memo.py), with
-    two remedies that this test pins: `G.clear_memo()` after the write, or the single switch (`P3D_NO_MEMO=1` /
-    `memo.set_enabled(False)`), under which every call recomputes.  Ordinary in-place writes are seen either way."""
-    import copy
-    G = _memo_generator()
-    cond = {"image_ortho_front": torch.rand(1, 3, 32, 32, device="cuda"), "resnet_feats": torch.randn(1, 16, device="cuda")}
-    truth = lambda: _memo_call(copy.deepcopy(G), {k: v.clone() for k, v in cond.items()})  # a generator that has never seen anything else
+    MC.one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(hip, how, "cuda")
 
-    def hidden_write(t, factor):
-        if how == "data":
-            t.data.mul_(factor)
-        else:
-            torch.from_dlpack(torch.utils.dlpack.to_dlpack(t)).mul_(factor)  # an alias with a version counter of its own
 
-    assert hip.memo.enabled()
-    a = _memo_call(G, cond)
-    assert torch.equal(a, truth())
-    for t, f in ((cond["image_ortho_front"], 0.5), (G.backbone.mapping.fc1.weight, 1.5), (cond["resnet_feats"], -1.0)):
-        v = t._version
-        hidden_write(t, f)
-        assert t._version == v  # the write the memo layers cannot see
-    stale = _memo_call(G, cond)
-    fresh = truth()
-    assert not torch.equal(fresh, a)            # the writes matter ...
-    assert torch.equal(stale, a)                # ... and with memoisation on they are NOT seen: unsupported, as documented
-    G.clear_memo()                              # remedy 1
-    assert torch.equal(_memo_call(G, cond), fresh)
-    # remedy 2: the switch.  Every call recomputes, so a hidden write is seen by the next call
-    prev = hip.memo.set_enabled(False)
-    try:
-        b = _memo_call(G, cond)
-        assert torch.equal(b, fresh)
-        hidden_write(cond["image_ortho_front"], 0.25)
-        hidden_write(G.backbone.mapping.fc0.weight, 0.5)
-        c = _memo_call(G, cond)
-        assert torch.equal(c, truth()) and not torch.equal(c, b)
-        assert hip.cameras._cached_view.cache_info().currsize == 0
-    finally:
-        hip.memo.set_enabled(prev)
-    # ordinary in-place writes (version bumps) are seen with memoisation on
-    d0 = _memo_call(G, cond)
-    with torch.no_grad():
-        cond["image_ortho_front"].mul_(2.0)
-        G.backbone.mapping.fc1.weight.mul_(0.9)
-    d1 = _memo_call(G, cond)
-    assert torch.equal(d1, truth()) and not torch.equal(d1, d0)
+def _memo_generator():
+    return MC.memo_generator("cuda")
+
+
+def _memo_call(G, cond, seed=4, azim=0.0):
+    return MC.memo_call(G, cond, "cuda", seed=seed, azim=azim)
 
 
 def test_generator_moved_between_devices_keeps_its_domain_watch_and_drops_device_state(hip):
