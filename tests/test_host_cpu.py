@@ -853,3 +853,56 @@ def test_one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen_c
         MC.one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(P, how, "cpu")
     finally:
         P.cameras.cached_view_clear()
+
+
+_GRID_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import panic3d_amd as P
+from panic3d_amd import volume, ops
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+N = {res}
+# stand-ins for the two kernels of the grid query: sigma of grid point i is i (so the gathered grid shows every slab in its place)
+ops.planes_to_nhwc = lambda planes: planes
+def grid_density(planes, grid_n, lo, hi, vs, offsets, mlp, opts, crop_limit=None, skip_cropped=False, staged=None, fast=False):
+    assert grid_n == N and 0 <= lo <= hi <= N ** 3 and lo % (N * N) == 0 and hi % (N * N) == 0  # whole slices of the slowest axis
+    return torch.arange(lo, hi, dtype=torch.float32).reshape(1, -1, 1)
+ops.grid_density = grid_density
+ops.sigma2density = lambda s, cropmask=None, cull=None: s * 2
+class FC:
+    def __init__(self, o, i):
+        self.weight, self.bias, self.weight_gain, self.bias_gain = torch.zeros(o, i), torch.zeros(o), 1.0, 1.0
+class Dec:
+    force_sigmoid = True
+    net = [FC(64, 32), None, FC(33, 64)]
+class G:
+    rendering_kwargs = dict(box_warp=0.7, ray_start=0.5, ray_end=1.5, depth_resolution=12, depth_resolution_importance=12, white_back=True, use_triplane=1)
+    decoder = Dec()
+    renderer = P.ImportanceRenderer(use_triplane=True)
+out = volume.density_grid_sharded(G, torch.zeros(1, 14, 512), {{}}, resolution=N, planes=torch.zeros(1, 3, 32, 8, 8))
+if rank == 0:
+    want = torch.arange(N ** 3, dtype=torch.float32).reshape(1, -1, 1)
+    assert torch.equal(out["sigmas"], want) and torch.equal(out["densities"], want * 2), (out["sigmas"].shape,)
+    print("GRID_OK")
+else:
+    assert out["sigmas"] is None and out["densities"] is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,res,port", [(2, 8, 29561), (3, 2, 29563)])
+def test_density_grid_sharded_gloo(tmp_path, world, res, port):
+    """BASELINE config c5 on N GPUs, host side (volume.density_grid_sharded): contiguous slabs of the slowest grid axis per rank, ONE
+    gather of the sigma / density slabs to rank 0 — at world size 2, and with more ranks than grid slices (an empty slab still joins
+    the gather).  The two kernels of the query are replaced by stand-ins whose output identifies the grid point."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GRID_WORKER.format(root=ROOT, res=res))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GRID_OK" in r.stdout
