@@ -630,16 +630,9 @@ def test_triplane_generator_f_host_logic_vs_reference(P, oracle, monkeypatch, fi
     assert out["image"].shape[1:] == (3, 512, 512) and d.mean() < 2e-3 and d.max() < 0.1, (d.mean(), d.max())
 
 
-def test_density_grid_host_logic_vs_the_references_get_eg3d_volume(P, oracle, monkeypatch):
-    """volume.density_grid / to_volume / create_samples — the host side of `_util/eg3d_metrics3d.py:94-183 get_eg3d_volume` — on CPU
-    against the output of the reference's OWN get_eg3d_volume (tests/golden/volume_reference.npz): the grid query kernel is replaced
-    by create_samples + the oracle's decoder, the activation pass by the oracle's, the backbone operators by their PyTorch
-    restatements.  (On the HIP kernels: tests/test_hip_synthesis.py.)"""
-    import p3d_torch_ops
-    from panic3d_amd.generator import TriPlaneGenerator
-    p3d_torch_ops.install(monkeypatch, P.ops)
-    _oracle_render_op(monkeypatch, P, oracle)
-    _oracle_stage_ops(monkeypatch, P, oracle, _TRI_RK["box_warp"])
+def _oracle_grid_ops(monkeypatch, P, oracle):
+    """The two kernels of the density-grid query replaced by create_samples + the oracle's decoder and the oracle's activation pass;
+    the iso-surface extractor by its C specification (oracle/p3d_oracle_mc.c)."""
     vol = P.volume
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 
@@ -652,9 +645,28 @@ def test_density_grid_host_logic_vs_the_references_get_eg3d_volume(P, oracle, mo
         lim = np.float32(crop_limit)
         return t(sigma), ((pts[..., 0].abs() > float(lim)) | (pts[..., 2].abs() > float(lim))).reshape(1, -1, 1)
 
+    def marching_cubes(v, level, flip0=False, allow_degenerate=True):
+        out = tuple(t(a) for a in oracle.marching_cubes(v.numpy(), level, flip0=flip0))
+        return out if allow_degenerate else P.ops.drop_degenerate_faces(*out)
+
     monkeypatch.setattr(P.ops, "grid_density", grid_density)
     monkeypatch.setattr(P.ops, "sigma2density", lambda s, cropmask=None, cull=None: t(oracle.sigma2density(
         s.numpy(), None if cropmask is None else cropmask.numpy(), cull)))
+    monkeypatch.setattr(P.ops, "marching_cubes", marching_cubes)
+
+
+def test_density_grid_host_logic_vs_the_references_get_eg3d_volume(P, oracle, monkeypatch):
+    """volume.density_grid / to_volume / create_samples — the host side of `_util/eg3d_metrics3d.py:94-183 get_eg3d_volume` — on CPU
+    against the output of the reference's OWN get_eg3d_volume (tests/golden/volume_reference.npz): the grid query kernel is replaced
+    by create_samples + the oracle's decoder, the activation pass by the oracle's, the backbone operators by their PyTorch
+    restatements.  (On the HIP kernels: tests/test_hip_synthesis.py.)"""
+    import p3d_torch_ops
+    from panic3d_amd.generator import TriPlaneGenerator
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    _oracle_render_op(monkeypatch, P, oracle)
+    _oracle_stage_ops(monkeypatch, P, oracle, _TRI_RK["box_warp"])
+    vol = P.volume
+    _oracle_grid_ops(monkeypatch, P, oracle)
     gv, gt = T.load_golden("volume_reference.npz"), T.load_golden("syn_triplane_f.npz")
     G = TriPlaneGenerator(**_TRI_KW)
     G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in gt.items() if k.startswith("sd_")}, strict=True)
@@ -906,3 +918,35 @@ def test_density_grid_sharded_gloo(tmp_path, world, res, port):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GRID_OK" in r.stdout
+
+
+def test_mesh_host_logic_equals_the_references_two_steps(P, oracle, monkeypatch):
+    """volume.mesh (generate.py:97-103 without the volume leaving the device: the UN-flipped flat grid read reversed by the extractor,
+    the colours decoded at exactly the vertices' voxels through create_samples' flat-index arithmetic) against the reference's two
+    steps on the same numbers — get_eg3d_volume's flipped [N,N,N] volume and its full colour grid, then marching_cubes(vol, rgbs)
+    indexing `rgbs[:3, a, b, c]` at `verts.astype(int)` (eg3d_metrics3d.py:166-177,186-210): same vertices, faces and colours.  CPU
+    stand-ins: the oracle's decoder, activation pass and iso-surface specification."""
+    _cpu_generator_env(monkeypatch, P, oracle)
+    _oracle_grid_ops(monkeypatch, P, oracle)
+    vol = P.volume
+    g = T.load_golden("syn_triplane_f.npz")
+    G = _cpu_fixture_generator(g)
+    N = 20
+    try:
+        with torch.no_grad():
+            x = dict(elevations=torch.zeros(1), azimuths=torch.zeros(1), seeds=[3], cond={}, neural_rendering_resolution=8)
+            G.f(x)
+            ws = x["ws"]
+            planes = G._planes(ws, {}, noise_mode="const")
+            dens = vol.density_grid(G, ws, {}, resolution=N, planes=planes)["densities"]
+            level = float(dens.median())  # (a level this random-init volume crosses)
+            fast = vol.mesh(G, ws, {}, resolution=N, level=level, planes=planes)
+            pts = vol.create_samples(N, cube_length=_TRI_RK["box_warp"])[0]
+            rgb = G.renderer.run_model(planes, G.decoder, pts.contiguous(), None, G.rendering_kwargs)["rgb"]
+            two = vol.marching_cubes(vol.to_volume(dens, N)[0, 0].contiguous(), vol.to_volume(rgb, N)[0], _TRI_RK["box_warp"], level=level)
+    finally:
+        P.cameras.cached_view_clear()
+    assert len(fast["faces"]) > 100 and set(fast) == {"verts", "faces", "normals", "values", "colors"}
+    for k in ("verts", "faces", "normals", "values", "colors"):
+        assert fast[k].shape == two[k].shape and np.array_equal(fast[k], two[k]), k
+    assert np.abs(fast["verts"]).max() <= 0.35 + 1e-6 and fast["colors"].shape == (len(fast["verts"]), 3)
