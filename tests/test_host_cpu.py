@@ -950,3 +950,25 @@ def test_mesh_host_logic_equals_the_references_two_steps(P, oracle, monkeypatch)
     for k in ("verts", "faces", "normals", "values", "colors"):
         assert fast[k].shape == two[k].shape and np.array_equal(fast[k], two[k]), k
     assert np.abs(fast["verts"]).max() <= 0.35 + 1e-6 and fast["colors"].shape == (len(fast["verts"]), 3)
+
+
+def test_mapping_zplus_takes_slot_i_of_the_ith_latent(P, oracle, monkeypatch):
+    """TriPlaneGenerator.mapping_zplus (triplane.py:123-143): with one z PER w slot, slot i of the result is slot i of mapping(z_i) —
+    also with resnet features in the conditioning — and the expanded-z shortcut of f() (one z for every slot) equals the general path."""
+    _cpu_generator_env(monkeypatch, P, oracle)
+    from panic3d_amd.generator import TriPlaneGenerator
+    torch.manual_seed(9)
+    G = TriPlaneGenerator(**dict(_TRI_KW, cond_mode="resnetcond_8")).eval()
+    n = G.backbone.num_ws
+    zs, c = torch.randn(2, n, 512), torch.randn(2, 25)
+    cond = {"resnet_feats": torch.randn(2, 16)}
+    with torch.no_grad():
+        got = G.mapping_zplus(zs, c, cond, truncation_psi=0.8)
+        for i in range(n):
+            want = G.mapping(zs[:, i], c, cond, truncation_psi=0.8)[:, i]
+            assert float((got[:, i] - want).abs().max()) < 1e-5, i
+        one = torch.randn(2, 512)
+        fast = G.mapping_zplus(one[:, None, :].expand(-1, n, -1), c, cond)
+        slow = G.mapping_zplus(one[:, None, :].repeat(1, n, 1), c, cond)
+        # (another batch size goes through another blocking of the same fp32 GEMM: round-off, not bits)
+        assert float((fast - slow).abs().max()) < 1e-5 and fast.shape == (2, n, 512), float((fast - slow).abs().max())
