@@ -301,8 +301,41 @@ def volume_case():
     save("volume_reference.npz", resolution=np.array(N), **out)
 
 
+def injection_case():
+    """SynthesisNetwork.forward with latent_injection (da_<lvl> added to x, db_<lvl> to img after a block and its conditioning,
+    networks_stylegan2.py:700-705) and with stop_level (the image of an inner level up-sampled to the output size, :707-714), on
+    the generators of syn_generator_none.npz and syn_generator_cond.npz (weights and inputs are read from those fixtures; this one
+    stores the injected tensors and the reference's outputs)."""
+    out = {}
+    for tag, cond_mode in COND_MODES[:2]:
+        g = dict(np.load(os.path.join(HERE, f"syn_generator_{tag}.npz")))
+        G = ns.Generator(cond_mode=cond_mode, **GEN_KW).eval()
+        G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+        cond = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+        ws = torch.from_numpy(g["ws"])
+        assert np.abs(G.synthesis(ws, cond, noise_mode="const").numpy() - g["img"]).max() < 1e-5  # the fixture's generator, rebuilt
+        gg = torch.Generator().manual_seed(91)
+        _, loc = G.synthesis(ws, cond, noise_mode="const", return_more=True)
+        inj = {}
+        for lvl, (x, img) in enumerate(loc["ximgs"]):
+            if lvl in (0, 2):
+                inj[f"da_{lvl}"] = torch.randn(x.shape, generator=gg) * 0.3
+            if lvl in (1, 2):
+                inj[f"db_{lvl}"] = torch.randn(img.shape, generator=gg) * 0.3
+        sub = lambda t: t[:, ::4, ::2, ::2].contiguous().numpy()  # (a quarter of the channels, every second pixel: 49 KB per output)
+        out[f"{tag}_inj_checksum"] = np.array([float(sum(v.double().sum() for v in inj.values()))])  # the test re-draws them from the seed
+        out[f"{tag}_img_inj"] = sub(G.synthesis(ws, cond, latent_injection=inj, noise_mode="const"))
+        for sl in (0, 2):
+            out[f"{tag}_img_stop{sl}"] = sub(G.synthesis(ws, cond, stop_level=sl, noise_mode="const"))
+        out[f"{tag}_img_inj_stop1"] = sub(G.synthesis(ws, cond, latent_injection=inj, stop_level=1, noise_mode="const"))
+    save("syn_generator_inject.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["inject"]:  # only the fixture added at the end of round 4
+        injection_case()
+        sys.exit(0)
     which = sys.argv[1:] or ["layers", "generator", "triplane"]
     if "layers" in which:
         layer_cases()

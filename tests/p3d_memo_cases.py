@@ -185,3 +185,44 @@ def one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(hip, h
         G.backbone.mapping.fc1.weight.mul_(0.9)
     d1 = memo_call(G, cond, device)
     assert torch.equal(d1, truth()) and not torch.equal(d1, d0)
+
+
+# ---- latent injection / stop_level of the backbone (networks_stylegan2.py:700-714), against the reference -----------------------
+GEN_KW = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+
+
+def latent_injection_and_stop_level_vs_reference(hip, tag, device):
+    """SynthesisNetwork.forward with latent_injection (da_<lvl> added to x and db_<lvl> to img after a block and its conditioning) and
+    with stop_level (an inner level's image up-sampled to the output size), alone and together, against the REFERENCE's outputs
+    (tests/golden/syn_generator_inject.npz; the generators of syn_generator_none / _cond).  The injected tensors are re-drawn from
+    the fixture's seed in the fixture's order and checked against its checksum."""
+    sg = hip.stylegan2
+    g, gi = T.load_golden(f"syn_generator_{tag}.npz"), T.load_golden("syn_generator_inject.npz")
+    G = sg.Generator(cond_mode=str(g["cond_mode"]), **GEN_KW)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G = G.to(device).eval()
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    cond = {k[5:]: tt(v) for k, v in g.items() if k.startswith("cond_") and k != "cond_mode"}
+    ws = tt(g["ws"])
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    sub = lambda t: t[:, ::4, ::2, ::2].cpu().numpy()
+    with torch.no_grad():
+        _, more = G.synthesis(ws, cond, noise_mode="const", return_more=True)
+        gg, inj = torch.Generator().manual_seed(91), {}
+        for lvl, (x, img) in enumerate(more["ximgs"]):
+            if lvl in (0, 2):
+                inj[f"da_{lvl}"] = torch.randn(tuple(x.shape), generator=gg) * 0.3
+            if lvl in (1, 2):
+                inj[f"db_{lvl}"] = torch.randn(tuple(img.shape), generator=gg) * 0.3
+        assert abs(float(sum(v.double().sum() for v in inj.values())) - float(gi[f"{tag}_inj_checksum"][0])) < 1e-6
+        inj = {k: v.to(device) for k, v in inj.items()}
+        plain = G.synthesis(ws, cond, noise_mode="const")
+        out = G.synthesis(ws, cond, latent_injection=inj, noise_mode="const")
+        assert rel(sub(out), gi[f"{tag}_img_inj"]) < 1e-4 and rel(sub(out), sub(plain)) > 1e-2  # right, and the injection matters
+        for sl in (0, 2):
+            o = G.synthesis(ws, cond, stop_level=sl, noise_mode="const")
+            assert o.shape == plain.shape and rel(sub(o), gi[f"{tag}_img_stop{sl}"]) < 1e-4, sl
+        o = G.synthesis(ws, cond, latent_injection=inj, stop_level=1, noise_mode="const")
+        assert rel(sub(o), gi[f"{tag}_img_inj_stop1"]) < 1e-4
+        assert rel(sub(G.synthesis(ws, cond, noise_mode="const")), sub(plain)) == 0.0  # (nothing of the injected passes is remembered)

@@ -810,6 +810,11 @@ def test_one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(h
     MC.one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(hip, how, "cuda")
 
 
+@pytest.mark.parametrize("tag", ["none", "cond"])
+def test_latent_injection_and_stop_level_vs_reference(hip, tag):
+    MC.latent_injection_and_stop_level_vs_reference(hip, tag, "cuda")
+
+
 def _memo_generator():
     return MC.memo_generator("cuda")
 

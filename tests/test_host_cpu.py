@@ -972,3 +972,10 @@ def test_mapping_zplus_takes_slot_i_of_the_ith_latent(P, oracle, monkeypatch):
         slow = G.mapping_zplus(one[:, None, :].repeat(1, n, 1), c, cond)
         # (another batch size goes through another blocking of the same fp32 GEMM: round-off, not bits)
         assert float((fast - slow).abs().max()) < 1e-5 and fast.shape == (2, n, 512), float((fast - slow).abs().max())
+
+
+@pytest.mark.parametrize("tag", ["none", "cond"])
+def test_latent_injection_and_stop_level_vs_reference_cpu(P, oracle, monkeypatch, tag):
+    import p3d_memo_cases as MC
+    _cpu_generator_env(monkeypatch, P, oracle)
+    MC.latent_injection_and_stop_level_vs_reference(P, tag, "cpu")
