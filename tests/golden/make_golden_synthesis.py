@@ -301,6 +301,55 @@ def volume_case():
     save("volume_reference.npz", resolution=np.array(N), **out)
 
 
+def triplane_options_case():
+    """TriPlaneGenerator.f with the options the other fixtures leave at their defaults, on the generator of syn_triplane_f.npz (its
+    weights are read from that fixture): one z PER w slot (x['zs']), truncation with a cutoff, latent injection given both ways (the
+    argument and x['latent_injection'], merged: dw / dws on the ws, da_<lvl> / db_<lvl> inside the backbone), stop_level,
+    binarize_clouds instead of cull_clouds, normalize_images=True.  The two draws of the renderer are captured and stored."""
+    from training.triplane import TriPlaneGenerator
+    g = dict(np.load(os.path.join(HERE, "syn_triplane_f.npz")))
+    G = TriPlaneGenerator(**TRI_KW).eval()
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}, strict=True)
+    G.set_force_sigmoid(True)
+    gg = torch.Generator().manual_seed(31)
+    n = G.backbone.num_ws
+    zs = torch.randn(1, n, 512, generator=gg)
+    _, loc = G.backbone.synthesis(torch.zeros(1, n, 512), {}, noise_mode="const", return_more=True)
+    x1, img2 = loc["ximgs"][1][0], loc["ximgs"][2][1]
+    inj_arg = {"dw": torch.randn(1, 1, 512, generator=gg) * 0.2, "da_1": torch.randn(x1.shape, generator=gg) * 0.3}
+    inj_x = {"dws": torch.randn(1, n, 512, generator=gg) * 0.1, "db_2": torch.randn(img2.shape, generator=gg) * 0.3}
+    rec = {}
+    o_rl, o_r = torch.rand_like, torch.rand
+
+    def rand_like(t, *a, **k):
+        r = o_rl(t, *a, **k)
+        rec.setdefault("jitter", r.clone())
+        return r
+
+    def rand(*a, **k):
+        r = o_r(*a, **k)
+        rec.setdefault("u", r.clone())
+        return r
+
+    x = dict(elevations=torch.tensor([12.0]), azimuths=torch.tensor([-50.0]), fovs=torch.tensor([25.0]), distances=torch.tensor([1.1]),
+             zs=zs, cond={}, triplane_crop=0.08, binarize_clouds=0.4, neural_rendering_resolution=16, normalize_images=True,
+             latent_injection=inj_x)
+    torch.rand_like, torch.rand = rand_like, rand
+    try:
+        torch.manual_seed(12)
+        out = G.f(x, truncation_psi=0.7, truncation_cutoff=6, latent_injection=inj_arg, stop_level=2)
+    finally:
+        torch.rand_like, torch.rand = o_rl, o_r
+    arrs = {k: out[k].numpy() for k in ("image_raw", "image_depth", "image_weights", "image_xyz")}
+    arrs["triplane_sub"] = out["triplane"][:, :, ::4].contiguous().numpy()
+    arrs["image_sub4"] = out["image"][..., ::4, ::4].contiguous().numpy()
+    arrs.update(jitter=rec["jitter"].numpy(), u=rec["u"].numpy(), ws=x["ws"].numpy(), camera_params=x["camera_params"].numpy(), zs=zs.numpy())
+    arrs.update({"injarg_" + k: v.numpy() for k, v in inj_arg.items()})
+    arrs.update({"injx_" + k: v.numpy() for k, v in inj_x.items()})
+    print("options fixture: weights mean %.3f, image range [%.2f, %.2f]" % (float(out["image_weights"].mean()), float(out["image"].min()), float(out["image"].max())))
+    save("syn_triplane_f_options.npz", **arrs)
+
+
 def injection_case():
     """SynthesisNetwork.forward with latent_injection (da_<lvl> added to x, db_<lvl> to img after a block and its conditioning,
     networks_stylegan2.py:700-705) and with stop_level (the image of an inner level up-sampled to the output size, :707-714), on
@@ -333,8 +382,11 @@ def injection_case():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if sys.argv[1:] == ["inject"]:  # only the fixture added at the end of round 4
+    if sys.argv[1:] == ["inject"]:  # only the fixtures added at the end of round 4
         injection_case()
+        sys.exit(0)
+    if sys.argv[1:] == ["options"]:
+        triplane_options_case()
         sys.exit(0)
     which = sys.argv[1:] or ["layers", "generator", "triplane"]
     if "layers" in which:

@@ -226,3 +226,40 @@ def latent_injection_and_stop_level_vs_reference(hip, tag, device):
         o = G.synthesis(ws, cond, latent_injection=inj, stop_level=1, noise_mode="const")
         assert rel(sub(o), gi[f"{tag}_img_inj_stop1"]) < 1e-4
         assert rel(sub(G.synthesis(ws, cond, noise_mode="const")), sub(plain)) == 0.0  # (nothing of the injected passes is remembered)
+
+
+def f_options_vs_reference(hip, device):
+    """TriPlaneGenerator.f with the options the other fixtures leave at their defaults — one z per w slot (x['zs']), truncation with a
+    cutoff, latent injection given both ways and merged (dw / dws on the ws, da_<lvl> / db_<lvl> inside the backbone), stop_level,
+    binarize_clouds, distances, normalize_images=True — against the REFERENCE's own G.f (tests/golden/syn_triplane_f_options.npz, the
+    generator of syn_triplane_f.npz)."""
+    from panic3d_amd.generator import TriPlaneGenerator
+    gw, g = T.load_golden("syn_triplane_f.npz"), T.load_golden("syn_triplane_f_options.npz")
+    G = TriPlaneGenerator(**TRI_KW)
+    G.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(v) for k, v in gw.items() if k.startswith("sd_")}, strict=True)
+    G = G.to(device).eval()
+    G.set_force_sigmoid(True)
+    G.set_render_exact(True)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    G._inject_draws = (tt(g["jitter"]), tt(g["u"]))
+    inj_arg = {k[7:]: tt(v) for k, v in g.items() if k.startswith("injarg_")}
+    inj_x = {k[5:]: tt(v) for k, v in g.items() if k.startswith("injx_")}
+    x = dict(elevations=tt(np.float32([12.0])), azimuths=tt(np.float32([-50.0])), fovs=tt(np.float32([25.0])), distances=tt(np.float32([1.1])),
+             zs=tt(g["zs"]), cond={}, triplane_crop=0.08, binarize_clouds=0.4, neural_rendering_resolution=16, normalize_images=True,
+             latent_injection=inj_x)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    try:
+        with torch.no_grad():
+            out = G.f(x, truncation_psi=0.7, truncation_cutoff=6, latent_injection=inj_arg, stop_level=2)
+    finally:
+        G._inject_draws = None
+        hip.cameras.cached_view_clear()
+    assert out["normalize_images"] is True
+    assert np.abs(x["camera_params"].cpu().numpy() - g["camera_params"]).max() < 1e-6
+    assert np.abs(x["ws"].cpu().numpy() - g["ws"]).max() < 1e-5
+    assert rel(out["triplane"][:, :, ::4].cpu().numpy(), g["triplane_sub"]) < 1e-4
+    for k, tol in (("image_raw", 2e-3), ("image_weights", 2e-3), ("image_xyz", 2e-3)):
+        d = np.abs(out[k].cpu().numpy() - g[k])
+        assert d.max() < 20 * tol and d.mean() < tol, (k, d.max(), d.mean())
+    d = np.abs(out["image"][..., ::4, ::4].cpu().numpy() - g["image_sub4"])
+    assert out["image"].shape == (1, 3, 512, 512) and d.mean() < 4e-3 and d.max() < 0.2, (d.mean(), d.max())

@@ -815,6 +815,10 @@ def test_latent_injection_and_stop_level_vs_reference(hip, tag):
     MC.latent_injection_and_stop_level_vs_reference(hip, tag, "cuda")
 
 
+def test_f_options_vs_reference(hip):
+    MC.f_options_vs_reference(hip, "cuda")
+
+
 def _memo_generator():
     return MC.memo_generator("cuda")
 

@@ -979,3 +979,9 @@ def test_latent_injection_and_stop_level_vs_reference_cpu(P, oracle, monkeypatch
     import p3d_memo_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.latent_injection_and_stop_level_vs_reference(P, tag, "cpu")
+
+
+def test_f_options_vs_reference_cpu(P, oracle, monkeypatch):
+    import p3d_memo_cases as MC
+    _cpu_generator_env(monkeypatch, P, oracle)
+    MC.f_options_vs_reference(P, "cpu")
