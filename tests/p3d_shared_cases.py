@@ -1,5 +1,6 @@
-"""Host-logic cases of the memo layers in front of a G.f call — written once, run twice: on the HIP kernels (tests/test_hip_synthesis.py,
-device "cuda") and on CPU with every device operator replaced by a stand-in (tests/test_host_cpu.py, device "cpu").  `hip` is the
+"""Test cases written once and run twice: on the HIP kernels (tests/test_hip_synthesis.py, device "cuda") and on CPU with every
+device operator replaced by a stand-in (tests/test_host_cpu.py, device "cpu") — the memo layers in front of a G.f call, latent
+injection / stop_level of the backbone, and G.f with the options the other fixtures leave at their defaults.  `hip` is the
 panic3d_amd module."""
 import numpy as np
 import pytest

@@ -788,9 +788,9 @@ def test_random_noise_from_one_draw_per_pass(hip, monkeypatch):
         assert torch.isfinite(y2).all() and y2.shape[0] == 2
 
 
-# ---- the memo layers in front of a G.f call: the cases live in tests/p3d_memo_cases.py and run here on the HIP kernels, and in
+# ---- the memo layers in front of a G.f call: the cases live in tests/p3d_shared_cases.py and run here on the HIP kernels, and in
 # tests/test_host_cpu.py on CPU stand-ins of the device operators
-import p3d_memo_cases as MC  # noqa: E402
+import p3d_shared_cases as MC  # noqa: E402
 
 
 def test_prepared_conditioning_follows_the_conditioning_tensors(hip):

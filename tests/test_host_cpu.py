@@ -835,21 +835,21 @@ def test_paste_front_host_logic_vs_reference(P, oracle, monkeypatch):
     assert np.abs(sub(out["image"]) - g["paste_image_sub4"]).mean() < 5e-3
 
 
-# ---- the memo layers in front of a G.f call (tests/p3d_memo_cases.py; the same cases run on the HIP kernels in tests/test_hip_synthesis.py) ----
+# ---- the memo layers in front of a G.f call (tests/p3d_shared_cases.py; the same cases run on the HIP kernels in tests/test_hip_synthesis.py) ----
 def test_prepared_conditioning_follows_the_conditioning_tensors_cpu(P, oracle, monkeypatch):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.prepared_conditioning_follows_the_conditioning_tensors(P, "cpu")
 
 
 def test_style_plan_memo_follows_ws_and_parameters_cpu(P, oracle, monkeypatch):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.style_plan_memo_follows_ws_and_parameters(P, "cpu")
 
 
 def test_f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed_cpu(P, oracle, monkeypatch):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     try:
         MC.f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed(P, "cpu")
@@ -859,7 +859,7 @@ def test_f_memoises_ws_only_while_nothing_the_mapping_reads_has_changed_cpu(P, o
 
 @pytest.mark.parametrize("how", ["data", "dlpack"])
 def test_one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen_cpu(P, oracle, monkeypatch, how):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     try:
         MC.one_switch_turns_every_memo_layer_off_and_hidden_writes_are_then_seen(P, how, "cpu")
@@ -976,12 +976,12 @@ def test_mapping_zplus_takes_slot_i_of_the_ith_latent(P, oracle, monkeypatch):
 
 @pytest.mark.parametrize("tag", ["none", "cond"])
 def test_latent_injection_and_stop_level_vs_reference_cpu(P, oracle, monkeypatch, tag):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.latent_injection_and_stop_level_vs_reference(P, tag, "cpu")
 
 
 def test_f_options_vs_reference_cpu(P, oracle, monkeypatch):
-    import p3d_memo_cases as MC
+    import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.f_options_vs_reference(P, "cpu")
