@@ -50,6 +50,20 @@ def render_source_hash():
     return h.hexdigest()[:16]
 
 
+SYNTHESIS_UNIT = ["p3d_synthesis.hip", os.path.join("..", "..", "include", "panic3d_hip.h")]
+
+
+def synthesis_source_hash():
+    """sha256[:16] over the translation unit of the convolution kernels (p3d_synthesis.hip and what it includes): the key of a
+    recorded MFMA-utilisation capture (profiles/*_mfma_util.json), like render_source_hash() for the renderer's counters."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SYNTHESIS_UNIT):
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def built_hash(so=SO):
     """The source hash a library was compiled from (embedded by build() as -DP3D_SRC_HASH in p3d_build_info's string), or None.
     Read from the FILE, not through dlopen: a library loaded here to ask it would stay mapped under its path, and the dlopen that

@@ -189,3 +189,103 @@ def fill_generator_params(G, seed):
         G.decoder.net[2].weight[0] *= 20.0
         G.decoder.net[2].bias[0] = 25.0
     return G
+
+
+# ---- index-level parity against the REFERENCE at BASELINE scale (tests/golden/bench_reference_block.npz) -------------------------
+REF_TOL = dict(feat=1e-4, depth=2e-5, wsum=3e-5, xyz=1e-4)  # the tolerances of tests/ vs the reference
+
+
+def reference_index_report(z, key, ours, outputs, tol=REF_TOL, max_detail=16):
+    """"`inds` and sort permutation: exact-match count = 100 % or reported mismatch count with cause".
+
+    z = the loaded bench_reference_block.npz (the REFERENCE's own searchsorted indices, sort permutation, mask bits, fine depths and
+    its lists of draws / samples that sit next to a decision boundary: tests/golden/make_golden_bench.py); key = 'surface' (48+48)
+    or 'surface96'; ours = dict(inds, perm, depths_coarse, depths_fine, sigma_coarse, sigma_fine) of THIS implementation on the
+    same rays and draws (numpy; sigma after the masks); outputs = (feat, depth, wsum, xyz).
+
+    Every mismatch is attributed to a cause measured on the reference's side:
+      inds      the draw's u lies within `near_ulps` float32 ulps of an edge of the reference's own cdf (two fp32 evaluation
+                orders of the same cdf round an edge differently);
+      perm      the two depths the reference ordered differ by no more than this implementation's deviation from the
+                reference's fine depths (or tie exactly: torch.sort is not stable);
+      mask      the reference's own opacity is within `near_thr_abs` of the cull threshold, or |x|,|z| within `near_ulps` ulps of
+                the crop limit.
+    and every ray whose outputs differ by more than the tolerance must contain an attributed inds mismatch or mask flip."""
+    p = key + "_"
+    Sc, Sf = int(z[p + "Sc"]), int(z[p + "Sf"])
+    R = int(z["side"]) ** 2
+    rep = {"rays": R, "Sc": Sc, "Sf": Sf}
+    # -- searchsorted indices
+    ref_inds = z[p + "inds"].astype(np.int64)
+    my_inds = np.asarray(ours["inds"]).reshape(R, Sf).astype(np.int64)
+    near = {int(i): (int(k), float(u)) for i, k, u in zip(z[p + "near_edge_index"], z[p + "near_edge_k"], z[p + "near_edge_ulps"])}
+    bad = np.argwhere(my_inds != ref_inds)
+    det, bad_rays, unexplained = [], set(), 0
+    for r, i in bad:
+        ent = near.get(int(r) * Sf + int(i))
+        ok = ent is not None and abs(int(my_inds[r, i]) - int(ref_inds[r, i])) == 1
+        unexplained += not ok
+        if ok:
+            bad_rays.add(int(r))
+        if len(det) < max_detail:
+            det.append({"ray": int(r), "draw": int(i), "ours": int(my_inds[r, i]), "reference": int(ref_inds[r, i]),
+                        "u_ulps_to_reference_cdf_edge": None if ent is None else abs(ent[1]), "explained": bool(ok)})
+    rep.update(inds_total=R * Sf, inds_mismatch=int(len(bad)), inds_unexplained=int(unexplained), inds_mismatch_detail=det)
+    # -- sort permutation
+    ref_perm = z[p + "perm"].astype(np.int64)
+    my_perm = np.asarray(ours["perm"]).reshape(R, Sc + Sf).astype(np.int64)
+    dc = np.asarray(ours["depths_coarse"], np.float32).reshape(R, Sc)
+    d_ref = np.concatenate([dc, z[p + "depths_fine"]], 1)  # coarse depths are bit-identical to the reference's (test_hip_parity.py)
+    d_my = np.concatenate([dc, np.asarray(ours["depths_fine"], np.float32).reshape(R, Sf)], 1)
+    dev = np.abs(d_my.astype(np.float64) - d_ref)
+    pb = np.argwhere(my_perm != ref_perm)
+    worst, punexp = 0.0, 0
+    for r, j in pb:
+        a, b = ref_perm[r, j], my_perm[r, j]
+        gap = abs(float(d_ref[r, a]) - float(d_ref[r, b]))
+        worst = max(worst, gap / float(np.spacing(np.float32(d_ref[r, a]))))
+        punexp += not (gap <= dev[r, a] + dev[r, b] + 1e-12)
+    rep.update(perm_total=R * (Sc + Sf), perm_mismatch=int(len(pb)), perm_mismatch_rays=int(len({int(r) for r, _ in pb})),
+               perm_unexplained=int(punexp), perm_max_gap_ulps=worst,
+               fine_depth_max_abs_dev=float(np.abs(d_my[:, Sc:].astype(np.float64) - d_ref[:, Sc:]).max()) if Sf else 0.0)
+    # -- crop / cull decisions
+    thr, lim = float(z[p + "cull_thresh"]), float(z[p + "crop_limit"])
+    near_thr = {(int(ps), int(i)): (float(a), float(s)) for ps, i, a, s in
+                zip(z[p + "near_thr_pass"], z[p + "near_thr_index"], z[p + "near_thr_alpha"], z[p + "near_thr_sigma"])}
+    near_crop = {(int(ps), int(i)): [float(x) for x in v] for ps, i, v in zip(z[p + "near_crop_pass"], z[p + "near_crop_index"], z[p + "near_crop_abs"])}
+    flips, fdet, funexp = 0, [], 0
+    for ps, (name, S) in enumerate((("coarse", Sc), ("fine", Sf))):
+        ref_m = np.unpackbits(z[p + "masked_" + name], axis=1)[:, :S].astype(bool)
+        my_m = np.asarray(ours["sigma_" + name]).reshape(R, S) == -1000.0
+        for r, i in np.argwhere(ref_m != my_m):
+            flips += 1
+            k = (ps, int(r) * S + int(i))
+            e = {"ray": int(r), "pass": name, "sample": int(i), "masked_here": bool(my_m[r, i]), "masked_in_reference": bool(ref_m[r, i])}
+            if k in near_thr:
+                a, s = near_thr[k]
+                e.update(cause="cull threshold", reference_alpha=a, reference_sigma=s, alpha_abs_to_threshold=abs(a - thr),
+                         alpha_ulps_to_threshold=abs(a - thr) / float(np.spacing(np.float32(thr))))
+            elif k in near_crop:
+                e.update(cause="crop limit", reference_abs_xz=near_crop[k],
+                         ulps_to_limit=min(abs(x - lim) for x in near_crop[k]) / float(np.spacing(np.float32(lim))))
+            else:
+                e.update(cause=None)
+                funexp += 1
+            if e["cause"]:
+                bad_rays.add(int(r))
+            if len(fdet) < max_detail:
+                fdet.append(e)
+    rep.update(mask_total=R * (Sc + Sf), mask_flips=int(flips), mask_unexplained=int(funexp), mask_flip_detail=fdet)
+    # -- outputs
+    beyond = np.zeros(R, bool)
+    for name, g in zip(("feat", "depth", "wsum", "xyz"), outputs):
+        want = z[p + name]
+        err = np.abs(np.asarray(g).reshape(want.shape) - want).reshape(R, -1).max(-1)
+        rep["max_abs_" + name] = float(err.max())
+        rep["median_abs_" + name] = float(np.median(err))
+        beyond |= err > tol[name]
+    rep["rays_beyond_tolerance"] = int(beyond.sum())
+    rep["rays_beyond_tolerance_unexplained"] = int(sum(int(r) not in bad_rays for r in np.flatnonzero(beyond)))
+    rep["rays_with_attributed_cause"] = sorted(bad_rays)[:256]
+    rep["all_explained"] = bool(unexplained == 0 and punexp == 0 and funexp == 0 and rep["rays_beyond_tolerance_unexplained"] == 0)
+    return rep

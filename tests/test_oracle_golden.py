@@ -135,3 +135,32 @@ def test_contract_math_accuracy(oracle):
     assert sv[0] == 0 and sv[2] == 1 and np.isinf(sv[3]) and np.isnan(sv[4]) and sv[5] == 0
     assert abs(float(sv[1]) / np.exp(-87.5) - 1) < 1e-5  # gradual underflow through ldexp (subnormal result)
     assert oracle.math_fn("softplus", np.array([25.0], np.float32))[0] == 25.0
+
+
+# the index-level record at BASELINE scale ("exact-match count = 100 % or reported mismatch count with cause"): the
+# REFERENCE's own searchsorted indices, sort permutation and mask bits on the 64x64 block of bench.py's frame.  The counts are
+# pinned — they are properties of (reference build, contract), the HIP path equals the oracle bit for bit — and every mismatch
+# must be attributed to a decision boundary measured on the reference's side (p3d_testing.reference_index_report).
+BENCH_BLOCK_COUNTS = {"surface": dict(inds_mismatch=1, perm_mismatch=4, mask_flips=1, rays_beyond_tolerance=1),
+                      "surface96": dict(inds_mismatch=0, perm_mismatch=12, mask_flips=0, rays_beyond_tolerance=0)}
+
+
+@pytest.mark.parametrize("key", ["surface", "surface96"])
+def test_bench_block_index_parity_with_cause(oracle, key):
+    z = T.load_golden("bench_reference_block.npz")
+    planes, raw = T.make_bench_scene("surface")
+    assert T.checksum(planes) == str(z["planes_checksum"])
+    Sc, Sf, side = int(z[key + "_Sc"]), int(z[key + "_Sf"]), int(z["side"])
+    jit, u = T.make_random_draws(int(z["seed"]), 1, side * side, Sc, Sf)
+    f, d, w, x, dm = oracle.render(planes, z[key + "_rays_o"], z[key + "_rays_d"], jit, u, oracle.prescale_mlp(*raw),
+                                   oracle.make_opts(T.bench_rendering_kwargs(Sc, Sf), **T.BENCH_KW), dumps=True)
+    rep = T.reference_index_report(z, key, dm, (f, d, w, x))
+    assert rep["all_explained"], rep
+    for k, v in BENCH_BLOCK_COUNTS[key].items():
+        assert rep[k] == v, (k, rep[k], v)
+    assert rep["inds_total"] == side * side * Sf and rep["perm_max_gap_ulps"] <= 2.0
+    if key == "surface":  # the one index: u EQUALS an edge of the reference's cdf (searchsorted right=True), ours is 1 ulp above
+        e = rep["inds_mismatch_detail"][0]
+        assert (e["ray"], e["draw"], e["ours"], e["reference"]) == (1506, 43, 32, 33) and e["u_ulps_to_reference_cdf_edge"] <= 1.0
+        m = rep["mask_flip_detail"][0]  # the one flip: the reference's own opacity is 1.1e-4 from the threshold (sigma = -45 + 46)
+        assert (m["ray"], m["pass"], m["cause"]) == (564, "fine", "cull threshold") and m["alpha_abs_to_threshold"] < 2e-4
