@@ -218,18 +218,24 @@ P3D_DEV f32x16 p3d_fold_taps(const float wg[12], LOAD load) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) f[c] = p3d_fma(w4[c >> 2], v[c], f[c]);
         }
-        if (k == 3) X = f;
-        if (k == 7) {
+        // pin the partial sums here: without it the compiler sinks all the arithmetic below the last load (sched_barrier only
+        // orders machine instructions that already sit on either side of it) and every tap stays live.  At the end of a plane the
+        // value that lives on is X, so X is what gets pinned and f simply dies there (pinning f AFTER `X = f` made f a modified
+        // copy of X: 16 v_mov per plane, 48 of a decode step's ~1600 vector instructions in the round-4 ISA).
+        if (k == 3) {
+            p3d_pin16(f);
+            X = f;
+        } else if (k == 7) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) X[c] = X[c] + f[c];
-        }
-        if (k == 11) {
+            p3d_pin16(X);
+        } else if (k == 11) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) X[c] = (X[c] + f[c]) * P3D_THIRD;  // triplane.py:530 mean(1)
+            p3d_pin16(X);
+        } else {
+            p3d_pin16(f);
         }
-        // pin the partial sums here: without it the compiler sinks all the arithmetic below the last load (sched_barrier only
-        // orders machine instructions that already sit on either side of it) and every tap stays live
-        p3d_pin16(f);
         __builtin_amdgcn_sched_barrier(0);
         if (k + P3D_GATHER_DEPTH < 12) tap[k % P3D_GATHER_DEPTH] = load(k + P3D_GATHER_DEPTH);
     }

@@ -1455,7 +1455,10 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
 // all lanes of the ray, the 16 colour channels only towards slot 0, whose lanes write the outputs.  Bit-identical to k_render.
 // =====================================================================================================================
 template <int NF, bool FAST>
-__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 2) void k_render_quad(RenderParams p) {  // two waves per SIMD: <= 256 registers
+// Registers: the tolerance-mode instantiations are compiled for two waves per SIMD (<= 256 registers; 128^2 rays = 2048 waves).  The
+// EXACT ones are compiled for one (512): under the 256-register cap they spilled 108-127 VGPRs (164-176 B of scratch per lane, round 4),
+// and the host picks the exact quad kernel only for launches of <= 8192 rays = <= 1024 waves — one per SIMD whatever the cap.
+__global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_quad(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
     if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
