@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 7  /* 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
+#define P3D_ABI_VERSION 8  /* 8: p3d_conv_takes_image, the convolution workspace must be 256-byte aligned; 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -205,7 +205,10 @@ int p3d_unify_perm_f32(const float* depths_coarse, const float* depths_fine, int
  * demod_coefs: NULL, or the [N][O] coefficients already computed by p3d_demod_coefs_f32 (then no per-call reduction over the
  * weights is launched); ignored unless demodulate.
  * Alignment: x, w, styles, noise, bias and y need only their natural 4-byte alignment (an offset view is fine); when up = 2 and
- * y / noise happen to be 16-byte aligned the FIR pass stores four outputs at a time, otherwise one by one — same values. */
+ * y / noise happen to be 16-byte aligned the FIR pass stores four outputs at a time, otherwise one by one — same values.
+ * The WORKSPACE must start on a 256-byte boundary (hipMalloc and torch allocations do; a sub-allocator must keep it): its regions are
+ * carved by rounding up from the base, and p3d_modconv2d_workspace_bytes budgets for an aligned base (P3D_E_RANGE otherwise).  The
+ * query's answer for a shape is fixed for the life of the process (the environment switches that select kernels are read once). */
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up);
 int p3d_modconv2d_f32(const float* x, int N, int I, int H, int W, const float* w, int O, int ks, const float* styles,
                       int demodulate, const float* demod_coefs, const float* noise, int noise_per_sample, const float* bias,
@@ -281,10 +284,14 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
  * writes it from its FIR + bias_act pass when p3d_conv_args.y_img / y_img_styles (the NEXT layer's styles) are set and y is null; a
  * plain 3x3 layer (up = 1) given y_img writes it NEXT TO y (from the convolution's own epilogue where the pipelined kernel runs
  * unsplit, by one more pass otherwise) — the up-sampling layer of the next block reads it, ToRGB reads y.  Consumers (two-term
- * operands, demod_coefs given, x and styles unused): a plain 3x3 layer with W >= 32, an up-sampling layer with W >= 32 and
- * O % 32 == 0 (P3D_E_RANGE otherwise), both staging with buffer_load ... lds alone.  The pieces are bit for bit what the layer
+ * operands, demod_coefs given, x and styles unused; P3D_E_RANGE otherwise), both staging with buffer_load ... lds alone:
+ *   a plain 3x3 layer (up = 1)   with I % 16 == 0 and W >= 32;
+ *   an up-sampling layer (up = 2) with I % 16 == 0, O % 32 == 0 and W >= P3D_UP3_MIN_W (4; the environment variable of that name
+ *                                 overrides it, P3D_NO_UP3 in the environment disables the kernel — both read once per process).
+ * p3d_conv_takes_image(I, O, W, up) returns 1 exactly when the library accepts x_img for that layer: bind THAT, not a copy of the rule.  The pieces are bit for bit what the layer
  * computes itself from the fp32 tensor, so results do not change.  p3d_act_to_image_f32 builds one from an fp32 tensor (styles may
  * be null = 1).  |16 s x| > 65504: clamped, *saturated |= 1, as in p3d_modconv2d_f16x2mma_f32. */
+int p3d_conv_takes_image(int I, int O, int W, int up);
 size_t p3d_act_image_bytes(int N, int C, int H, int W);
 int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int H, int W, void* img, uint32_t* saturated, void* stream);
 

@@ -13,7 +13,7 @@ P3D_FLAG_DISPARITY = 4096
 P3D_FLAG_PAIR16 = 16384
 P3D_FLAG_QUAD8 = 32768
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 7  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 8  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "p3d_conv_weights_to_f16x2": (_I, [_P, _I, _I, _I, _P, _P]),
     "p3d_modconv2d_f16x2mma_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _Z, _P, _P]),
     "p3d_modconv2d_ex_f32": (_I, [C.POINTER(ConvArgs), _P]),
+    "p3d_conv_takes_image": (_I, [_I, _I, _I, _I]),
     "p3d_act_image_bytes": (_Z, [_I, _I, _I, _I]),
     "p3d_act_to_image_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "p3d_torgb_weights_f32": (_I, [_P, _I, _I, _P, _P]),

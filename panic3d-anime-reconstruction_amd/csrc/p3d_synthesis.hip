@@ -23,6 +23,8 @@
 
 #include "../../include/panic3d_hip.h"
 
+static bool env_no_w3();  // (defined with the other read-once environment switches, above up3_applies)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DEV __device__ __forceinline__
@@ -2341,7 +2343,7 @@ static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
     if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
         dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (p.ximg && p.O % 64 == 0 && !getenv("P3D_NO_W3")) hipLaunchKernelGGL(k_modconv_w3, gw, dim3(256), 0, st, p);
+        if (p.ximg && p.O % 64 == 0 && !env_no_w3()) hipLaunchKernelGGL(k_modconv_w3, gw, dim3(256), 0, st, p);
         else if (p.ximg) hipLaunchKernelGGL(k_modconv_w2<true>, gw, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_w2<false>, gw, dim3(256), 0, st, p);
         return;
@@ -2383,7 +2385,11 @@ static int up3_min_w() {  // (P3D_UP3_MIN_W in the environment: A/B runs)
     static const int v = getenv("P3D_UP3_MIN_W") ? atoi(getenv("P3D_UP3_MIN_W")) : P3D_UP3_MIN_W;
     return v;
 }
-static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= up3_min_w() && !getenv("P3D_NO_UP3"); }
+// The kernel-selection switches of the environment (A/B runs) are read ONCE per process: what p3d_modconv2d_workspace_bytes
+// answered for a shape stays the size the launch of that shape needs (a caller may cache the query).
+static bool env_no_up3() { static const bool v = getenv("P3D_NO_UP3") != nullptr; return v; }
+static bool env_no_w3() { static const bool v = getenv("P3D_NO_W3") != nullptr; return v; }
+static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= up3_min_w() && !env_no_up3(); }
 static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
     int ks = 1;
@@ -2412,6 +2418,14 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     return b + 256;
 }
 
+// the rule by which an image-consuming layer is accepted (p3d_conv_args.x_img): exported so that a binding cannot drift from it
+int p3d_conv_takes_image(int I, int O, int W, int up) {
+    if (I <= 0 || O <= 0 || W <= 0 || I % 16 != 0) return 0;
+    if (up == 1) return W >= WX_TW ? 1 : 0;
+    if (up == 2) return up3_applies(I, O, W) ? 1 : 0;
+    return 0;
+}
+
 static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int wsplit, int O, int ks,
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
@@ -2434,6 +2448,9 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     if (!((ks == 3 && (up == 1 || up == 2)) || (ks == 1 && up == 1))) return P3D_E_RANGE;
     if (up == 2 && !fir) return P3D_E_ARG;
     if (workspace_bytes < p3d_modconv2d_workspace_bytes(N, I, O, H, W, up)) return P3D_E_WORKSPACE;
+    // the carve-up below rounds its regions to 256 bytes from the BASE: the budget of the query holds for a 256-byte aligned base
+    // (hipMalloc and torch allocations are); anything else is refused rather than written past
+    if ((uintptr_t)workspace & 255) return P3D_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
     float* dco = (float*)workspace;
     float* tmp = dco + (((size_t)N * O + 63) / 64) * 64;
@@ -2454,7 +2471,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     // An fp32 input of a layer the pipelined kernel can run (O % 64 == 0) is first turned into the image that kernel stages from
     // (one pass, 8 bytes per value; the generator's blocks hand over images and never come here): ONE kernel does the arithmetic
     // of a layer whichever way its input arrives, so both ways give the same bits.
-    if ((up3 && !ximg) || (wide && !ximg && O % 64 == 0 && I % 16 == 0 && !getenv("P3D_NO_W3"))) {
+    if ((up3 && !ximg) || (wide && !ximg && O % 64 == 0 && I % 16 == 0 && !env_no_w3())) {
         char* img = (char*)(part + (ksplit > 1 ? ((size_t)ksplit * out_elems + 63) / 64 * 64 : 0));
         img = (char*)(((uintptr_t)img + 255) & ~(uintptr_t)255);
         const long long tot = (long long)N * (I / 8) * H * W;
@@ -2469,7 +2486,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     static const bool xcd_order = !getenv("P3D_NO_XCD_ORDER");  // (A/B runs)
     p.xcd = xcd_order ? 1 : 0;
     // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
-    const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !getenv("P3D_NO_W3");
+    const bool w3_img = up == 1 && yimg && wide && ximg && O % 64 == 0 && ksplit == 1 && !env_no_w3();
     // up = 2 into an image, unsplit, few input channels: the FIR pass and the epilogue run inside k_modconv_up3<true> (no
     // intermediate).  Measured (tools/conv_layers_time.py, us): 32 -> 256 @128^2 -> 256^2 71 -> 56; 256 -> 128 @256^2 -> 512^2 240 -> 254:
     // with a long K loop the filter's VALU work (76 us chip-wide) and the 1.42 x MFMA work of the overlapping tiles cost more than

@@ -390,6 +390,15 @@ class TriPlaneGenerator(torch.nn.Module):
             return False
         return any([ops.conv_domain_violated(w, reset) for w in list(flags.words.values())])  # (a list: every device's word is read and reset)
 
+    def set_noise_pool(self, state):
+        """noise_mode='random' of THIS generator's backbone and super-resolution: True = one pooled draw per pass, False = the reference's
+        call-for-call torch.randn sequence (seed-compatible with it), None = the process default (stylegan2.NOISE_POOL)."""
+        for net in (self.backbone.synthesis, self.superresolution):
+            for m in net.modules():
+                if isinstance(m, stylegan2.SynthesisNetwork):
+                    m.__dict__["noise_pool"] = None if state is None else bool(state)
+        return state
+
     def clear_memo(self):
         """Drop everything this generator remembers between calls — the memoised latents, both StylePlans (styles and the
         parameter-derived tables), the prepared conditioning, the cached planes and their channels-last copy, every layer's derived

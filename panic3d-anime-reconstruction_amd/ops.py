@@ -719,12 +719,23 @@ class ActImage:
         return v.permute(0, 1, 4, 2, 3).reshape(N, C, H, W).contiguous()
 
 
-UP_IMAGE_MIN_W = int(os.environ.get("P3D_UP3_MIN_W", "4"))  # (the library reads the same variable: csrc/p3d_synthesis.hip up3_min_w)
+_TAKES_IMAGE = {}
+
+
+def takes_image(I, O, W, up):
+    """The LIBRARY's rule for when a 3x3 layer with these sizes stages its input from an ActImage (p3d_conv_takes_image: k_modconv_w3 for
+    up = 1, k_modconv_up3 for up = 2) — asked, not restated, so that the host's choice of hand-overs and the library's acceptance of
+    x_img cannot drift apart; fixed for the life of the process, hence memoised."""
+    key = (int(I), int(O), int(W), int(up))
+    r = _TAKES_IMAGE.get(key)
+    if r is None:
+        r = _TAKES_IMAGE[key] = bool(_lib.lib().p3d_conv_takes_image(*key))
+    return r
 
 
 def takes_image_up(I, O, W):
     """An up-sampling 3x3 layer with these sizes stages its input from an ActImage (k_modconv_up3)."""
-    return I % 16 == 0 and O % 32 == 0 and W >= UP_IMAGE_MIN_W and not os.environ.get("P3D_NO_UP3")
+    return takes_image(I, O, W, 2)
 
 
 def act_to_image(x, styles=None, saturated=None):
@@ -756,7 +767,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     ximg = x if isinstance(x, ActImage) else None
     if ximg is not None:
         if up == 2 and not takes_image_up(ximg.shape[1], weight.shape[0], ximg.shape[3]):
-            raise RuntimeError("modulated_conv2d: an up-sampling layer stages from an ActImage only with I % 16 == 0, O % 32 == 0 and W >= UP_IMAGE_MIN_W")
+            raise RuntimeError("modulated_conv2d: the library does not stage this up-sampling layer from an ActImage (p3d_conv_takes_image: I % 16 == 0, O % 32 == 0, W >= P3D_UP3_MIN_W)")
         if weight_f16 is None or weight_f16.ndim != 4 or (demodulate and dcoef is None):
             raise RuntimeError("modulated_conv2d: an ActImage input needs two-term weights (conv_weights_to_f16(split=True)) and precomputed dcoef")
         x = None

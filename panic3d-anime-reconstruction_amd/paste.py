@@ -17,7 +17,9 @@ import torch.nn.functional as F
 
 
 def sobel_magnitude(x, eps=1e-6):
-    """3x3 Sobel gradient magnitude, kernels / 8, replicate padding.  Written with shifted slices: on ROCm a 1-channel
+    """3x3 Sobel gradient magnitude, kernels / 8, replicate padding — a restatement of kornia.filters.sobel's published definition,
+    PARITY UNPINNED against kornia itself (absent here: tests/golden/make_golden_sobel.py + test_sobel_against_kornia wait for a box
+    that has it).  Written with shifted slices: on ROCm a 1-channel
     F.conv2d of a 512^2 image goes through MIOpen and costs ~150 ms per call, the slices ~0.1 ms."""
     xp = F.pad(x, [1, 1, 1, 1], mode="replicate")
     tl, tc, tr = xp[..., :-2, :-2], xp[..., :-2, 1:-1], xp[..., :-2, 2:]

@@ -11,10 +11,31 @@ import torch
 import torch.distributed as dist
 
 # RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails with "invalid argument" otherwise), and the HSA
-# runtime reads the variable when it initialises — i.e. at the first HIP call of the process, long after this import.  Set here for
-# EVERY way a rank can come to life (an external torch.distributed.run, ensure_ranks' own re-exec, a test's subprocess); a value the
-# user exported wins.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# runtime reads HSA_ENABLE_IPC_MODE_LEGACY when it initialises — at the first HIP call of the process.  The variable is therefore set
+# only where RANKS come to life (not for every importer of the package — a single-process user keeps the runtime's
+# default IPC mode, e.g. for torch.multiprocessing tensor sharing):
+#   * a process that a launcher started as a rank (RANK and MASTER_ADDR in its environment: torch.distributed.run, the driver's
+#     form, ensure_ranks' own re-exec) gets it here, at import, which precedes any HIP call this package makes;
+#   * ensure_ranks puts it into the environment of the ranks it starts;
+#   * a rank whose HIP runtime was initialised without it is TOLD so when it first touches the collective (_check_ipc_env) instead of
+#     failing later inside RCCL with "invalid argument".  A value the user exported always wins.
+def _is_launched_rank():
+    return "RANK" in os.environ and "MASTER_ADDR" in os.environ
+
+
+if _is_launched_rank():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _check_ipc_env():
+    """Called where a multi-rank RCCL group is first used: the IPC mode cannot be changed any more (HIP is up), so say what to do."""
+    if (dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() > 1
+            and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") is None):
+        import warnings
+        warnings.warn("panic3d_amd.sharding: HSA_ENABLE_IPC_MODE_LEGACY is not set in this rank's environment; on this driver RCCL between "
+                      "processes needs HSA_ENABLE_IPC_MODE_LEGACY=0 BEFORE the first HIP call (export it, start the ranks through "
+                      "sharding.ensure_ranks / torch.distributed.run, or import panic3d_amd before initialising torch.cuda in a launched rank)",
+                      RuntimeWarning, stacklevel=3)
 
 
 def ensure_ranks(gpus, argv=None):
@@ -81,6 +102,7 @@ def _ensure_communicator(device):
     operation of a group — ranks without frames skip the P2P batch, so one tiny group-wide all_reduce goes first (once per process)."""
     key = (dist.get_backend(), dist.get_world_size())
     if key not in _COMM_READY:
+        _check_ipc_env()
         dist.all_reduce(torch.zeros(1, device=device))
         _COMM_READY.add(key)
 
@@ -144,6 +166,7 @@ class FrameGather:
         # then the maximum over ranks, which is also the group-wide collective that has to precede the first P2P batch
         want = os.environ.get("P3D_GATHER_P2P", "0") == "1" or (self.active and dist.get_backend() not in ("nccl", "gloo"))
         if self.active and (self.world > 1 or self.force):
+            _check_ipc_env()
             flag = torch.tensor([1.0 if want else 0.0], device=local.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             want = bool(flag.item() > 0)

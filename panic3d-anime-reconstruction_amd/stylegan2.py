@@ -125,9 +125,20 @@ CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
 # (the pass timings of tools/bench_backbone.py, graph_backbone.py, profile_backbone.py are taken that way).
 STYLE_MEMO = os.environ.get("P3D_STYLE_MEMO", "1") != "0"
 IMG_MIN_RES = 32
-# noise_mode='random': one draw per pass for all layers (NoisePool) instead of one per layer.  P3D_NOISE_POOL=0: the reference's
-# call-for-call sequence of torch.randn calls.
+# noise_mode='random': one draw per pass for all layers (NoisePool) instead of one per layer.  The pool consumes the device generator
+# in ONE randn call per pass, so under a fixed torch seed the noise VALUES differ from the reference's call-for-call sequence (same
+# distribution; INTEGRATION.md "seed compatibility").  Switches, all read at call time: P3D_NOISE_POOL=0 in the environment (the
+# default for the process), set_noise_pool(False) (the process, at run time), `net.noise_pool = False` on a SynthesisNetwork /
+# TriPlaneGenerator.set_noise_pool(False) (one network) — then every layer calls torch.randn itself, in the reference's order
+# (networks_stylegan2.py:342), and a seeded run reproduces the reference's draws (tests/test_host_cpu.py).
 NOISE_POOL = os.environ.get("P3D_NOISE_POOL", "1") != "0"
+
+
+def set_noise_pool(state):
+    """Process-wide default of the pooled random noise (see NOISE_POOL); returns the previous value."""
+    global NOISE_POOL
+    prev, NOISE_POOL = NOISE_POOL, bool(state)
+    return prev
 
 
 def _takes_image(layer, res):
@@ -628,7 +639,8 @@ class SynthesisNetwork(_CacheFree):
             plan = StylePlan(plan_entries([(f"b{res}", getattr(self, f"b{res}")) for res in self.block_resolutions], starts))
             self.__dict__["_style_plan"] = plan
         pre = plan(ws, memo_of=ws)  # every layer's styles + demodulation coefficients: one GEMM + three small launches
-        if block_kwargs.get("noise_mode", "random") == "random" and NOISE_POOL:  # all layers' random noise of this pass: two launches
+        use_pool = self.__dict__.get("noise_pool")  # per-network override (None: the process default)
+        if block_kwargs.get("noise_mode", "random") == "random" and (NOISE_POOL if use_pool is None else use_pool):  # all layers' random noise of this pass: two launches
             pool = self.__dict__.get("_noise_pool")
             if pool is None:
                 blocks = [getattr(self, f"b{res}") for res in self.block_resolutions]

@@ -95,7 +95,9 @@ def marching_cubes(vol, rgbs, boxwarp, level=0.5, flip0=False, allow_degenerate=
     vol [n,n,n] (device tensor; numpy is uploaded), rgbs: [>=3,n,n,n] tensor indexed like the reference does
     (`rgbs[:3, a, b, c]` at `verts.astype(int)`), or a callable `rgbs(ijk[V,3] long) -> [V,3]`, or None.
     Returns the reference's dict (verts scaled by /n*bw - bw/2 as eg3d_metrics3d.py:201-202 — sic, n not n-1; numpy
-    arrays).  The triangulation is this repo's, not Lewiner's.  allow_degenerate=False is what the reference
+    arrays).  The triangulation is this repo's, not Lewiner's: PARITY UNPINNED against skimage (absent here; the
+    fixture generator tests/golden/make_golden_mesh.py and tests/test_mcubes_cpu.py::test_triangulation_against_skimage_lewiner are
+    ready for a box that has it).  allow_degenerate=False is what the reference
     passes to skimage (eg3d_metrics3d.py:189-194): zero-area triangles (a grid value exactly on the level) are removed."""
     if not torch.is_tensor(vol):
         vol = torch.as_tensor(np.ascontiguousarray(vol, dtype=np.float32)).cuda()

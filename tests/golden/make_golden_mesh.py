@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""Fixtures that would PIN the two third-party semantics this repo restates without a reference run:
+"""The fixture that would PIN the iso-surface triangulation this repo restates without a reference run:
 
-  * skimage.measure.marching_cubes(vol, level, method='lewiner', gradient_direction='descent')   (_util/eg3d_metrics3d.py:186-210)
-  * kornia.filters.sobel (kornia 0.6.5)                                                           (training/triplane.py:632,652)
+    skimage.measure.marching_cubes(vol, level, method='lewiner', gradient_direction='descent')   (_util/eg3d_metrics3d.py:186-210)
 
-Neither package is installed in the build container and `pip install scikit-image kornia==0.6.5` has no index to talk to
-(profiles/history/r02_notes.txt records the attempt), so this script is the generator to run in an environment that has them:
+scikit-image is not installed in the build container and cannot be (no package index), so this is the generator to run in an
+environment that has it (the reference pins scikit-image 0.19: _env/Dockerfile):
 
-    python tests/golden/make_golden_mesh.py        -> tests/golden/mesh_lewiner_{64,128}.npz, tests/golden/sobel_kornia.npz
+    python tests/golden/make_golden_mesh.py        -> tests/golden/mesh_lewiner_{64,128}.npz
 
-tests/test_mcubes_cpu.py / tests/test_hip_synthesis.py pick the files up when they exist (vertex-set equality up to order,
-surface area and Hausdorff distance of the meshes; Sobel magnitude on random images to 1e-6).  Until then both rows stay
-"parity unpinned" (oracle/p3d_oracle_mc.c and paste.py say so)."""
+It FAILS (exit code 2, instructions on stderr) where scikit-image is missing — it never writes a fixture from anything else.
+tests/test_mcubes_cpu.py::test_triangulation_against_skimage_lewiner compares oracle/p3d_oracle_mc.c (which the HIP kernel equals bit
+for bit: tests/test_hip_mcubes.py) with the fixture when it exists; where skimage IS importable and the fixture is not there, that
+test FAILS with the command above instead of skipping; with neither, it skips and the row stays "parity unpinned"
+(oracle/p3d_oracle_mc.c, volume.marching_cubes and the bench line's config.workload say so).  The Sobel filter of the paste has its own
+generator: tests/golden/make_golden_sobel.py."""
 import os
 import sys
 
@@ -32,32 +34,18 @@ def volumes():
 
 
 def main():
-    missing = []
     try:
+        import skimage
         from skimage import measure
     except ImportError:
-        measure = None
-        missing.append("scikit-image")
-    try:
-        import torch
-        import kornia
-    except ImportError:
-        kornia = None
-        missing.append("kornia==0.6.5")
-    if measure is not None:
-        for n, vol in volumes().items():
-            v, f, nrm, val = measure.marching_cubes(vol, 0.5, spacing=(1, 1, 1), gradient_direction="descent", method="lewiner")
-            np.savez_compressed(os.path.join(HERE, f"mesh_lewiner_{n}.npz"), vol_seed=n, verts=v, faces=f, normals=nrm, values=val)
-            print(f"mesh_lewiner_{n}.npz: {len(v)} vertices, {len(f)} faces")
-    if kornia is not None:
-        g = torch.Generator().manual_seed(0)
-        x = torch.rand(2, 3, 64, 64, generator=g)
-        np.savez_compressed(os.path.join(HERE, "sobel_kornia.npz"), x=x.numpy(), sobel=kornia.filters.sobel(x).numpy(),
-                            kornia_version=str(kornia.__version__))
-        print("sobel_kornia.npz written with kornia", kornia.__version__)
-    if missing:
-        print("not importable here:", ", ".join(missing), "-> those fixtures were NOT generated (parity stays unpinned)")
-        return 1
+        sys.stderr.write("make_golden_mesh.py: scikit-image is not importable here — nothing written, the triangulation stays UNPINNED.\n"
+                         "Run this script where `pip install scikit-image==0.19.*` is possible and commit tests/golden/mesh_lewiner_*.npz.\n")
+        return 2
+    for n, vol in volumes().items():
+        v, f, nrm, val = measure.marching_cubes(vol, 0.5, spacing=(1, 1, 1), gradient_direction="descent", method="lewiner")
+        np.savez_compressed(os.path.join(HERE, f"mesh_lewiner_{n}.npz"), vol_seed=n, verts=v, faces=f, normals=nrm, values=val,
+                            skimage_version=str(skimage.__version__))
+        print(f"mesh_lewiner_{n}.npz: {len(v)} vertices, {len(f)} faces (scikit-image {skimage.__version__})")
     return 0
 
 

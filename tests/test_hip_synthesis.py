@@ -780,6 +780,18 @@ def test_random_noise_from_one_draw_per_pass(hip, monkeypatch):
         torch.manual_seed(3)
         y_calls = net(ws, {}, noise_mode="random")  # one randn per layer, as networks_stylegan2.py:342
         assert torch.isfinite(y_calls).all() and not torch.equal(y_calls, y_none)
+        # ... and it IS the reference's sequence: one torch.randn([N,1,res,res]) per layer in execution order (seed compatibility
+        # with a call-for-call run on the same device); the per-network switch does the same with the process default back on
+        torch.manual_seed(3)
+        for l in layers:
+            l.noise_const.copy_(torch.randn([1, 1, l.resolution, l.resolution], device="cuda")[0, 0])
+        assert torch.equal(net(ws, {}, noise_mode="const"), y_calls) and not torch.equal(y_calls, y_rand)
+        monkeypatch.setattr(sg, "NOISE_POOL", True)
+        net.noise_pool = False
+        torch.manual_seed(3)
+        assert torch.equal(net(ws, {}, noise_mode="random"), y_calls)
+        net.noise_pool = None
+        monkeypatch.setattr(sg, "NOISE_POOL", False)
         assert float((y_calls - y_none).abs().mean()) == pytest.approx(float((y_rand - y_none).abs().mean()), rel=0.5)
         # batch 2: per-sample noise, every sample its own slice
         ws2 = torch.randn(2, net.num_ws, 512, device="cuda")

@@ -231,6 +231,20 @@ def test_bench_gpus_flag_starts_its_own_ranks_dry_launch():
     import json
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_ranks_seen"] == 2 and line["world_size"] == 2 and "itself" in line["launcher"]
+    # ... and the dry launch runs the SAME timed-sweep code as the GPU run (bench.timed_sweep) over stand-in frames: the multi-GPU
+    # fields of the contract line are there — ranks seen, per-rank render ms, per-rank exposed gather ms, what moved into rank 0 —
+    # and every rank's frames arrived in rank order
+    assert len(line["per_rank"]["ms_per_step_render"]) == 2 and len(line["per_rank"]["gather_ms"]) == 2
+    g = line["gather"]
+    assert g["mode"].startswith("streamed") and g["content_ok"] is True and g["frames_per_rank"] == line["steps"] * line["views_per_step"]
+    assert g["bytes_into_rank0"] == g["frames_per_rank"] * g["frame_bytes"] and g["exposed_ms_max"] >= g["exposed_ms_rank0"] >= 0
+    # V views per launch, one gather at the end, three ranks with an odd step count
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-launch", "--steps", "5", "--warmup", "1",
+                        "--views-per-step", "4", "--gather", "end"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_ranks_seen"] == 3 and line["views_per_step"] == 4 and line["gather"]["mode"].startswith("end")
+    assert line["gather"]["content_ok"] is True and line["gather"]["frames_per_rank"] == 20 and len(line["per_rank"]["gather_ms"]) == 3
     # under a launcher the world size must match --gpus: a 3-rank launch of `--gpus 2` refuses to run
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
                         "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
@@ -985,3 +999,70 @@ def test_f_options_vs_reference_cpu(P, oracle, monkeypatch):
     import p3d_shared_cases as MC
     _cpu_generator_env(monkeypatch, P, oracle)
     MC.f_options_vs_reference(P, "cpu")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/_train/eg3dc/src"), reason="needs the reference tree")
+def test_noise_pool_off_reproduces_the_references_random_draws(P, monkeypatch):
+    """with the pooled noise switched off (P3D_NOISE_POOL=0 / stylegan2.set_noise_pool(False) / net.noise_pool = False) every
+    layer calls torch.randn itself in the reference's order (networks_stylegan2.py:342), so under the same torch seed the backbone with
+    noise_mode='random' — what generate.py's G.f calls run — reproduces the REFERENCE's planes; with the pool on (the default) the
+    same seed gives other noise values (one randn call per pass): same distribution, not the same stream."""
+    import types
+    import p3d_torch_ops
+    sg = P.stylegan2
+    os.environ.setdefault("PROJECT_DN", "/root/reference")
+    os.environ.setdefault("PROJECT_NAME", "x")
+    added = ["/root/reference", "/root/reference/_train/eg3dc/src"]
+    sys.path[:0] = [added[0]]
+    sys.path.append(added[1])
+    sys.modules.setdefault("kornia", types.ModuleType("kornia"))
+    try:
+        from training.networks_stylegan2 import Generator as RefGenerator
+    finally:
+        for p_ in added:
+            sys.path.remove(p_)
+    p3d_torch_ops.install(monkeypatch, P.ops)
+    g = T.load_golden("syn_generator_none.npz")
+    kw = dict(z_dim=64, c_dim=25, w_dim=64, img_resolution=32, img_channels=96, mapping_kwargs={"num_layers": 2},
+              channel_base=2048, channel_max=64, num_fp16_res=0, conv_clamp=None, fused_modconv_default="inference_only")
+    sd = {k[3:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd_")}
+    ours, ref = sg.Generator(cond_mode="none", **kw).eval(), RefGenerator(cond_mode="none", **kw).eval()
+    ours.load_state_dict(sd, strict=True)
+    ref.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        for G in (ours, ref):  # the fixture's noise strengths may be zero: make the random noise matter
+            for n, p_ in G.named_parameters():
+                if n.endswith("noise_strength"):
+                    p_.fill_(0.3)
+        ws = torch.from_numpy(g["ws_psi1"])
+        torch.manual_seed(11)
+        want = ref.synthesis(ws, {}, noise_mode="random")
+        torch.manual_seed(12)
+        other = ref.synthesis(ws, {}, noise_mode="random")
+        assert float((want - other).abs().max()) > 1e-2  # the noise is visible in the planes
+        prev = sg.set_noise_pool(False)  # the process-wide switch
+        try:
+            torch.manual_seed(11)
+            got = ours.synthesis(ws, {}, noise_mode="random")
+        finally:
+            sg.set_noise_pool(prev)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) < 2e-5 * scale  # the reference's draws, call for call
+        ours.synthesis.noise_pool = False  # the per-network switch, with the process default back on
+        torch.manual_seed(11)
+        assert torch.equal(ours.synthesis(ws, {}, noise_mode="random"), got)
+        ours.synthesis.noise_pool = None
+        # (with the pool ON the CPU generator happens to give the same values too — its normal sampler works in blocks of 16 and every
+        #  layer's count is a multiple of 16, so one randn(total) equals the layers' consecutive calls; the device generator (Philox,
+        #  offset per call) does not have that property: tests/test_hip_synthesis.py checks there that the two modes differ)
+
+
+def test_sobel_against_kornia(P):
+    """f4: kornia.filters.sobel (training/triplane.py:632,652; kornia 0.6.5) vs paste.sobel_magnitude on the inputs of
+    tests/golden/make_golden_sobel.py — compared when the fixture exists; FAILS with the generating command where kornia is importable
+    and the fixture is not committed; skips (row stays UNPINNED) where neither is there."""
+    from test_mcubes_cpu import _third_party_fixture
+    (z,) = _third_party_fixture(["sobel_kornia.npz"], "kornia", "make_golden_sobel.py")
+    from panic3d_amd import paste
+    got = paste.sobel_magnitude(torch.from_numpy(z["x"]))
+    assert got.shape == z["sobel"].shape and float((got - torch.from_numpy(z["sobel"])).abs().max()) < 1e-6, str(z["kornia_version"])
