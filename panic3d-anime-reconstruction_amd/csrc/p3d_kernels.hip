@@ -303,6 +303,7 @@ struct RenderParams {
     int rng;          // p3d_render_rng_f32: the two draws come from the counter-based generator of include/p3d_numerics.h
     uint32_t seed_lo, seed_hi;
     int swz;          // XCD swizzle run length (blocks)
+    int blocked;      // k_render: tiles ordered by 16 x 16-tile super-tiles, one per XCD run (see the kernel)
     P3dDecodeCfg cfg;
 };
 
@@ -541,7 +542,11 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, TCG)) void k_
     long long bs = b;
     if (b < full) {
         long long slot = b >> 3, x = b & 7;  // slot-th block of XCD x
-        bs = (slot / swz) * (8 * swz) + x * swz + (slot % swz);
+        // p.blocked (round 5): a run is one 16 x 16-tile SUPER-TILE (below); XCD x takes element (x + g) % 8 of group g of eight runs,
+        // so that over its runs it visits every column of super-tiles (the subject sits in the middle columns: a fixed column per
+        // XCD would leave the XCDs of the outer columns idle early)
+        const long long g = slot / swz, xr = p.blocked ? ((x + g) & 7) : x;
+        bs = g * (8 * swz) + xr * swz + (slot % swz);
     }
     const int nwaves = blockDim.x >> 6;
     long long tile = bs * nwaves + wave;
@@ -553,6 +558,18 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, P3D_NF_OCC(NF, TCG)) void k_
     long long r;
     if (p.tile_w > 0) {
         long long ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
+        if (p.blocked) {
+            // Blocked tile order (round 5): consecutive tiles fill a SUPER-TILE of 16 x 16 tiles (128 x 64 pixels)
+            // before the next one starts, and the XCD swizzle above hands an XCD whole super-tiles — so the ~256 waves resident on an
+            // XCD march through a compact screen block whose footprint in the three planes (x-extent 1/4, y-extent 1/8 of the image:
+            // ~0.3 + 2.1 + 1.0 MB) fits that XCD's 4 MB L2.  Row-major order gave an XCD four full-width tile rows: the whole xz plane
+            // (8.4 MB) streamed through every L2 (measured round 4: the 25 MB of planes fetched ~5 x per XCD).  A pure permutation of
+            // which wave renders which tile: results are bit-identical.  The host sets it when the tile grid divides into super-tiles.
+            const long long st = tl >> 8;
+            const int q = (int)(tl & 255), SX = p.tiles_x >> 4;
+            tx = (st % SX) * 16 + (q & 15);
+            ty = (st / SX) * 16 + (q >> 4);
+        }
         // 8x4 pixel tile in Morton-like lane order: every lane quad is a 2x2 pixel block, so the quad's four gathers of a
         // tap fall into 1-2 cache lines (the L1 coalesces within a quad; rocprof: TCP accesses/instr 48 -> see DESIGN.md)
         const int lx = (j & 1) | ((j >> 1) & 6), ly = ((j >> 1) & 1) | ((j >> 3) & 2);
@@ -2210,6 +2227,7 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     if (workspace_bytes < p3d_render_workspace_bytes(N, R, Sc, Sf)) return P3D_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     RenderParams p;
+    p.blocked = 0;
     p.planes = planes; p.rays_o = rays_o; p.rays_d = rays_d; p.jitter = jitter; p.u = u;
     p.rng = rng; p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1;
@@ -2283,8 +2301,12 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     // a decode step is ~4k MFMA clocks + ~1.5k VALU instructions of ISSUE, which ONE wave per SIMD already saturates; a second wave
     // per SIMD has nothing to hide and the per-ray work (draws, sort, marcher) is then done by twice as many waves.
     // P3D_FLAG_QUAD8 / P3D_FLAG_PAIR16 force one of the two (tests, A/B timing).
+    // Round 5 (profiles/r05_notes.txt): the tolerance-mode quad kernels spill 30 VGPRs instead of 109 (the fold no longer copies its
+    // partial sums) and win at every sample count of a 128^2 view (48+48: 0.42 -> 0.325 ms vs 0.354 for the pair kernel; 96+96: 0.559 vs
+    // 0.618): the tolerance mode takes the quad kernel for every small launch.  The exact quad kernels are compiled for one wave per
+    // SIMD (no spills: 64^2 x (96+96) 0.60 -> 0.50 ms) and stay the choice for <= 8192 rays only.
     const bool quad = pair && !(opts->flags & P3D_FLAG_PAIR16) &&
-                      ((opts->flags & P3D_FLAG_QUAD8) || (long long)N * R <= 8192 || (fast && nf == 96));
+                      ((opts->flags & P3D_FLAG_QUAD8) || (long long)N * R <= 8192 || (fast && (nf == 96 || nf == 48)));
     if (quad) {
         if (p.tile_w > 0) { p.tiles_x = ray_tile_w / 4; p.tiles_per_img = (long long)p.tiles_x * (R / ray_tile_w / 2); }
         else p.tiles_per_img = (R + 7) / 8;
@@ -2355,6 +2377,15 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     }
     long long blocks = (p.ntiles + nwaves - 1) / nwaves;
     p.swz = 16;  // measured: 8..64 within 0.5 %, 1..4 and >= 256 about 1-3 % slower
+    p.blocked = 0;
+    {   // blocked tile order (k_render): whole 16 x 16-tile super-tiles per XCD run when the tile grid divides into them
+        static const int tile_order = getenv("P3D_TILE_ORDER") ? atoi(getenv("P3D_TILE_ORDER")) : 1;  // 0: row-major (A/B runs)
+        const long long tiles_y = p.tile_w > 0 ? p.tiles_per_img / p.tiles_x : 0;
+        if (tile_order == 1 && p.tile_w > 0 && p.tiles_x % 16 == 0 && tiles_y % 16 == 0 && 256 % nwaves == 0) {
+            p.blocked = 1;
+            p.swz = 256 / nwaves;
+        }
+    }
     dim3 grid((unsigned)blocks), blk(64 * nwaves);
     hipError_t e = hipSuccess;
 #define P3D_LAUNCH(NFV, DV, FV, EV)                                                                                  \

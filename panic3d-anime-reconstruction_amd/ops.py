@@ -375,7 +375,7 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         tiles = (R // 32) * N if tiled else -(-R // 32) * N
         pair = not dumps and not (opts.flags & _lib.P3D_FLAG_NO_PAIR) and tiles <= 512  # the host's choice (p3d_render_f32)
         quad = pair and not (opts.flags & _lib.P3D_FLAG_PAIR16) and bool((opts.flags & _lib.P3D_FLAG_QUAD8) or N * R <= 8192 or
-                                                                         ((opts.flags & _lib.P3D_FLAG_FAST_COLOR) and Sf == 96 and Sc <= 96))
+                                                                         ((opts.flags & _lib.P3D_FLAG_FAST_COLOR) and ((Sf == 96 and Sc <= 96) or Sf == 48)))
         kind = ("quad" if quad else "pair") if pair else None
         if kind == "pair":  # 16 rays x 2 samples per wave-step
             tiles = (R // 16) * N if tiled else -(-R // 16) * N
