@@ -64,6 +64,12 @@ extern "C" {
                                    1 / depth.  opts->ray_start / ray_end then hold (float)(1 / ray_start), (float)(1 / ray_end) and
                                    depth_delta (float)(1 / (Sc - 1)): d = linspace(0, 1, Sc) + jitter * depth_delta;
                                    t = 1 / (ray_start * (1 - d) + ray_end * d).  Not with per-ray limits. */
+#define P3D_FLAG_WEIGHTS_ONLY 65536 /* p3d_render_f32: a HINT that the caller reads out_wsum and out_depth only (the occlusion pass of
+                                     * paste_front, training/triplane.py:565-578, reads `image_weights` of its second render and nothing
+                                     * else).  Where the library has a weights-only instantiation (small launches in the tolerance mode at
+                                     * 48 / 96 fine samples) the final pass decodes densities only: wsum / depth bit-identical to the full
+                                     * launch's, out_feat / out_xyz LEFT UNWRITTEN (still valid pointers: elsewhere the hint is ignored and
+                                     * the full kernel fills them). */
 #define P3D_FLAG_SHARED_PLANES 64 /* planes holds ONE image [1][3][H][W][32] shared by all N batches of rays / points (many
                                     views of one subject in one launch; the reference would pass planes.expand(N, ...)) */
 

@@ -12,6 +12,7 @@ P3D_FLAG_CROP, P3D_FLAG_CULL, P3D_FLAG_BINARIZE, P3D_FLAG_FORCE_SIGMOID, P3D_FLA
 P3D_FLAG_DISPARITY = 4096
 P3D_FLAG_PAIR16 = 16384
 P3D_FLAG_QUAD8 = 32768
+P3D_FLAG_WEIGHTS_ONLY = 65536
 P3D_MAX_S = 192
 P3D_ABI_VERSION = 8  # include/panic3d_hip.h; lib() refuses a library built for another version
 

@@ -1471,11 +1471,17 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, 1) void k_render_pair(Render
 // lanes, as in k_render_pair; a step decodes four consecutive samples of every ray; sigma and the skipped flag are exchanged to
 // all lanes of the ray, the 16 colour channels only towards slot 0, whose lanes write the outputs.  Bit-identical to k_render.
 // =====================================================================================================================
-template <int NF, bool FAST>
+// WO ("weights only", P3D_FLAG_WEIGHTS_ONLY; tolerance-mode instantiations only): the launch is asked for the accumulated opacity
+// (wsum) and depth alone — the occlusion pass of paste_front (training/triplane.py:565-578 reads `image_weights` of a second render and
+// nothing else).  A ray's weights depend on depths and densities only, so the final pass decodes DENSITIES (layer 1 + the sigma row, the
+// coarse pass's cost), exchanges no colours, runs no colour guards and composites nothing but W and D: wsum and depth are bit-identical
+// to the full launch's, feat / xyz are not written.
+template <int NF, bool FAST, bool WO = false>
 // Registers: the tolerance-mode instantiations are compiled for two waves per SIMD (<= 256 registers; 128^2 rays = 2048 waves).  The
 // EXACT ones are compiled for one (512): under the 256-register cap they spilled 108-127 VGPRs (164-176 B of scratch per lane, round 4),
 // and the host picks the exact quad kernel only for launches of <= 8192 rays = <= 1024 waves — one per SIMD whatever the cap.
 __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_quad(RenderParams p) {
+    static_assert(!WO || FAST, "the weights-only launch exists for the tolerance mode (the renderer class's default, what the paste runs)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     p3d_load_mlp_to_lds(lds, p.w0, p.b0, p.w1, p.b1, !FAST);
     if constexpr (FAST) p3d_load_mlp_f16_to_lds(lds, p.w0, p.w1);
@@ -1684,7 +1690,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_
             if (m > 0) {
                 float tm;
                 float w = p3d_march_weight(st, t, sigma, tm);
-                if (early) {
+                if (early && !WO) {
                     if (__builtin_amdgcn_ballot_w64(prev_skipped && w != 0.0f) != 0) {
                         float s2;
                         f32x16 c2;
@@ -1700,11 +1706,13 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_
                         skipped = false;
                     }
                 }
+                if constexpr (!WO) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
-                Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
-                Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
-                Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                    for (int c = 0; c < 16; ++c) C[c] = p3d_fma(w, (prev_rgb[c] + rgb[c]) * 0.5f, C[c]);
+                    Cx = p3d_fma(w, (ppx + px) * 0.5f, Cx);
+                    Cy = p3d_fma(w, (ppy + py) * 0.5f, Cy);
+                    Cz = p3d_fma(w, (ppz + pz) * 0.5f, Cz);
+                }
                 st.W = st.W + w;
                 st.D = p3d_fma(w, tm, st.D);
             }
@@ -1733,7 +1741,7 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_
                 skipped = __builtin_amdgcn_ballot_w64(live) == 0;
             }
             if (!skipped) {
-                if constexpr (FAST) p3d_decode_wave_fast<true, P3D_QUAD_PAIR != 0, false, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
+                if constexpr (FAST) p3d_decode_wave_fast<!WO, P3D_QUAD_PAIR != 0, false, true>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 else p3d_decode_wave<true, P3D_QUAD_PAIR != 0>(lds, rs, g, cfg, px, py, pz, sigma, rgb, live);
                 ndec += 1;
                 skipped = !live;
@@ -1745,9 +1753,11 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_
             const float s8 = swz8(sigma), s16 = swz16(sigma), s24 = swz24(sigma);
             const float kf = skipped ? 1.0f : 0.0f;
             const float k8 = swz8(kf), k16 = swz16(kf), k24 = swz24(kf);
-            f32x16 r8, r16, r24;
+            f32x16 r8 = rgb, r16 = rgb, r24 = rgb;
+            if constexpr (!WO) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { r8[c] = swz8(rgb[c]); r16[c] = swz16(rgb[c]); r24[c] = swz24(rgb[c]); }
+                for (int c = 0; c < 16; ++c) { r8[c] = swz8(rgb[c]); r16[c] = swz16(rgb[c]); r24[c] = swz24(rgb[c]); }
+            }
             consume(m, tq[0], pxq[0], pyq[0], pzq[0], of_slot(0, sigma, s8, s16, s24), rgb, of_slot(0, kf, k8, k16, k24) != 0.0f);
             if (m + 1 < S) consume(m + 1, tq[1], pxq[1], pyq[1], pzq[1], of_slot(1, sigma, s8, s16, s24), r8, of_slot(1, kf, k8, k16, k24) != 0.0f);
             if (m + 2 < S) consume(m + 2, tq[2], pxq[2], pyq[2], pzq[2], of_slot(2, sigma, s8, s16, s24), r16, of_slot(2, kf, k8, k16, k24) != 0.0f);
@@ -1767,13 +1777,15 @@ __global__ __launch_bounds__(64 * P3D_RENDER_WAVES, FAST ? 2 : 1) void k_render_
         if (p.white_back) { Cx = (Cx + 1.0f) - Wt; Cy = (Cy + 1.0f) - Wt; Cz = (Cz + 1.0f) - Wt; }
         Cx = Cx * 2.0f - 1.0f; Cy = Cy * 2.0f - 1.0f; Cz = Cz * 2.0f - 1.0f;
         if (active && slot == 0) {
-            float* dst = p.out_feat + ray * 32 + 4 * h;
+            if constexpr (!WO) {
+                float* dst = p.out_feat + ray * 32 + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){C[4 * q], C[4 * q + 1], C[4 * q + 2], C[4 * q + 3]};
+                for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 8 * q) = (f32x4){C[4 * q], C[4 * q + 1], C[4 * q + 2], C[4 * q + 3]};
+            }
             if (h == 0) {
                 p.out_depth[ray] = d;
                 p.out_wsum[ray] = Wt;
-                p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz;
+                if constexpr (!WO) { p.out_xyz[ray * 3] = Cx; p.out_xyz[ray * 3 + 1] = Cy; p.out_xyz[ray * 3 + 2] = Cz; }
             }
         }
     }
@@ -2325,10 +2337,19 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
         if (e4 == hipSuccess) hipLaunchKernelGGL((k_render_quad<NFV, FV>), grid4, blk4, lds_bytes, st, p);          \
     } while (0)
 #define P3D_LAUNCH4(NFV) do { if (fast) P3D_LAUNCH4F(NFV, true); else P3D_LAUNCH4F(NFV, false); } while (0)
+#define P3D_LAUNCH4WO(NFV)                                                                                           \
+    do {                                                                                                             \
+        e4 = p3d_ensure_dynamic_lds(k_render_quad<NFV, true, true>, lds_bytes);                                      \
+        if (e4 == hipSuccess) hipLaunchKernelGGL((k_render_quad<NFV, true, true>), grid4, blk4, lds_bytes, st, p);  \
+    } while (0)
+        // P3D_FLAG_WEIGHTS_ONLY: honoured by the tolerance-mode quad kernels at 48 / 96 fine samples (what paste_front's occlusion pass runs)
+        const bool wo = fast && (opts->flags & P3D_FLAG_WEIGHTS_ONLY) != 0;
 #ifdef P3D_ONLY_NF
         P3D_LAUNCH4(P3D_ONLY_NF);
 #else
-        if (nf == 48) P3D_LAUNCH4(48);
+        if (wo && nf == 48) P3D_LAUNCH4WO(48);
+        else if (wo && nf == 96) P3D_LAUNCH4WO(96);
+        else if (nf == 48) P3D_LAUNCH4(48);
         else if (nf == 64) P3D_LAUNCH4(64);
         else if (nf == 96) P3D_LAUNCH4(96);
         else P3D_LAUNCH4(0);

@@ -298,7 +298,7 @@ DUMP_KEYS = ("depths_coarse", "sigma_coarse", "weights_coarse", "depths_fine", "
 
 
 def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False,
-           ray_limits=None, rng_seed=None):
+           ray_limits=None, rng_seed=None, weights_only=False):
     """ImportanceRenderer.forward (renderer.py:162-264) with the two random draws passed in:
     jitter [N,R,Sc(,1)] (torch.rand_like, :324) and u [N*R,Sf] (torch.rand, :371).
     Returns (feat [N,R,32], depth [N,R,1], wsum [N,R,1], xyz [N,R,3]) (+ dict of per-stage dumps).
@@ -307,7 +307,14 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
     ray_limits: (ray_start, ray_end) per ray [N,R(,1)] for rendering_options['ray_start'] == ['ray_end'] == 'auto'
     (renderer.py:165-171; cameras.ray_limits_box + cameras.patch_ray_limits compute them).
     rng_seed (int, with jitter = u = None): the two draws are made inside the kernel by the counter-based generator of
-    include/p3d_numerics.h (p3d_render_rng_f32) — no draw tensors exist."""
+    include/p3d_numerics.h (p3d_render_rng_f32) — no draw tensors exist.
+    weights_only: the caller wants wsum and depth only (P3D_FLAG_WEIGHTS_ONLY: paste_front's occlusion pass) — returns
+    (None, depth, wsum, None); where the library has a weights-only kernel the colours are never decoded, elsewhere the full
+    kernel runs: wsum / depth are the full launch's bits either way."""
+    if weights_only:
+        if dumps:
+            raise RuntimeError("render: weights_only and dumps exclude each other")
+        opts = _with_flag(opts, _lib.P3D_FLAG_WEIGHTS_ONLY)
     if per_view_clamp:
         opts = _with_flag(opts, _lib.P3D_FLAG_PER_VIEW_CLAMP)
     planes_nhwc = _chk(planes_nhwc, "planes_nhwc")
@@ -386,6 +393,8 @@ def render(planes_nhwc, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dump
         else:
             full = tiles * (Sc + Sc + Sf if Sf > 0 else Sc)
         stats.update(decode_steps=steps, decode_steps_full=full, small_launch_kernel=pair, small_launch_kind=kind)
+    if weights_only:  # (feat / xyz may have been left unwritten)
+        return None, depth, wsum, None
     return (feat, depth, wsum, xyz, d) if dumps else (feat, depth, wsum, xyz)
 
 

@@ -62,9 +62,10 @@ def front_occlusion(G, x, out, offset=0.01):
     draws = G._inject_draws or (None, None)
     if isinstance(draws, list):
         draws = draws.pop(0)
+    # only the accumulated opacity of this second render is read (triplane.py:578): a weights-only launch — no colour decode
     _, _, wsum, _ = G.renderer(out["triplane"], G.decoder, flat(ro), consts[2], G.rendering_kwargs,
                                triplane_crop=x.get("triplane_crop"), cull_clouds=x.get("cull_clouds"),
-                               binarize_clouds=x.get("binarize_clouds"), jitter=draws[0], u=draws[1])
+                               binarize_clouds=x.get("binarize_clouds"), jitter=draws[0], u=draws[1], weights_only=True)
     return wsum.permute(0, 2, 1).reshape(N, 1, H, W)
 
 

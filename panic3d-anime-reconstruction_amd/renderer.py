@@ -82,7 +82,9 @@ class ImportanceRenderer(torch.nn.Module):
 
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, triplane_crop=None,
                 cull_clouds=None, binarize_clouds=None, jitter=None, u=None, ray_tile_w=None, return_dumps=False,
-                per_view_clamp=False, exact=None, density_noise_draws=None):
+                per_view_clamp=False, exact=None, density_noise_draws=None, weights_only=False):
+        # weights_only (an extension): the caller reads `weights.sum(2)` and the depth only — returns (None, depth, wsum, None); the
+        # colours are not decoded where the library has a weights-only kernel (ops.render)
         if (rendering_options.get("density_noise", 0) or 0) > 0:  # renderer.py:276-277 (a training-time option): the staged path
             if return_dumps or per_view_clamp:
                 raise NotImplementedError("density_noise > 0 runs the staged path: no per-stage dumps, no per-view clamp")
@@ -112,7 +114,7 @@ class ImportanceRenderer(torch.nn.Module):
             ray_tile_w = side if side * side == R else 0
         out = ops.render(self._nhwc(planes), ray_origins.float(), ray_directions.float(), jitter, u,
                          decoder_params(decoder), opts, ray_tile_w=ray_tile_w, dumps=return_dumps, per_view_clamp=per_view_clamp,
-                         ray_limits=limits)
+                         ray_limits=limits, weights_only=weights_only)
         return out  # rgb_final, depth_final, weights.sum(2), xyz_final  (renderer.py:264)
 
     # ---- the reference's own structure, stage by stage ---------------------------------------------------------------------

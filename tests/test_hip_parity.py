@@ -745,3 +745,27 @@ def test_staged_path_random_configs(hip, seed):
         ok = np.isfinite(a) & np.isfinite(b)
         frac, worst = _within(np.where(ok, a, 0), np.where(ok, b, 0), tol)
         assert frac >= 0.99, (key, seed, frac, worst)
+
+
+@pytest.mark.parametrize("Sc,Sf,res", [(96, 96, 32), (48, 48, 32), (48, 48, 128), (64, 64, 32), (48, 48, 256)])
+def test_weights_only_launch_equals_the_full_launch(hip, Sc, Sf, res):
+    """P3D_FLAG_WEIGHTS_ONLY (round 5): paste_front's occlusion pass reads `image_weights` of its second render and nothing else
+    (training/triplane.py:565-578).  A ray's weights depend on depths and densities only, so the weights-only launch (tolerance mode,
+    small launches, 48 / 96 fine samples: k_render_quad<NF, true, true>) decodes no colours — and wsum / depth must be BIT-IDENTICAL to
+    the full tolerance-mode launch's; where the library has no such instantiation (64 fine samples; a large launch; the exact mode) the
+    hint is ignored and the same bits come from the full kernel."""
+    ro = dict(T.RENDERING_KWARGS, depth_resolution=Sc, depth_resolution_importance=Sf)
+    planes = T.make_planes(71, 1, 64, 64, scale=4.0, smooth=8)
+    raw = T.make_decoder_params(72, 1.0, 30.0)
+    o, d = hip.cameras.rays_from_label(hip.cameras.camera_label(5.0, 30.0, 1.0, 30.0)[None], res)
+    jit, u = T.make_random_draws(73, 1, res * res, Sc, Sf)
+    kw = dict(triplane_crop=0.1, cull_clouds=0.5, force_sigmoid=True)
+    mlp, nhwc = hip_mlp(hip, raw, 1.0), hip.ops.planes_to_nhwc(dev(planes))
+    for fast in (True, False):
+        opts = hip.ops.make_opts(ro, fast_color=fast, **kw)
+        full = hip.ops.render(nhwc, o.cuda(), d.cuda(), dev(jit), dev(u), mlp, opts, ray_tile_w=res)
+        st = {}
+        wo = hip.ops.render(nhwc, o.cuda(), d.cuda(), dev(jit), dev(u), mlp, opts, ray_tile_w=res, weights_only=True, stats=st)
+        assert wo[0] is None and wo[3] is None
+        assert torch.equal(wo[2], full[2]) and torch.equal(wo[1], full[1]), (fast, Sc, res)
+        assert float(full[2].mean()) > 0.05  # a volume with surfaces: the weights are not trivially zero

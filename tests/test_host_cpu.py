@@ -569,8 +569,11 @@ def _oracle_render_op(monkeypatch, P, oracle):
     n = lambda x: x.detach().cpu().numpy()
 
     def render(planes, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w=0, dumps=False, stats=None, per_view_clamp=False, ray_limits=None,
-               rng_seed=None):
+               rng_seed=None, weights_only=False):
         assert not dumps and rng_seed is None and ray_limits is None
+        if weights_only:  # (ops.render: feat / xyz are not returned; wsum / depth are the full render's)
+            full = render(planes, rays_o, rays_d, jitter, u, mlp, opts, ray_tile_w, per_view_clamp=per_view_clamp)
+            return None, full[1], full[2], None
         oo = oracle.Opts(opts.coord_scale, opts.ray_start, opts.ray_end, opts.depth_delta, opts.crop_limit, opts.cull_thresh, opts.Sc, opts.Sf,
                          opts.plane_mode, int(opts.flags) & 31)
         N, R = rays_o.shape[0], rays_o.shape[1]
