@@ -10,6 +10,7 @@ O=$R/gpurun_out/${TAG}_convpmc
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$R'); import panic3d_amd as P; print(P._build.source_hash())" > $O/kernel_src_sha.txt
+python -c "import sys; sys.path.insert(0, '$R'); import panic3d_amd as P; print(P._build.synthesis_source_hash())" > $O/synthesis_src_sha.txt
 for what in bb sr; do
   FL=""; [ $what = sr ] && FL="--sr"
   timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$what -o r -- python $R/tools/profile_backbone.py --passes 2 $FL > $O/trace_$what.log 2>&1

@@ -25,7 +25,9 @@ def last_pass(rows, key_start):
     return rows[idx[-1]:] if idx else rows
 
 
+_ss = os.path.join(src, "synthesis_src_sha.txt")
 out = {"tag": tag, "kernel_src_sha": open(os.path.join(src, "kernel_src_sha.txt")).read().strip(),
+       "synthesis_src_sha": open(_ss).read().strip() if os.path.exists(_ss) else None,  # the key bench.py's pipeline block matches on
        "note": __doc__.strip().splitlines()[1], "passes": {}}
 for what, first in (("bb", "k_demod_plan"), ("sr", "k_demod_plan")):
     tr = glob.glob(os.path.join(src, f"trace_{what}", "**", "*kernel_trace.csv"), recursive=True)
