@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$REPO'); import panic3d_amd as P; print(P._build.source_hash())" > "$OUT/kernel_src_sha.txt"
 python -c "import sys; sys.path.insert(0, '$REPO'); import panic3d_amd as P; print(P._build.render_source_hash())" > "$OUT/render_src_sha.txt"
-B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-table --roofline-steps 0 $EXTRA"
+B="python $REPO/bench.py --no-cpu-baseline --no-verify --no-table --no-pipeline --roofline-steps 0 $EXTRA"
 for scene in $SCENES; do
   for mode in early noearly exact_early exact_noearly; do
     FL="--scene $scene"
