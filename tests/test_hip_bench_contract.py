@@ -141,3 +141,15 @@ def test_bench_under_torch_distributed_run_streams_the_frames():
     assert "pipeline" not in d and "pipeline" not in e
     assert e["dtype"].startswith("f32 (final-pass MLP operands as two-term f16") and "ONE gather" in e["config"]["workload"]
     assert "results" not in e and "value_surface" not in e and e["gather"]["mode"].startswith("end")
+
+
+def test_bench_views_per_step_renders_v_views_per_launch():
+    """`--views-per-step V`: V views of the subject in ONE renderer launch (planes shared by the batch, per-view depth clamp) — the
+    whole-job value counts V x 512^2 rays per step, the roofline's per-launch byte counts scale with V, the verification still passes."""
+    d = _bench(["--steps", "4", "--warmup", "1", "--roofline-steps", "2", "--views-per-step", "3", "--no-table", "--no-pipeline", "--no-cpu-baseline"],
+               launched=False)
+    assert d["config"]["views_per_step"] == 3 and d["config"]["rays_per_step_per_gpu"] == 3 * 512 * 512
+    assert abs(d["value"] - 3 * 512 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 3 * 512 * 512 * (96 * 1536 + 172) and 0 < r["frac"] <= 1.0
+    assert d["verify"]["ok"] is True and "3 views per GPU per step in ONE launch" in d["config"]["workload"]

