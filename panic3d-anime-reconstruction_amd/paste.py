@@ -7,11 +7,14 @@ lerp — the reference runs three bilinear resizes, a Sobel, a nearest resize, a
 
 kornia is not a dependency: the kernel restates kornia 0.6.5 `kornia.filters.sobel(x, normalized=True, eps=1e-6)` (3x3
 Sobel kernels divided by 8, replicate padding, sqrt(gx^2 + gy^2 + eps)) — "parity unpinned": kornia cannot be installed here
-(profiles/history/r02_notes.txt; tests/golden/make_golden_mesh.py generates the pin where it can).  `front_weight_erosion >= 1`
-(kornia.morphology.erosion; not used by _scripts/eval/generate.py:55-66) is not mirrored.  `sobel_magnitude`,
+(profiles/history/r02_notes.txt; tests/golden/make_golden_sobel.py generates the pin where it can).  `front_weight_erosion >= 1`
+(an extra front-view render + kornia.morphology.erosion, restated below) and `force_image` — the two options
+_scripts/eval/generate.py:55-66 never passes — run on the torch formulation (`paste_front_torch`), not on the fused kernel.  `sobel_magnitude`,
 `sample_orthofront` and `xyz_discrepancy` below are the torch formulation of the same steps, kept as the kernel's reference
 in tests/ (`paste_front_torch`).
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -81,7 +84,11 @@ def paste_front(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02
     """training/triplane.py:607-691 on the fused kernel; same arguments and return keys."""
     from . import ops
     if front_weight_erosion >= 1 or force_image is not None:
-        raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
+        # the two options _scripts/eval/generate.py never passes (triplane.py:644-667): the torch formulation below carries them — the
+        # extra front-view render + erosion, or another image to paste — on the same renderer launches; not on the fused paste kernel
+        return paste_front_torch(G, x, out, mode=mode, thresh_weight=thresh_weight, thresh_edges=thresh_edges, thresh_occ=thresh_occ,
+                                 offset_occ=offset_occ, thresh_dxyz=thresh_dxyz, front_weight_erosion=front_weight_erosion,
+                                 grad_sample=grad_sample, force_image=force_image, **kwargs)
     with torch.no_grad():
         occ = front_occlusion(G, x, out, offset=offset_occ)
         res = ops.paste_front(out["image_weights"], out["image_xyz"], occ, x["force_rays"]["ray_origins"], x["force_rays"]["ray_directions"],
@@ -94,9 +101,9 @@ def paste_front(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02
 
 def paste_front_torch(G, x, out, mode="default", thresh_weight=0.95, thresh_edges=0.02, thresh_occ=0.05, offset_occ=0.01,
                       thresh_dxyz=0.01, front_weight_erosion=0, grad_sample=False, force_image=None, **kwargs):
-    """The same post-process as a composition of torch ops (the reference's own formulation): the comparator of the fused kernel."""
-    if front_weight_erosion >= 1 or force_image is not None:
-        raise NotImplementedError("front_weight_erosion / force_image are not used by _scripts/eval/generate.py")
+    """The same post-process as a composition of torch ops (the reference's own formulation): the comparator of the fused kernel, and
+    the path of the two options generate.py does not use — `front_weight_erosion >= 1` (triplane.py:644-658: the paste is also masked
+    by the eroded silhouette of a front-view render) and `force_image` (:666-667: paste that image instead of the conditioning one)."""
     view_xyz = out["image_xyz"]
     front_rgb = x["cond"]["image_ortho_front"]
     if len(front_rgb) == 1 and len(view_xyz) > 1:  # V views of one subject in one call (generator.synthesis)
@@ -110,9 +117,37 @@ def paste_front_torch(G, x, out, mode="default", thresh_weight=0.95, thresh_edge
         fmask = F.interpolate(fmask, S, mode="bilinear")
         dmask = F.interpolate(xyz_discrepancy(view_xyz, x["force_rays"]), S, mode="nearest")
         dmask = (dmask < thresh_dxyz).float()
+        frontw = None
         fwmask = torch.ones_like(dmask)
+        if front_weight_erosion >= 1:  # triplane.py:644-658
+            frontw = front_weights(G, x)
+            fwmask = erosion((frontw > 0.5).float(), int(front_weight_erosion))
+            fwmask = sample_orthofront(fwmask, F.interpolate(view_xyz, S, mode="bilinear"), G.rendering_kwargs["box_warp"])
+            fwmask = F.interpolate(fwmask, S, mode="nearest")
         mask = wmask * smask * fmask * dmask * fwmask
-        tocopy = front_rgb if not x["normalize_images"] else front_rgb * 2 - 1
+        if force_image is None:
+            tocopy = front_rgb if not x["normalize_images"] else front_rgb * 2 - 1
+        else:  # the reference takes its image wrapper (`force_image.t()[None,]`, triplane.py:667); a [C,H,W] / [1,C,H,W] tensor works too
+            t = force_image.t() if not torch.is_tensor(force_image) else force_image
+            tocopy = (t[None] if t.dim() == 3 else t).to(mask.device)
+    with (contextlib.nullcontext() if grad_sample else torch.no_grad()):
         paste = sample_orthofront(tocopy, F.interpolate(view_xyz, S, mode="bilinear"), G.rendering_kwargs["box_warp"])
     return {"image": torch.lerp(out["image"], paste, mask), "paste": paste, "mask": mask, "mask_weights": wmask,
-            "mask_edges": smask, "mask_occ": fmask, "mask_dxyz": dmask, "mask_frontweight": fwmask, "frontweight": None}
+            "mask_edges": smask, "mask_occ": fmask, "mask_dxyz": dmask, "mask_frontweight": fwmask, "frontweight": frontw}
+
+
+def front_weights(G, x):
+    """`get_front_weights` (triplane.py:579-599): `image_weights` of an orthographic front view of the same subject."""
+    dev = x["cond"]["image_ortho_front"].device
+    xin = {k: v for k, v in x.items() if k not in ("paste_params", "camera_params", "conditioning_params", "force_rays")}
+    xin["elevations"], xin["azimuths"], xin["fovs"] = torch.zeros(1, device=dev), torch.zeros(1, device=dev), -torch.ones(1, device=dev)
+    return G.f(xin, return_more=True)["image_weights"]
+
+
+def erosion(mask, e, max_val=1e4):
+    """`kornia.morphology.erosion(mask, torch.ones(e, e))` as kornia 0.6.5 defines it for a flat structuring element: origin (e // 2,
+    e // 2), border_type 'geodesic' (the image is padded with max_val, so the border itself does not erode), output = minimum over the
+    window.  PARITY UNPINNED against kornia (absent here), like the Sobel filter above."""
+    o = e // 2
+    padded = F.pad(mask, [o, e - o - 1, o, e - o - 1], value=max_val)
+    return -F.max_pool2d(-padded, kernel_size=e, stride=1)

@@ -185,8 +185,13 @@ class ImportanceRenderer(torch.nn.Module):
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
         """renderer.py:266-280 — sample_directions are ignored, as the reference's decoder ignores them
         (training/triplane.py:528-531)."""
+        dn = float(options.get("density_noise", 0) or 0)
+        if dn > 0:  # renderer.py:276-277: `out['sigma'] += torch.randn_like(out['sigma']) * options['density_noise']` after the decode
+            options = {k: v for k, v in options.items() if k != "density_noise"}
         opts = self._opts(options, decoder)
         sigma, rgb = ops.triplane_decode(self._nhwc(planes), sample_coordinates.float(), decoder_params(decoder), opts)
+        if dn > 0:
+            sigma = sigma + torch.randn_like(sigma) * dn
         return {"rgb": rgb, "sigma": sigma, "xyz": sample_coordinates}
 
     def run_model_density(self, planes, decoder, sample_coordinates, options):

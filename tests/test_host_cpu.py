@@ -1069,3 +1069,73 @@ def test_sobel_against_kornia(P):
     from panic3d_amd import paste
     got = paste.sobel_magnitude(torch.from_numpy(z["x"]))
     assert got.shape == z["sobel"].shape and float((got - torch.from_numpy(z["sobel"])).abs().max()) < 1e-6, str(z["kornia_version"])
+
+
+def test_paste_front_options_generate_py_does_not_use(P, oracle, monkeypatch):
+    """`force_image` and `front_weight_erosion >= 1` (training/triplane.py:644-667; VERDICT r04 "missing" 7: they used to raise): both run on
+    the torch formulation of the paste.  force_image: same masks, the pasted colours come from that image.  front_weight_erosion: one
+    more render (the orthographic front view's `image_weights`, get_front_weights), its silhouette eroded by an e x e element and
+    sampled (bilinearly) at the rendered xyz — a mask in [0, 1] that can only shrink the paste, and shrinks with e.  The erosion is kornia's definition for a
+    flat element (geodesic border), checked against a brute-force minimum filter (PARITY UNPINNED against kornia itself, absent here)."""
+    import torch.nn.functional as F
+    from panic3d_amd import paste
+    # erosion == brute force: window rows i - e//2 .. i - e//2 + e - 1, outside the image = +max (never the minimum)
+    m = (torch.rand(1, 1, 9, 11, generator=torch.Generator().manual_seed(4)) > 0.3).float()
+    for e in (1, 2, 3, 4):
+        got, o = paste.erosion(m, e), e // 2
+        want = torch.ones_like(m)
+        for i in range(9):
+            for j in range(11):
+                win = [m[0, 0, a, b] for a in range(i - o, i - o + e) for b in range(j - o, j - o + e) if 0 <= a < 9 and 0 <= b < 11]
+                want[0, 0, i, j] = min(win)
+        assert torch.equal(got, want), e
+    assert torch.equal(paste.erosion(m, 1), m)
+    _cpu_generator_env(monkeypatch, P, oracle)
+    g = T.load_golden("syn_triplane_f.npz")
+    G = _cpu_fixture_generator(g)
+    front = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(11))
+    other = torch.rand(3, 512, 512, generator=torch.Generator().manual_seed(12))
+    pp = {"mode": "default", "thresh_weight": 0.5, "thresh_edges": 0.2, "thresh_occ": 0.5, "offset_occ": 0.01, "thresh_dxyz": 0.05}
+    mk = lambda **o: dict(elevations=torch.tensor([10.0]), azimuths=torch.tensor([25.0]), fovs=torch.tensor([-1.0]), seeds=[3],
+                          cond={"image_ortho_front": front}, triplane_crop=0.1, cull_clouds=0.5, neural_rendering_resolution=16,
+                          noise_mode="const", paste_params=dict(pp, **o))
+
+    def run(**o):
+        torch.manual_seed(5)  # the renderer's draws (torch.rand on the CPU stand-in) in the same order for every variant
+        try:
+            with torch.no_grad():
+                return G.f(mk(**o))
+        finally:
+            P.cameras.cached_view_clear()
+    base, forced, er1, er3 = run(), run(force_image=other), run(front_weight_erosion=1), run(front_weight_erosion=3)
+    assert base["paste"]["mask"].mean() > 0.02  # something is pasted in this fixture
+    # force_image: the masks are the view's, the paste is sampled from the other image
+    assert torch.equal(forced["paste"]["mask"], base["paste"]["mask"]) and not torch.equal(forced["paste"]["paste"], base["paste"]["paste"])
+    want = paste.sample_orthofront(other[None], F.interpolate(base["image_xyz"], 512, mode="bilinear"), G.rendering_kwargs["box_warp"])
+    assert torch.allclose(forced["paste"]["paste"], want, atol=1e-6)
+    assert torch.allclose(forced["image"], torch.lerp(base["image_prepaste"], want, base["paste"]["mask"]), atol=1e-6)
+    # erosion: one more render, a front-weight mask in {0, 1}, monotone in e, only ever removing paste
+    assert er1["paste"]["frontweight"].shape == base["image_weights"].shape and base["paste"]["frontweight"] is None
+    fw1, fw3 = er1["paste"]["mask_frontweight"], er3["paste"]["mask_frontweight"]
+    # (bilinear samples of a 0 / 1 silhouette: values in [0, 1]; the eroded silhouette is a subset, so the samples can only drop)
+    assert float(fw1.min()) >= 0.0 and float(fw1.max()) <= 1.0 and bool((fw3 <= fw1 + 1e-6).all()) and fw3.sum() < fw1.sum()
+    assert bool((er1["paste"]["mask"] <= base["paste"]["mask"]).all()) and bool((er3["paste"]["mask"] <= er1["paste"]["mask"] + 1e-6).all())
+    assert torch.equal(er1["paste"]["mask"], base["paste"]["mask"] * fw1)
+
+
+def test_run_model_with_density_noise(P, oracle, monkeypatch):
+    """`run_model` with rendering_options['density_noise'] > 0 (renderer.py:276-277; used to raise): the decode, then
+    `sigma += randn_like(sigma) * density_noise` with the caller's torch generator — the noise-free sigma plus exactly those draws."""
+    _oracle_stage_ops(monkeypatch, P, oracle, 0.7)
+    monkeypatch.setattr(P.ops, "planes_to_nhwc", lambda planes: planes)
+    planes = torch.from_numpy(T.make_planes(5, 1, 32, 32))
+    pts = torch.from_numpy(T.make_points(6, 1, 257, extent=0.4)).float()
+    dec = _cpu_decoder(T.make_decoder_params(7), True, 1.0)
+    rend = P.ImportanceRenderer(use_triplane=True)
+    ro = dict(T.RENDERING_KWARGS)
+    quiet = rend.run_model(planes, dec, pts, None, ro)
+    torch.manual_seed(9)
+    noisy = rend.run_model(planes, dec, pts, None, dict(ro, density_noise=0.5))
+    torch.manual_seed(9)
+    want = quiet["sigma"] + torch.randn_like(quiet["sigma"]) * 0.5
+    assert torch.equal(noisy["sigma"], want) and torch.equal(noisy["rgb"], quiet["rgb"]) and float((noisy["sigma"] - quiet["sigma"]).abs().mean()) > 0.1
