@@ -2402,7 +2402,9 @@ static int render_impl(const float* planes, int N, int H, int W, const float* ra
     {   // blocked tile order (k_render): whole 16 x 16-tile super-tiles per XCD run when the tile grid divides into them
         static const int tile_order = getenv("P3D_TILE_ORDER") ? atoi(getenv("P3D_TILE_ORDER")) : 1;  // 0: row-major (A/B runs)
         const long long tiles_y = p.tile_w > 0 ? p.tiles_per_img / p.tiles_x : 0;
-        if (tile_order == 1 && p.tile_w > 0 && p.tiles_x % 16 == 0 && tiles_y % 16 == 0 && 256 % nwaves == 0) {
+        // ... and into a multiple of 8 of them: 384^2 (18 super-tiles on 8 XCDs) loses 2-3 % to the imbalance, every shape with whole
+        // super-tiles per XCD is equal or up to 3 % better (profiles/r05_tile_order_shapes.json)
+        if (tile_order == 1 && p.tile_w > 0 && p.tiles_x % 16 == 0 && tiles_y % 16 == 0 && 256 % nwaves == 0 && (p.ntiles / 256) % 8 == 0) {
             p.blocked = 1;
             p.swz = 256 / nwaves;
         }
