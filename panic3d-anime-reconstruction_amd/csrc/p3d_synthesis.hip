@@ -16,69 +16,9 @@
 //   k_upfirdn2d       zero-insert x up, pad/crop, FIR, with an optional fused epilogue d*v + noise -> +bias -> act*gain -> clamp
 //                     (upfirdn2d.py:169-213 _upfirdn2d_ref; bias_act.py:93-122 _bias_act_ref)
 //   k_bias_act        clamp(act(x + b) * gain)                                            (bias_act.py:93-122)
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include <type_traits>
-
-#include "../../include/panic3d_hip.h"
+#include "p3d_conv_common.hpp"
 
 static bool env_no_w3();  // (defined with the other read-once environment switches, above up3_applies)
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define DEV __device__ __forceinline__
-
-#define CONV_TH 8
-#define CONV_TW 16
-#define XS_ROW (CONV_TW + 2)
-#define XS_PLANE ((CONV_TH + 2) * XS_ROW)
-// a K chunk = 8 input channels (72 k values for 3x3, 8 for 1x1)
-template <int MODE> struct ConvTaps;
-// N taps; dy, dx: input offset of tap t relative to the output position (tap t is element ky*3+kx of the 3x3 kernel)
-template <> struct ConvTaps<0> { static constexpr int N = 9; static constexpr int dy[9] = {-1,-1,-1,0,0,0,1,1,1}; static constexpr int dx[9] = {-1,0,1,-1,0,1,-1,0,1}; };
-template <> struct ConvTaps<1> { static constexpr int N = 1; static constexpr int dy[1] = {0}; static constexpr int dx[1] = {0}; };
-
-struct ConvParams {
-    const float* x;       // [N][I][H][W]
-    const float* w;       // [O][I][ks][ks]
-    const void* wh;       // f16 copy [O][ks*ks][I] (f16-operand kernels) or null
-    int wsplit;           // wh holds hi parts followed by lo parts (two-term operands)
-    const float* styles;  // [N][I]
-    const float* dcoef;   // [N][O] or null
-    const float* noise;   // [OH*OW] (shared) or [N][OH*OW] or null; already multiplied by noise_strength
-    const float* bias;    // [O] or null
-    float* y;             // [N][O][OH][OW]
-    int N, I, O, H, W;    // input dims
-    int GH, GW;           // output grid of this launch (phase grid for MODE >= 2)
-    int OH, OW;           // output tensor dims
-    int ks;               // kernel size of w (1 or 3)
-    int noise_per_sample;
-    int act;              // 0 linear, 1 lrelu
-    float alpha, gain, clamp;
-    int epilogue;         // 1: dcoef/noise/bias/act applied here; 0: raw store (transposed-conv intermediate)
-    int tox;              // up = 2: the intermediate T [N][O][2H+1][OW = pitch] stores column ox at index ox + tox (tox = 1, pitch = 2W + 4: the
-                          // FIR pass reads its 36-column windows — columns X0 - 1 .. X0 + 34 — as aligned 16-byte loads); 0 elsewhere
-    int ksplit;           // input channels split over ksplit workgroups (blockIdx.z = n*ksplit + kz); > 1 => raw partials
-    int xcd;              // k_modconv_w3 / k_modconv_up3: XCD-aware workgroup order (p3d_wg_order)
-    unsigned int* sat;    // caller-owned device word, OR-ed with 1 when a two-term operand left its domain (or null: not reported)
-    // ---- the activation IMAGE path (the producer prepares the consumer's operand; see "activation IMAGE" below)
-    const void* ximg;     // input as an image [hi | lo][N][I/8][H][W] of 16-byte pieces, or null (then x + styles are used)
-    long long ximg_lo;    // byte offset of the lo half of ximg (= N*I*H*W*2)
-    // k_modconv_w3 only: ALSO write the result as the image of a following layer with styles ystyles [N][O] (next to the fp32 y)
-    void* yimg;
-    long long yimg_lo;    // = N*O*OH*OW*2
-    const float* ystyles;
-    const float* fir;     // k_modconv_up3<true>: the 4x4 filter of the FIR pass it contains (flipped, times up^2)
-};
-
-DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
-    if (act == 1) v = v < 0.0f ? v * alpha : v;
-    v = v * gain;
-    if (clamp >= 0.0f) v = __builtin_fminf(__builtin_fmaxf(v, -clamp), clamp);
-    return v;
-}
-
 // =====================================================================================================================
 // The convolution kernels.  The f32 MFMA shares its SIMD with the VALU (tools/ubench/mfma_valu_overlap.hip), so the K loop is
 // written to contain ds_reads and MFMAs only:
@@ -91,8 +31,6 @@ DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {
 //   * LDS is double buffered: the next chunk is stored while the other buffer is read -> ONE barrier per chunk; with the plan
 //     registers gone three workgroups fit a CU (k_modconv) / two instead of one (k_modconv_up).
 // =====================================================================================================================
-#define CONV_OOB ((int)0x80000000)
-#define CONV_RSRC_FLAGS 0x00020000
 
 struct ConvStagePlan {
     int xoff[6];  // byte offset of staged patch value u inside the chunk-relative image slice (CONV_OOB = zero)
@@ -349,8 +287,6 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up(ConvParams p) {
 //   LDS A: [tap][k half][64 o][8 ch] f16       (lanes = consecutive o -> consecutive slots)
 // Requires I % 16 == 0 (the host falls back to the f32 kernels otherwise).
 // =====================================================================================================================
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define HX_PITCH 32                           // pixels per patch row in LDS
 #define HX_HALF ((CONV_TH + 2) * HX_PITCH * 16)  // bytes of one k half of the patch
 #define HX_BYTES (2 * HX_HALF)
@@ -393,17 +329,6 @@ DEV ConvStagePlanH conv_plan_h(const ConvParams& p, int tid, int gy0, int gx0, i
 // ~2^-22 relative, i.e. fp32-class results at 3 f16 MFMAs (96 cycles per 16 channels) instead of 8 f32 ones (512 cycles).
 // The weight tensor then holds the hi parts followed by the lo parts (k_weights_to_f16 with split = 1); LDS keeps the lo images
 // behind the hi ones, and the weights single-buffered (hi + lo of a chunk are 36 KB for 3x3: two workgroups per CU still fit).
-// The matrix cores flush f16 subnormals, so the operands are scaled by a power of two before they are split — the weights by
-// 2^6 (lo parts of |w| >= 2^-8 stay normal), the modulated activations s*x by 2^4 (|s*x| >= 2^-6; more headroom at the top:
-// hi saturates, it does not overflow, at |s*x| = 65504 / 16 = 4094) — and the accumulators are scaled back by 2^-10
-// when they are stored; all exact.  A value below those thresholds loses its lo part (absolute error <= 2^-11 |v|, i.e.
-// below 8e-6 / 2e-6): rare and small next to the 2^-22 relative rounding of the ordinary terms.
-#define HX_SPLIT_SCALE_X 16.0f
-#define HX_SPLIT_SCALE_W 64.0f
-#define HX_SPLIT_UNSCALE (1.0f / 1024.0f)
-// Out of domain: a scaled operand beyond the f16 range (|s*x| > 65504 / 16 = 4094, or NaN) is clamped to +-65504 — finite, wrong —
-// and the CALLER's flag word (ConvParams::sat, the `saturated` argument of p3d_modconv2d_f16x2mma_f32) is OR-ed with 1: no state
-// lives in the library.
 template <int NT, bool SPLIT = false>
 struct ConvStageRegsH { float x[2][8]; f32x4 s[2][2]; i32x4 w[NT ? (NT * 128 + 255) / 256 : 1]; i32x4 wl[SPLIT ? (NT * 128 + 255) / 256 : 1]; };  // NT = 0: activations only
 
@@ -605,8 +530,6 @@ __global__ __launch_bounds__(256, 2) void k_modconv_h(ConvParams p) {
 //   LDS B: [hi | lo][buffer][k half][10 rows][34 px][8 ch] f16 = 2 x 2 x 10 880 B;  LDS A: [hi | lo][tap][k half][64 o][8 ch] = 36 864 B
 //   -> 80 384 B per workgroup, two workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------
-#define WX_TW 32
-#define WX_ROW (WX_TW + 2)                         // patch columns = LDS row pitch (px)
 #define WX_HALF ((CONV_TH + 2) * WX_ROW * 16)      // bytes of one k half
 #define WX_BYTES (2 * WX_HALF)                     // one (hi or lo) patch image: 10 880
 #define WX_ITEMS (2 * (CONV_TH + 2) * WX_ROW)      // (k half, pixel) items per chunk: 680
@@ -884,48 +807,12 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 // workgroups per CU.  Same products as k_modconv_w2, summation order (dx-major) identical to it: bit-identical results.
 // Requires O % 64 == 0 (the 3x3 layers of the backbone / super-resolution: 512 .. 64); others take k_modconv_w2<true>.
 // ---------------------------------------------------------------------------------------------------------------------
-// Workgroup order of the image-fed kernels.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with an L2
-// of its own, and in (tile, channel tile) order the four channel tiles of a spatial tile — which read the SAME patch — landed on four
-// different XCDs at four different times: 256 -> 256 @256^2 staged 356 MB of patches out of a 67 MB image, all of it past the L2s.
-// Here XCD x is given a CONTIGUOUS range of the (slice, tile, channel tile) sequence, channel tile fastest: the channel tiles of a
-// tile, and neighbouring tiles with their shared halos, run back to back on one XCD and meet in its L2.
-struct WgOrder { int tile, otile, z; };
-DEV WgOrder p3d_wg_order(bool xcd) {
-    const int T = gridDim.x * gridDim.y * gridDim.z;
-    int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    WgOrder r;
-    if (!xcd) { r.tile = blockIdx.x; r.otile = blockIdx.y; r.z = blockIdx.z; return r; }
-    const int q = T >> 3, rem = T & 7, x = L & 7, m = L >> 3;
-    L = x * q + (x < rem ? x : rem) + m;
-    r.otile = L % gridDim.y;
-    L /= gridDim.y;
-    r.tile = L % gridDim.x;
-    r.z = L / gridDim.x;
-    return r;
-}
-
 #define W3_GROUP_BYTES (768 * 16)
 #define W3_WBYTES (3 * W3_GROUP_BYTES)
 #define W3_SUB ((CONV_TH + 2) * WX_ROW * 16)
 #define W3_PATCH (4 * W3_SUB)
 #define W3_EPI (W3_WBYTES + 2 * W3_PATCH)
 #define W3_LDS (W3_EPI + 768)
-DEV i32x4 w3_rsrc(const void* base, uint32_t bytes) {
-    const uint64_t a = (uint64_t)base;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = CONV_RSRC_FLAGS;
-    return r;
-}
-// 64 lanes x 16 bytes from rsrc[voff] to LDS [lds_addr + lane * 16] (lds_addr wave-uniform); one wait state between the M0 write
-// and the LDS-DMA (what the compiler inserts for its own: s_nop 0)
-DEV void w3_dma16(uint32_t lds_addr, i32x4 rsrc, int voff) {
-    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);  // ("s" alone does not make a value uniform: s_mov_b32 m0, v75 was emitted)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-#define W3_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[W3_LDS];
@@ -1150,7 +1037,6 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
 // Raw store of the four phases into the (2H+1) x (2W+1) intermediate (or split-K partials); the FIR pass applies the epilogue.
 // Same products as k_modconv_up_h<true>; fp32 summation order: per tap a_hi*b_lo, a_lo*b_hi, a_hi*b_hi.
 // ---------------------------------------------------------------------------------------------------------------------
-#define U3_WB (2 * 9 * 64 * 16)                    // one buffer of weights: 18 432
 #define U3_ROWS 9
 #define U3_SUB (U3_ROWS * WX_ROW * 16)             // one (hi|lo, k half) sub-image of the patch: 4 896
 #define U3_PATCH (4 * U3_SUB)
@@ -2390,6 +2276,22 @@ static int up3_min_w() {  // (P3D_UP3_MIN_W in the environment: A/B runs)
 static bool env_no_up3() { static const bool v = getenv("P3D_NO_UP3") != nullptr; return v; }
 static bool env_no_w3() { static const bool v = getenv("P3D_NO_W3") != nullptr; return v; }
 static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= up3_min_w() && !env_no_up3(); }
+// k_modconv_up4 (p3d_conv_up4.hip)
+int p3d_up4_shape(int N, int O, int H, int W);
+int p3d_up4_launch(const ConvParams& p, int rpw, hipStream_t st);
+// P3D_UP4=0 in the environment: the round-5 kernels (k_modconv_up3 + FIR pass) for every layer; P3D_UP4_MIN_WGS / P3D_UP4_MIN_I: the
+// launch size (workgroups of the 8-row tiling) and K depth from which the one-launch form is taken — defaults 384 and 64: measured
+// (p3d_conv_up4.hip, above p3d_up4_shape) it wins from the 128^2 -> 256^2 layer of the backbone up, loses on underfilled launches
+// (split-K fills the chip) and on two-chunk K loops.  Read per call (tests switch them), like P3D_UP3_FUSED.
+static bool up4_applies(int N, int I, int O, int H, int W) {
+    const char* e = getenv("P3D_UP4");
+    if (e && atoi(e) == 0) return false;
+    const char* m = getenv("P3D_UP4_MIN_WGS");
+    const char* mi = getenv("P3D_UP4_MIN_I");
+    const long long min_wgs = m ? atoll(m) : 384;
+    const long long wgs = (long long)((2 * W + 59) / 60) * ((2 * H + 11) / 12) * (O / 32) * N;
+    return wgs >= min_wgs && I >= (mi ? atoi(mi) : 64);
+}
 static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
     int ks = 1;
@@ -2464,9 +2366,13 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
-    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w3 / k_modconv_w2
-    const bool up3 = wh && wsplit && ks == 3 && up == 2 && up3_applies(I, O, W);  // k_modconv_up3
-    const int ksplit = up3 ? choose_ksplit_up3(N, I, O, H, W)
+    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w3 / k_modconv_up3
+    const bool up3 = wh && wsplit && ks == 3 && up == 2 && up3_applies(I, O, W);  // k_modconv_up3 / k_modconv_up4
+    // k_modconv_up4 (round 6): transposed convolution + FIR pass + epilogue in one launch, no intermediate and no split-K — every
+    // up-sampling layer whose 8-row tiling alone gives the chip enough workgroups (the 64^2 .. 512^2 maps of the backbone and of
+    // the super-resolution); smaller maps keep the split-K form (k_modconv_up3 + reduction + FIR pass)
+    const bool up4 = up3 && (act == 0 || (alpha >= 0.0f && alpha <= 1.0f)) && up4_applies(N, I, O, H, W);
+    const int ksplit = up4 ? 1 : up3 ? choose_ksplit_up3(N, I, O, H, W)
                            : choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W, wide ? WX_TW : CONV_TW);
     // An fp32 input of a layer the pipelined kernel can run (O % 64 == 0) is first turned into the image that kernel stages from
     // (one pass, 8 bytes per value; the generator's blocks hand over images and never come here): ONE kernel does the arithmetic
@@ -2504,6 +2410,10 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     } else {  // stride-2 transposed conv into [N][O][2H+1][2W+1]: all four output phases in one launch
         p.GH = H + 1; p.GW = W + 1;
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
+        if (up4) {
+            p.y = y; p.yimg = yimg;
+            return p3d_up4_launch(p, p3d_up4_shape(N, O, H, W), st);
+        }
         if (up3) {
             dim3 g3(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + 7) / 8), p.O / 32, p.N * p.ksplit);
             if (up3_fused) {

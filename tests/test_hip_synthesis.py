@@ -710,6 +710,7 @@ def test_up_conv_with_the_fir_pass_inside_is_bit_identical(hip, monkeypatch):
         k0 = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz, weight_f16=wf0,
                   clamp=1.5 if N > 1 else None, next_styles=s1)
         out = {}
+        monkeypatch.setenv("P3D_UP4", "0")  # (round 6: k_modconv_up4 takes these shapes by default; this test pins the round-4 kernel)
         for mode in ("0", "1"):
             monkeypatch.setenv("P3D_UP3_FUSED", mode)
             flag = ops.conv_domain_flag(x.device)
@@ -720,6 +721,48 @@ def test_up_conv_with_the_fir_pass_inside_is_bit_identical(hip, monkeypatch):
         flag = ops.conv_domain_flag(x.device)
         ops.modulated_conv2d(x * 3e4, w0, s0, saturated=flag, **dict(k0, clamp=None))
         assert ops.conv_domain_violated(flag)
+
+
+@pytest.mark.parametrize("N,I,O,H", [(1, 256, 128, 128), (2, 64, 128, 88), (1, 32, 256, 128), (2, 128, 256, 64), (2, 16, 64, 40), (1, 16, 32, 72)])
+@pytest.mark.parametrize("rpw", ["0", "2"])
+def test_up4_one_launch_up_layer_equals_the_two_pass_form(hip, monkeypatch, N, I, O, H, rpw):
+    """k_modconv_up4 (round 6: transposed convolution + FIR pass + epilogue in one launch; 16 x 32 grid points per tile on eight waves
+    or 8 x 32 on four) against the round-5 form it replaces (k_modconv_up3 + k_fir4x4_img / k_fir4x4_tiled, P3D_UP4=0; shapes whose
+    round-5 launch is unsplit, so that both sum in the same order): the activation image AND the fp32 tensor BIT FOR BIT — long and
+    short K loops (1, 2, 16 chunks), batch 2 with per-sample noise and a clamp, ragged tiles (80^2, 144^2, 176^2 outputs), both tile
+    heights forced, the domain flag, fp32 and image inputs."""
+    ops = hip.ops
+    filt = ops.setup_filter([1, 3, 3, 1]).cuda()
+    g = torch.Generator().manual_seed(I + O + H)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    x, w0 = rn(N, I, H, H), rn(O, I, 3, 3)
+    s0, s1 = rn(N, I) * 0.4 + 1.0, rn(N, O) * 0.4 + 1.0
+    d0 = ((w0[None] * s0[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    wf0 = ops.conv_weights_to_f16(w0, split=True)
+    nz = rn(N, 1, 2 * H, 2 * H) * 0.1 if N > 1 else rn(2 * H, 2 * H) * 0.1
+    k0 = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz, weight_f16=wf0,
+              clamp=1.5 if N > 1 else None)
+    ximg = ops.act_to_image(x, s0)
+    monkeypatch.setenv("P3D_UP4_RPW", rpw)
+    monkeypatch.setenv("P3D_UP4_MIN_WGS", "0")
+    monkeypatch.setenv("P3D_UP4_MIN_I", "0")
+    monkeypatch.setenv("P3D_UP3_FUSED", "0")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P3D_UP4", mode)
+        flag = ops.conv_domain_flag(x.device)
+        out[mode] = (ops.modulated_conv2d(x, w0, s0, saturated=flag, next_styles=s1, **k0).data.clone(),
+                     ops.modulated_conv2d(x, w0, s0, saturated=flag, **k0).clone(),
+                     ops.modulated_conv2d(ximg, w0, None, saturated=flag, next_styles=s1, **k0).data.clone())
+        assert not ops.conv_domain_violated(flag)
+    for a, b, what in zip(out["0"], out["1"], ("image out", "fp32 out", "image in, image out")):
+        assert torch.equal(a, b), (what, N, I, O, H, rpw, float((a.float() - b.float()).abs().max()))
+    assert torch.equal(out["1"][0], out["1"][2])
+    monkeypatch.setenv("P3D_UP4", "1")
+    flag = ops.conv_domain_flag(x.device)
+    ops.modulated_conv2d(x * 3e4, w0, s0, saturated=flag, next_styles=s1, **dict(k0, clamp=None))
+    assert ops.conv_domain_violated(flag)
+    ops.modulated_conv2d(x, w0, s0, next_styles=s1, **dict(k0, noise=None, bias=None))  # (no noise, no bias: runs)
 
 
 def test_generator_blocks_use_the_activation_image(hip, monkeypatch):
