@@ -119,7 +119,8 @@ class TriPlaneGenerator(torch.nn.Module):
     def __getstate__(self):
         """Pickling / deep copies (the reference snapshots G): derived tensors and per-call state stay out."""
         state = dict(self.__dict__)
-        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo", "_conv_domain_flag", "_mapping_dicts", "_occ_consts"):
+        for k in ("_sign_cache", "_last_planes", "_inject_draws", "_sr_plan", "_ws_memo", "_conv_domain_flag", "_mapping_dicts", "_occ_consts",
+                  "_view_graphs", "_state_list"):
             if k in state:
                 state[k] = None
         return state
@@ -184,6 +185,22 @@ class TriPlaneGenerator(torch.nn.Module):
                 ray_directions = rd.permute(0, 2, 3, 1).reshape(len(ro), res * res, 3)
         else:
             assert False, "force_rays not understood"
+        opts = dict(cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, latent_injection=latent_injection,
+                    stop_level=stop_level, triplane_crop=triplane_crop, cull_clouds=cull_clouds, binarize_clouds=binarize_clouds,
+                    normalize_images=normalize_images)
+        ray_origins, ray_directions = ray_origins.contiguous(), ray_directions.contiguous()
+        self._domain_begin(ws.device)
+        ans = self._replay_view(ws, cond, ray_origins, ray_directions, res, opts, synthesis_kwargs)
+        if ans is None:
+            ans = self._synthesis_impl(ws, cond, ray_origins, ray_directions, res, **opts, **synthesis_kwargs)
+            self._domain_end()
+        return ans
+
+    def _synthesis_impl(self, ws, cond, ray_origins, ray_directions, res, cache_backbone=False, use_cached_backbone=False,
+                        latent_injection=None, stop_level=None, triplane_crop=None, cull_clouds=None, binarize_clouds=None,
+                        normalize_images=True, **synthesis_kwargs):
+        """Everything of `synthesis` that launches device work, from flat rays [N,R,3]: backbone -> renderer -> super-resolution.
+        No host read of a device value in here: the whole call can be captured into a hipGraph (`_replay_view`)."""
         N = ray_origins.shape[0]
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
@@ -202,7 +219,7 @@ class TriPlaneGenerator(torch.nn.Module):
         draws = self._inject_draws or (None, None)
         if isinstance(draws, list):  # tests: one (jitter, u) pair per renderer pass, consumed in call order
             draws = draws.pop(0)
-        feat, depth, wsum, xyz = self.renderer(planes, self.decoder, ray_origins.contiguous(), ray_directions.contiguous(),
+        feat, depth, wsum, xyz = self.renderer(planes, self.decoder, ray_origins, ray_directions,
                                                self.rendering_kwargs, triplane_crop=triplane_crop, cull_clouds=cull_clouds,
                                                binarize_clouds=binarize_clouds, jitter=draws[0], u=draws[1],
                                                per_view_clamp=many_views)
@@ -228,6 +245,133 @@ class TriPlaneGenerator(torch.nn.Module):
             ans["image"], ans["image_raw"] = torch.add(half, ans["image"], alpha=0.5), torch.add(half, ans["image_raw"], alpha=0.5)
         return ans
 
+    # ---- launch replay of a view (round 6) ------------------------------------------------------------------------
+    # A view is ~100 launches that Python needs ~2.2 ms to issue while the GPU runs them in ~2.1 ms: the interpreter is the
+    # co-bound of `generate.py`'s view loop.  Views 2 .. 16 of a subject repeat view 1's launches with other rays (and, for the
+    # next subjects, other latents and conditioning images): the second call of a kind is captured into a hipGraph and every
+    # later one replays it —
+    #   * inputs that change per call (ws, rays) are copied into the capture's own buffers;
+    #   * everything the launches read besides — parameters, parameter-derived operands, the prepared conditioning terms —
+    #     keeps its ADDRESS while its VALUES may change: derived operands are rebuilt only when a parameter version moves (then
+    #     the captures are dropped), prepared conditioning terms are updated in place (stylegan2._cond_prepared); the first view
+    #     of a subject therefore runs eagerly (it refreshes those terms) and its further views replay;
+    #   * outputs are CLONES of the capture's buffers: a caller may keep view i while view i + 1 replays.
+    # Same launches, same arithmetic, same random stream as the eager call (torch registers the device generator with the capture):
+    # bit-identical images (tests/test_hip_synthesis.py).  Off: memo.set_enabled(False) / P3D_NO_MEMO=1 (no memo layer, no replay),
+    # P3D_VIEW_REPLAY=0, or G.set_view_replay(False).  Not replayed: calls under autograd, with injected draws, latent injections,
+    # cache_backbone / use_cached_backbone, return_more.
+    _REPLAY_MAX = 4  # captures kept per generator (each owns the intermediates of a whole view)
+
+    def set_view_replay(self, state):
+        """True / False: allow / forbid the launch replay of this generator's views; None: the process default (P3D_VIEW_REPLAY)."""
+        self.__dict__["_view_replay"] = state
+        if state is False:
+            self.__dict__["_view_graphs"] = None
+        return state
+
+    def _state_tensors(self):
+        st = self.__dict__.get("_state_list")
+        if st is None:
+            st = self.__dict__["_state_list"] = [t for t in list(self.parameters()) + list(self.buffers())]
+        return st
+
+    def _apply(self, fn):  # .to() / .cuda() / .float(): every capture holds addresses of the old storage
+        self.__dict__["_view_graphs"] = None
+        self.__dict__["_state_list"] = None
+        return super()._apply(fn)
+
+    def _replay_view(self, ws, cond, ray_origins, ray_directions, res, opts, synthesis_kwargs):
+        """The view from a captured launch sequence, or None (the caller then runs it eagerly)."""
+        allowed = self.__dict__.get("_view_replay")
+        if allowed is None:
+            allowed = os.environ.get("P3D_VIEW_REPLAY", "1") != "0"
+        if not (allowed and memo.enabled() and ws.is_cuda and not torch.is_grad_enabled()) or self._inject_draws is not None \
+                or opts["latent_injection"] is not None or opts["cache_backbone"] or opts["use_cached_backbone"] \
+                or torch.cuda.is_current_stream_capturing():
+            return None
+        flags = self.__dict__.get("_conv_domain_flag")
+        if flags is not None and flags.dirty:  # the first call on new weights runs eagerly and reads the domain flag
+            return None
+        try:
+            ctens = sorted((k, v) for k, v in cond.items() if torch.is_tensor(v))
+            if len(ctens) != len(cond):
+                return None
+            from operator import attrgetter
+            pver = sum(map(attrgetter("_version"), self._state_tensors()))
+            rk = self.rendering_kwargs
+            key = (tuple(ws.shape), ws.dtype, ws.device, tuple(ray_origins.shape), ray_origins.dtype, res, opts["stop_level"], opts["triplane_crop"],
+                   opts["cull_clouds"], opts["binarize_clouds"], opts["normalize_images"], tuple(sorted(synthesis_kwargs.items())),
+                   tuple((k, tuple(v.shape), v.dtype) for k, v in ctens), pver, self.renderer.exact, bool(self.decoder.force_sigmoid),
+                   tuple(sorted((k, v) for k, v in rk.items() if isinstance(v, (int, float, str, bool, type(None))))), self.cond_mode)
+            hash(key)
+        except TypeError:  # an option that cannot be compared by value
+            return None
+        graphs = self.__dict__.get("_view_graphs")
+        if graphs is None or graphs.get("pver") != pver:  # new parameter values: derived operands move
+            graphs = self.__dict__["_view_graphs"] = {"pver": pver, "entries": {}}
+        ent = graphs["entries"].get(key)
+        sig = tuple((k, id(v), v._version) for k, v in ctens)
+        syn = self.backbone.synthesis
+        if ent is None:  # first call of this kind: eager (it also creates every lazily made constant)
+            if len(graphs["entries"]) >= self._REPLAY_MAX:
+                graphs["entries"].pop(next(iter(graphs["entries"])))
+            graphs["entries"][key] = {"graph": None, "sig": sig, "cond": [v for _, v in ctens], "failed": False}
+            return None
+        if ent["failed"]:
+            return None
+        if ent["sig"] != sig or ent.get("gen") not in (None, syn.__dict__.get("_cond_gen", 0)):
+            # another subject (or conditioning tensors written to): this call runs eagerly and refreshes the prepared terms in place;
+            # a term that had to be REPLACED invalidates the capture
+            if ent.get("gen") not in (None, syn.__dict__.get("_cond_gen", 0)):
+                ent["graph"] = None
+            ent["sig"], ent["cond"], ent["gen"] = sig, [v for _, v in ctens], None
+            return None
+        if ent["graph"] is None:
+            try:
+                self._capture_view(ent, ws, cond, ray_origins, ray_directions, res, opts, synthesis_kwargs)
+            except Exception as e:  # noqa: BLE001 — anything the capture cannot hold: stay eager for this kind of call
+                ent["failed"], ent["graph"] = True, None
+                import warnings
+                warnings.warn(f"launch replay of TriPlaneGenerator.synthesis disabled for this call signature: {type(e).__name__}: {e}", RuntimeWarning)
+                torch.cuda.synchronize()
+                return None
+            ent["gen"] = syn.__dict__.get("_cond_gen", 0)
+        ent["ws"].copy_(ws)
+        ent["ro"].copy_(ray_origins)
+        ent["rd"].copy_(ray_directions)
+        ent["graph"].replay()
+        ent["replays"] = ent.get("replays", 0) + 1
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ent["out"].items()}
+
+    def _capture_view(self, ent, ws, cond, ray_origins, ray_directions, res, opts, synthesis_kwargs):
+        ent["ws"], ent["ro"], ent["rd"] = ws.clone(), ray_origins.clone(), ray_directions.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._synthesis_impl(ent["ws"], cond, ent["ro"], ent["rd"], res, **opts, **synthesis_kwargs)
+        ent["graph"], ent["out"] = g, out
+        # what the launches read beyond the inputs and the modules' own state: the prepared conditioning terms (kept alive here)
+        ent["keep"] = list((self.backbone.synthesis.__dict__.get("_cond_cache") or {}).values())
+
+    # ---- the domain of the two-term convolutions, checked once per set of weights -----------------------------------
+    def _domain_begin(self, device):
+        if self.__dict__.get("_conv_domain_flag") is None and device.type == "cuda":
+            self.watch_conv_domain(device)
+
+    def _domain_end(self):
+        """The default convolution path (two-term f16 operands) is exact to fp32 class only for |s * x| <= 4094 and SATURATES beyond
+        (stylegan2.DEFAULT_CONV_MMA).  Nothing bounds a real checkpoint's activations (conv_clamp=None, train_eclustrousC.py:554), so
+        the first synthesis after the operands were derived from the weights — construction, load_state_dict,
+        copy_params_and_buffers — reads the generator's flag word back (one 4-byte copy, once per set of weights) and says so."""
+        flags = self.__dict__.get("_conv_domain_flag")
+        if flags is None or not (flags.dirty or os.environ.get("P3D_CHECK_CONV_DOMAIN")) or torch.cuda.is_current_stream_capturing():
+            return
+        flags.dirty = False
+        if self.conv_domain_violated():
+            self.__dict__["conv_domain_was_violated"] = True
+            import warnings
+            warnings.warn("a two-term f16 convolution met |s*x| > 4094 and saturated it: the image is WRONG — call "
+                          "G.set_conv_mma('f32') for this model (INTEGRATION.md, 'convolution operand domain')", RuntimeWarning)
+
     def sample_mixed(self, coordinates, directions, ws, cond, truncation_psi=1, truncation_cutoff=None, update_emas=False,
                      **synthesis_kwargs):
         """triplane.py:273-298 (the density-grid query of _util/eg3d_metrics3d.py:140).  The reference re-runs the backbone
@@ -236,7 +380,9 @@ class TriPlaneGenerator(torch.nn.Module):
         if reuse and self._last_planes is not None:
             planes = self._last_planes
         else:
+            self._domain_begin(ws.device)
             planes = self._planes(ws, cond, **synthesis_kwargs)
+            self._domain_end()
             self._last_planes = planes if reuse else self._last_planes
         return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
 
@@ -362,10 +508,6 @@ class TriPlaneGenerator(torch.nn.Module):
             ret["image_prepaste"] = ret["image"]
             ret["paste"] = paste_front(self, x, ret, **x["paste_params"])
             ret["image"] = ret["paste"]["image"]
-        if os.environ.get("P3D_CHECK_CONV_DOMAIN") and self.conv_domain_violated():  # validation runs (synchronises)
-            import warnings
-            warnings.warn("a two-term f16 convolution met |s*x| > 4094 and saturated it: use set_conv_mma('f32') for this model",
-                          RuntimeWarning)
         return ret
 
     def watch_conv_domain(self, device=None):
@@ -405,6 +547,8 @@ class TriPlaneGenerator(torch.nn.Module):
         weights — and the process-wide view cache.  For callers that wrote into parameters or conditioning tensors behind the
         version counter (`.data`, DLPack aliases; memo.py), and for servers that want the last subject's tensors released."""
         self.__dict__["_ws_memo"] = None
+        self.__dict__["_view_graphs"] = None
+        self.__dict__["_state_list"] = None
         self.__dict__["_mapping_dicts"] = None
         self.__dict__["_occ_consts"] = None
         self._last_planes = None

@@ -147,7 +147,8 @@ def _takes_image(layer, res):
     mode = layer.__dict__.get("mma_f16")
     if mode is None:
         mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
-    return CONV_IMG and mode == "x2" and layer.up == 1 and layer._parameters["weight"].shape[-1] == 3 and layer.in_channels % 16 == 0 and res >= IMG_MIN_RES
+    w = layer._parameters["weight"]
+    return CONV_IMG and mode == "x2" and layer.up == 1 and w.shape[-1] == 3 and res >= IMG_MIN_RES and ops.takes_image(layer.in_channels, w.shape[0], res, 1)
 
 
 def _next_conv0_styles(next_block, next_pre, res):
@@ -178,6 +179,9 @@ def _f16_operand(layer):
     d = layer.__dict__
     if d.get("_wh_key") != key or not memo.enabled():
         d["_wh"], d["_wh_key"] = ops.conv_weights_to_f16(w.detach(), split=(mode == "x2")), key
+        f = d.get("conv_domain_flag")
+        if isinstance(f, DomainFlags):  # new weights (load_state_dict, copy_params_and_buffers, an optimiser step): check their domain once
+            f.dirty = True
     return d["_wh"]
 
 
@@ -189,6 +193,7 @@ class DomainFlags:
 
     def __init__(self):
         self.words = {}
+        self.dirty = True  # operands were (re-)derived from the weights since the flag was last read: TriPlaneGenerator reads it once
 
     def get(self, device):
         device = torch.device(device)
@@ -534,13 +539,23 @@ class SynthesisNetwork(_CacheFree):
         if hit is not None and len(hit[0]) == len(tensors) and all(a is b and v == b._version for (a, v), b in zip(hit[0], tensors)):
             return hit[1]
         val = make()
+        # Round 6: a term prepared for OTHER conditioning tensors of the same shape (the next subject) is written INTO the tensor the
+        # previous subject's term lived in: the prepared terms keep their addresses, which a captured view (TriPlaneGenerator's
+        # launch replay) has baked into its launches.  A term that cannot be updated in place is replaced, and `_cond_gen` says so.
+        if hit is not None and hit[1].shape == val.shape and hit[1].dtype == val.dtype and hit[1].device == val.device \
+                and not torch.is_grad_enabled():
+            hit[1].copy_(val)
+            val = hit[1]
+        elif hit is not None:
+            self.__dict__["_cond_gen"] = self.__dict__.get("_cond_gen", 0) + 1
         cache[key] = ([(t, t._version) for t in tensors], val)
         return val
 
     def clear_cond_cache(self):
         """Drop the prepared conditioning terms (they hold strong references to the last subject's conditioning images and their
         resized copies: a long-running server calls this between subjects, or when it is done; G.to(device) does it too)."""
-        self.__dict__.pop("_cond_cache", None)
+        if self.__dict__.pop("_cond_cache", None) is not None:
+            self.__dict__["_cond_gen"] = self.__dict__.get("_cond_gen", 0) + 1
 
     def _apply(self, fn):  # .to() / .cuda() / .float(): prepared terms live on the old device
         self.clear_cond_cache()
@@ -556,7 +571,8 @@ class SynthesisNetwork(_CacheFree):
         assert not (torch.is_grad_enabled() and (x.requires_grad or img.requires_grad)), "inference only: the conditioning is applied in place"
         if res == 8 and chonkadd > 0:  # resnet "chonk" added to the first channels of the 8x8 activations (:554-560)
             k = chonkadd
-            x[:, :k].add_(cond["resnet_chonk"][:, :k])
+            chonk = cond["resnet_chonk"]
+            x[:, :k].add_(self._cond_prepared(("chonk", k), [chonk], lambda: chonk[:, :k].to(x.dtype).clone()))  # (a copy: an address that outlives the subject)
             return x, img
         interp = torch.nn.functional.interpolate
         if self.cond_mode.startswith("ortho_front."):

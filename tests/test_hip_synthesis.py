@@ -930,3 +930,81 @@ def test_osg_decoder_forward_is_the_contract_decoder(hip, oracle, tag):
         assert np.array_equal(forced["rgb"].cpu().numpy(), oracle.decode_features(feats, oracle.prescale_mlp(*raw, lr_mul=lr_mul), force_sigmoid=True)[1])
     with pytest.raises(RuntimeError):
         dec(torch.from_numpy(feats), None)  # CPU tensors: no fallback
+
+
+def _view(G, cond, azim, noise, seed=4, paste=False):
+    x = dict(seeds=[seed], cond=cond, elevations=torch.zeros(1, device="cuda"), azimuths=torch.full((1,), float(azim), device="cuda"),
+             neural_rendering_resolution=16, noise_mode=noise, triplane_crop=0.1, cull_clouds=0.5)
+    with torch.no_grad():
+        out = G.f(x)
+    return {k: out[k].clone() for k in ("image", "image_raw", "image_depth", "image_weights", "image_xyz", "triplane")}
+
+
+@pytest.mark.parametrize("noise", ["const", "random"])
+def test_view_replay_is_bit_identical_to_eager_calls(hip, noise):
+    """Round 6: the second call of a kind is captured into a hipGraph and later ones replay it
+    (TriPlaneGenerator._replay_view).  Two subjects x four views, conditioned generator: every output of every call equals the eager
+    generator's BIT FOR BIT — also under noise_mode='random' with the same torch seed (the device generator is registered with the
+    capture) —, the replays really happen (views 2 .. 4 of both subjects; the first view of subject B refreshes the prepared
+    conditioning terms in place), outputs of earlier views are not overwritten by later replays, and the switches turn it off."""
+    import p3d_testing as T
+    G = T.fill_generator_params(MC.memo_generator("cuda"), 3)  # (a volume with surfaces: the views differ)
+    G.set_render_exact(None)
+    conds = [{"image_ortho_front": torch.rand(1, 3, 32, 32, device="cuda"), "resnet_feats": torch.randn(1, 16, device="cuda")} for _ in range(2)]
+    plan = [(s, c, 30.0 * v) for s, c in ((4, conds[0]), (9, conds[1])) for v in range(4)]
+
+    def run(replay):
+        G.clear_memo()
+        G.set_view_replay(replay)
+        torch.manual_seed(123)
+        return [_view(G, c, az, noise, seed=s) for s, c, az in plan]
+
+    eager = run(False)
+    assert not G.__dict__.get("_view_graphs")
+    rep = run(True)
+    ents = list(G.__dict__["_view_graphs"]["entries"].values())
+    assert len(ents) == 1 and ents[0]["graph"] is not None and ents[0]["replays"] == 6, [(e["graph"] is not None, e.get("replays")) for e in ents]
+    for i, (a, b) in enumerate(zip(eager, rep)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k, float((a[k] - b[k]).abs().max()))
+    assert not torch.equal(rep[2]["image_depth"], rep[3]["image_depth"])  # (views differ, and view 3's tensors survived view 4's replay)
+    # in-place parameter writes drop the capture (the derived operands move); the memo switch forbids replays altogether
+    with torch.no_grad():
+        G.backbone.synthesis.b8.conv1.weight.mul_(1.25)
+    a = _view(G, conds[0], 0.0, noise)
+    assert all(e["graph"] is None for e in G.__dict__["_view_graphs"]["entries"].values())
+    prev = hip.memo.set_enabled(False)
+    try:
+        for _ in range(3):
+            _view(G, conds[0], 0.0, noise)
+        assert all(e["graph"] is None for e in (G.__dict__.get("_view_graphs") or {"entries": {}})["entries"].values())
+    finally:
+        hip.memo.set_enabled(prev)
+
+
+def test_conv_domain_is_checked_once_per_set_of_weights(hip):
+    """Round 6: nothing bounds a real checkpoint's activations (conv_clamp=None), and the default two-term f16
+    convolutions SATURATE beyond |s*x| = 4094.  A generator whose weights drive an activation out of the domain says so on the FIRST
+    call after the weights arrived (RuntimeWarning + G.conv_domain_was_violated), without any environment variable; fp32 operands
+    (set_conv_mma('f32')) run clean; in-domain weights are checked once and never again (no per-call synchronisation)."""
+    import warnings
+    G = MC.memo_generator("cuda")
+    G.set_render_exact(None)
+    cond = {"image_ortho_front": torch.rand(1, 3, 32, 32, device="cuda"), "resnet_feats": torch.randn(1, 16, device="cuda")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _view(G, cond, 0.0, "const")          # in-domain weights: checked, silent
+    flags = G.__dict__["_conv_domain_flag"]
+    assert flags.dirty is False and not G.__dict__.get("conv_domain_was_violated")
+    state = {k: v.clone() for k, v in G.state_dict().items()}
+    big = {k: (v * 3e3 if k.endswith("b16.conv0.weight") or k == "backbone.synthesis.b4.const" else v) for k, v in state.items()}
+    G.load_state_dict(big)                    # "a checkpoint": one layer's input now leaves the domain
+    with pytest.warns(RuntimeWarning, match="saturated"):
+        _view(G, cond, 0.0, "const")
+    assert G.__dict__.get("conv_domain_was_violated") and flags.dirty is False
+    G.set_conv_mma("f32")
+    G.__dict__["conv_domain_was_violated"] = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = _view(G, cond, 0.0, "const")
+    assert torch.isfinite(out["image"]).all() and not G.__dict__.get("conv_domain_was_violated")
