@@ -16,6 +16,11 @@ from . import cameras, memo, stylegan2
 from .renderer import ImportanceRenderer
 
 
+def _capturing():
+    """A hipGraph capture is underway on the current stream (False on a box without a device)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class OSGDecoder(torch.nn.Module):
     """The tiny decoder MLP (triplane.py:516-547).  The renderer evaluates it INSIDE the fused kernels (it reads the parameters
     only); `forward` keeps the module callable like the reference's, on the same device arithmetic (p3d_decode_features_f32)."""
@@ -287,7 +292,7 @@ class TriPlaneGenerator(torch.nn.Module):
             allowed = os.environ.get("P3D_VIEW_REPLAY", "1") != "0"
         if not (allowed and memo.enabled() and ws.is_cuda and not torch.is_grad_enabled()) or self._inject_draws is not None \
                 or opts["latent_injection"] is not None or opts["cache_backbone"] or opts["use_cached_backbone"] \
-                or torch.cuda.is_current_stream_capturing():
+                or _capturing():
             return None
         flags = self.__dict__.get("_conv_domain_flag")
         if flags is not None and flags.dirty:  # the first call on new weights runs eagerly and reads the domain flag
@@ -363,7 +368,7 @@ class TriPlaneGenerator(torch.nn.Module):
         the first synthesis after the operands were derived from the weights — construction, load_state_dict,
         copy_params_and_buffers — reads the generator's flag word back (one 4-byte copy, once per set of weights) and says so."""
         flags = self.__dict__.get("_conv_domain_flag")
-        if flags is None or not (flags.dirty or os.environ.get("P3D_CHECK_CONV_DOMAIN")) or torch.cuda.is_current_stream_capturing():
+        if flags is None or not (flags.dirty or os.environ.get("P3D_CHECK_CONV_DOMAIN")) or _capturing():
             return
         flags.dirty = False
         if self.conv_domain_violated():

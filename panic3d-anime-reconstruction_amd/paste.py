@@ -122,14 +122,20 @@ def paste_front_torch(G, x, out, mode="default", thresh_weight=0.95, thresh_edge
         if front_weight_erosion >= 1:  # triplane.py:644-658
             frontw = front_weights(G, x)
             fwmask = erosion((frontw > 0.5).float(), int(front_weight_erosion))
+            if len(fwmask) == 1 and len(view_xyz) > 1:  # one front-view render, V views in this call
+                fwmask = fwmask.expand(len(view_xyz), -1, -1, -1)
             fwmask = sample_orthofront(fwmask, F.interpolate(view_xyz, S, mode="bilinear"), G.rendering_kwargs["box_warp"])
             fwmask = F.interpolate(fwmask, S, mode="nearest")
         mask = wmask * smask * fmask * dmask * fwmask
-        if force_image is None:
-            tocopy = front_rgb if not x["normalize_images"] else front_rgb * 2 - 1
-        else:  # the reference takes its image wrapper (`force_image.t()[None,]`, triplane.py:667); a [C,H,W] / [1,C,H,W] tensor works too
-            t = force_image.t() if not torch.is_tensor(force_image) else force_image
-            tocopy = (t[None] if t.dim() == 3 else t).to(mask.device)
+    # the image to paste is built OUTSIDE no_grad, as the reference builds it (triplane.py:666-673): with grad_sample a gradient
+    # reaches force_image / the conditioning image through the sampling below
+    if force_image is None:
+        tocopy = front_rgb if not x["normalize_images"] else front_rgb * 2 - 1
+    else:  # the reference takes its image wrapper (`force_image.t()[None,]`, triplane.py:667); a [C,H,W] / [1,C,H,W] tensor works too
+        t = force_image.t() if not torch.is_tensor(force_image) else force_image
+        tocopy = (t[None] if t.dim() == 3 else t).to(mask.device)
+        if len(tocopy) == 1 and len(view_xyz) > 1:
+            tocopy = tocopy.expand(len(view_xyz), -1, -1, -1)
     with (contextlib.nullcontext() if grad_sample else torch.no_grad()):
         paste = sample_orthofront(tocopy, F.interpolate(view_xyz, S, mode="bilinear"), G.rendering_kwargs["box_warp"])
     return {"image": torch.lerp(out["image"], paste, mask), "paste": paste, "mask": mask, "mask_weights": wmask,

@@ -27,6 +27,25 @@ if _is_launched_rank():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def prepare_rank_env(env=None):
+    """For launchers that create ranks themselves — `torch.multiprocessing.spawn`, a process that sets RANK / MASTER_ADDR after
+    importing this package: put HSA_ENABLE_IPC_MODE_LEGACY=0 into `env` (default: os.environ, which spawned children
+    inherit) unless the user exported a value.  Call it BEFORE the first HIP call of every process that will be a rank — in the
+    parent before `spawn`, or first thing in the child; afterwards the runtime's IPC mode is fixed and only `_check_ipc_env`'s warning is
+    left.  Returns True when the variable is (now) set, False — with a RuntimeWarning — when HIP is already up in this process without it."""
+    env = os.environ if env is None else env
+    if env.get("HSA_ENABLE_IPC_MODE_LEGACY") is not None:
+        return True
+    if env is os.environ and torch.cuda.is_initialized():
+        import warnings
+        warnings.warn("panic3d_amd.sharding.prepare_rank_env: the HIP runtime of this process is already initialised without "
+                      "HSA_ENABLE_IPC_MODE_LEGACY=0; RCCL between processes will fail with 'invalid argument' on this driver — "
+                      "call prepare_rank_env() (or export the variable) before the first torch.cuda / panic3d_amd device call", RuntimeWarning, stacklevel=2)
+        return False
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return True
+
+
 def _check_ipc_env():
     """Called where a multi-rank RCCL group is first used: the IPC mode cannot be changed any more (HIP is up), so say what to do."""
     if (dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() > 1
@@ -34,7 +53,7 @@ def _check_ipc_env():
         import warnings
         warnings.warn("panic3d_amd.sharding: HSA_ENABLE_IPC_MODE_LEGACY is not set in this rank's environment; on this driver RCCL between "
                       "processes needs HSA_ENABLE_IPC_MODE_LEGACY=0 BEFORE the first HIP call (export it, start the ranks through "
-                      "sharding.ensure_ranks / torch.distributed.run, or import panic3d_amd before initialising torch.cuda in a launched rank)",
+                      "sharding.ensure_ranks / torch.distributed.run, or call sharding.prepare_rank_env() before spawning / before the first device call)",
                       RuntimeWarning, stacklevel=3)
 
 

@@ -119,6 +119,17 @@ def test_bench_default_invocation_prints_the_contract_line():
     assert p["backbone"]["GFLOP"] > 90 and p["superresolution"]["GFLOP"] > 150 and p["g_f_view"]["ms_with_paste"] > p["g_f_view_ms"] * 0.9
     assert p["c2"]["batch"] == 4 and p["c5_512"]["points"] == 512 ** 3 and p["c5_512"]["faces"] > 0
     assert "source" in p["mfma_busy_recorded"]
+    # round 6: the convolution path under the driver's clock with its own roofline object — GPU time of a pass
+    # replayed from a hipGraph, the live launch count of that capture, the fraction of the two-term MFMA peak
+    for k, max_launches in (("backbone", 45), ("superresolution", 12)):
+        r = p[k]
+        assert r["kernel_us"] > 0 and r["kernel_us"] * 1e-3 <= r["ms"] * 1.05 and 0 < r["frac_of_two_term_peak"] < 1
+        assert r["launches"] is None or 0 < r["launches"] <= max_launches, (k, r["launches"])
+        assert r["roofline"]["bound"] == "mfma" and abs(r["roofline"]["frac"] - r["frac_of_two_term_peak"]) < 1e-9
+    assert p["g_f_view"]["replayed"] is True
+    # item 8: the tolerance-mode headline beside the exact one (same scene, same K); ADVICE r05: both timing passes of a table row
+    assert d["value_tolerance"] > d["value_surface"] * 0.95 and d["ms_per_step_tolerance"] > 0
+    assert all(len(r["ms_per_step_passes"]) == 2 and min(r["ms_per_step_passes"]) == r["ms_per_step"] for r in d["results"])
 
 
 def test_bench_canonical_scene_is_still_a_switch():

@@ -1121,6 +1121,37 @@ def test_paste_front_options_generate_py_does_not_use(P, oracle, monkeypatch):
     assert float(fw1.min()) >= 0.0 and float(fw1.max()) <= 1.0 and bool((fw3 <= fw1 + 1e-6).all()) and fw3.sum() < fw1.sum()
     assert bool((er1["paste"]["mask"] <= base["paste"]["mask"]).all()) and bool((er3["paste"]["mask"] <= er1["paste"]["mask"] + 1e-6).all())
     assert torch.equal(er1["paste"]["mask"], base["paste"]["mask"] * fw1)
+    # V views in ONE call with these options — the batch-1 front-weight mask and the forced image are expanded to the V views
+    # (used to fail in grid_sample with a batch mismatch); every view equals its own single-view call
+    try:
+        with torch.no_grad():
+            x0 = mk()
+            x0["paste_params"] = None
+            G.f(x0)
+            ws = x0["ws"]
+            el, az, fv = torch.tensor([10.0, 0.0]), torch.tensor([25.0, 60.0]), torch.tensor([-1.0, 30.0])
+            for opt in (dict(force_image=other), dict(front_weight_erosion=2)):
+                torch.manual_seed(5)
+                both = G.f(dict(mk(**opt), ws=ws, elevations=el, azimuths=az, fovs=fv))
+                assert both["paste"]["mask"].shape[0] == 2 and both["paste"]["paste"].shape == (2, 3, 512, 512)
+                for v in range(2):
+                    # (the renderer's draws differ between a V-view launch and a single one: the masks agree up to a few boundary pixels)
+                    torch.manual_seed(5)
+                    one = G.f(dict(mk(**opt), ws=ws, elevations=el[v:v + 1], azimuths=az[v:v + 1], fovs=fv[v:v + 1]))
+                    assert ((both["paste"]["mask"][v:v + 1] - one["paste"]["mask"]).abs() > 1e-3).float().mean() < 8e-2, (opt.keys(), v)
+                    if "force_image" in opt:
+                        assert float((both["paste"]["paste"][v:v + 1] - one["paste"]["paste"]).abs().mean()) < 8e-2
+    finally:
+        P.cameras.cached_view_clear()
+    # ... and with grad_sample the forced image receives a gradient through the sampling (the reference builds it outside no_grad, triplane.py:666-673)
+    fi = other.clone().requires_grad_(True)
+    xg = mk()
+    with torch.no_grad():
+        out = G.f(dict(xg, paste_params=None))
+    res = paste.paste_front_torch(G, xg, out, **dict(pp, force_image=fi, grad_sample=True))
+    P.cameras.cached_view_clear()
+    res["paste"].sum().backward()
+    assert fi.grad is not None and float(fi.grad.abs().sum()) > 0
 
 
 def test_run_model_with_density_noise(P, oracle, monkeypatch):
@@ -1139,3 +1170,16 @@ def test_run_model_with_density_noise(P, oracle, monkeypatch):
     torch.manual_seed(9)
     want = quiet["sigma"] + torch.randn_like(quiet["sigma"]) * 0.5
     assert torch.equal(noisy["sigma"], want) and torch.equal(noisy["rgb"], quiet["rgb"]) and float((noisy["sigma"] - quiet["sigma"]).abs().mean()) > 0.1
+
+
+def test_prepare_rank_env_for_spawn_style_launchers(P, monkeypatch):
+    """ranks made by torch.multiprocessing.spawn (or by setting RANK after the import) do not pass through the import-time
+    hook; `sharding.prepare_rank_env()` gives them the dmabuf IPC setting RCCL needs on this driver — into os.environ (inherited by
+    spawned children) or into an environment dict — and never overrides a value the user exported."""
+    from panic3d_amd import sharding
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    env = {}
+    assert sharding.prepare_rank_env(env) is True and env == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
+    assert sharding.prepare_rank_env(env) is True and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    assert sharding.prepare_rank_env() is True and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"  # (no HIP runtime is up in the CPU suite)

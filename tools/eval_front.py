@@ -183,13 +183,27 @@ def score_subject(data, name, out, roi):
 
 def run(G, data, out, subset="front", mesh=False, limit=None, device="cuda", seed=0):
     names = read_subjects(data)[:limit]
-    per = {}
+    per, fp32_subjects = {}, []
     for name in names:
         cond, roi = load_subject(data, name, device)
+        # The default convolutions run on two-term f16 operands, exact to fp32 class for |s*x| <= 4094 and SATURATING beyond; nothing
+        # bounds a released checkpoint's activations (conv_clamp=None, train_eclustrousC.py:554).  Every subject is therefore watched:
+        # the flag word is reset before, read after, and a subject that tripped it is rendered AGAIN on fp32 operands and reported.
+        G.watch_conv_domain(device)
+        G.conv_domain_violated(reset=True)
         render_subject(G, cond, name, out, subset=subset, seed=seed, mesh=mesh, device=device)
+        if G.conv_domain_violated(reset=True):
+            G.set_conv_mma("f32")
+            try:
+                render_subject(G, cond, name, out, subset=subset, seed=seed, mesh=mesh, device=device)
+            finally:
+                G.set_conv_mma(None)
+            fp32_subjects.append(name)
         per[name] = score_subject(data, name, out, roi)
     rep = {"subjects": len(names), "subset": subset, "out": out, "per_subject": per,
-           "readme_front_psnr": README_FRONT_PSNR, "readme_source": "readme.md:83 (AnimeRecon, front)"}
+           "readme_front_psnr": README_FRONT_PSNR, "readme_source": "readme.md:83 (AnimeRecon, front)",
+           "conv_operands": {"default": "two-term f16 (fp32-class inside |s*x| <= 4094)", "subjects_rerun_on_fp32_operands": fp32_subjects,
+                             "note": "a subject listed here left the two-term domain; its files and scores come from the fp32-operand run"}}
     for view in ("front", "back"):
         vals = [p[view] for p in per.values() if view in p]
         if vals:
