@@ -147,6 +147,11 @@ def front_weights(G, x):
     dev = x["cond"]["image_ortho_front"].device
     xin = {k: v for k, v in x.items() if k not in ("paste_params", "camera_params", "conditioning_params", "force_rays")}
     xin["elevations"], xin["azimuths"], xin["fovs"] = torch.zeros(1, device=dev), torch.zeros(1, device=dev), -torch.ones(1, device=dev)
+    if "distances" in xin and len(xin["distances"]) != 1:  # V views in the caller's dict: ONE front view here, at the first view's distance
+        xin["distances"] = xin["distances"][:1]
+    for k in ("image", "image_raw", "image_depth", "image_weights", "triplane", "image_xyz", "normalize_images"):  # (the caller's outputs are not inputs)
+        xin.pop(k, None)
+    xin["normalize_images"] = x["normalize_images"]
     return G.f(xin, return_more=True)["image_weights"]
 
 

@@ -1145,9 +1145,9 @@ def test_paste_front_options_generate_py_does_not_use(P, oracle, monkeypatch):
         P.cameras.cached_view_clear()
     # ... and with grad_sample the forced image receives a gradient through the sampling (the reference builds it outside no_grad, triplane.py:666-673)
     fi = other.clone().requires_grad_(True)
-    xg = mk()
+    xg = dict(mk(), paste_params=None)
     with torch.no_grad():
-        out = G.f(dict(xg, paste_params=None))
+        out = G.f(xg)  # (fills xg's rays and camera parameters, as f() does for its caller)
     res = paste.paste_front_torch(G, xg, out, **dict(pp, force_image=fi, grad_sample=True))
     P.cameras.cached_view_clear()
     res["paste"].sum().backward()
