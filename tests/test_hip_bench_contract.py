@@ -121,7 +121,7 @@ def test_bench_default_invocation_prints_the_contract_line():
     assert "source" in p["mfma_busy_recorded"]
     # round 6: the convolution path under the driver's clock with its own roofline object — GPU time of a pass
     # replayed from a hipGraph, the live launch count of that capture, the fraction of the two-term MFMA peak
-    for k, max_launches in (("backbone", 45), ("superresolution", 12)):
+    for k, max_launches in (("backbone", 60), ("superresolution", 20)):
         r = p[k]
         assert r["kernel_us"] > 0 and r["kernel_us"] * 1e-3 <= r["ms"] * 1.05 and 0 < r["frac_of_two_term_peak"] < 1
         assert r["launches"] is None or 0 < r["launches"] <= max_launches, (k, r["launches"])

@@ -11,5 +11,6 @@ up4dbg() { timeout 600 python tools/up4_ab.py --n 20 --dbg > "$OUT/up4dbg.jsonl"
 up4ab() { timeout 600 python tools/up4_ab.py --n 30 > "$OUT/up4ab.jsonl" 2> "$OUT/up4ab.err"; cat "$OUT/up4ab.jsonl"; tail -3 "$OUT/up4ab.err"; }
 synth() { timeout 1500 python -m pytest tests/test_hip_synthesis.py -x -q ${SYNTH_K:+-k "$SYNTH_K"} > "$OUT/synth.log" 2>&1; tail -5 "$OUT/synth.log"; }
 gputests() { timeout 2400 python -m pytest tests -x -q -m gpu > "$OUT/gputests.log" 2>&1; tail -8 "$OUT/gputests.log"; }
+benchtest() { timeout 1500 python -m pytest tests/test_hip_bench_contract.py -x -q > "$OUT/benchtest.log" 2>&1; tail -8 "$OUT/benchtest.log"; }
 bench() { timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err"; }
 for step in "$@"; do echo "== $step"; $step; done
