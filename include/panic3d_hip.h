@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 8  /* 8: p3d_conv_takes_image, the convolution workspace must be 256-byte aligned; 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
+#define P3D_ABI_VERSION 9  /* 9: p3d_conv_args rgb_* (a block's ToRGB on its conv1 launch), p3d_conv_fuses_torgb, p3d_torgb_partial_bytes, p3d_torgb_combine_f32; 8: p3d_conv_takes_image, the convolution workspace must be 256-byte aligned; 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -278,11 +278,29 @@ typedef struct p3d_conv_args {
     const void* x_img;         /* the input as an activation image (already modulated by its producer), or null: then x + styles */
     void* y_img;               /* the output as an activation image for the layer that follows, or null: up = 2 INSTEAD of y (y null), up = 1 NEXT TO y */
     const float* y_img_styles; /* with y_img: that layer's styles [N][O] */
+    const float* rgb_w;        /* ABI 9, all three null or all set (only where p3d_conv_fuses_torgb says 1): the block's ToRGB weights [rgb_channels][O] ... */
+    const float* rgb_styles;   /* ... its styles [N][O], already multiplied by the layer's weight_gain (networks_stylegan2.py:377) ... */
+    float* rgb_partial;        /* ... and p3d_torgb_partial_bytes(N, O, H, W, rgb_channels) bytes that receive the ToRGB sums of this layer's result, one
+                                * share per 64-channel tile [O/64][N][rgb_channels][H][W]; p3d_torgb_combine_f32 finishes the layer.  y may then be null. */
     size_t workspace_bytes;
     int32_t N, I, H, W, O, ks, up, demodulate, noise_per_sample, act, mma;
     float alpha, gain, clamp;
+    int32_t rgb_channels;      /* ToRGB output channels (1 .. 4) with rgb_partial */
 } p3d_conv_args;
 int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
+
+/* ToRGBLayer.forward (networks_stylegan2.py:366-380) of a block with <= 4 image channels, riding on the block's conv1 launch (the
+ * super-resolution blocks: 3 channels): conv1's epilogue holds the finished activation in registers, multiplies it by the ToRGB styles
+ * (the reference's own rounding of the modulated input) and by the 1x1 weights and stores, per 64-channel tile, that tile's share of the
+ * sum — the 134 MB activation of the 512^2 block is never read back (k_torgb: 44 us) and, when nobody else reads it, never written.
+ * p3d_conv_fuses_torgb: 1 exactly when p3d_modconv2d_ex_f32 accepts rgb_* for a plain 3x3 layer of that shape (two-term operands, an
+ * activation image as input, the pipelined kernel unsplit); p3d_torgb_combine_f32 adds the shares in tile order, the bias, the clamp
+ * and the up-sampled skip image (p3d_torgb_f32's epilogue: same taps, same order): y [N][O][H][W].  The channel sum runs in another
+ * order than p3d_torgb_f32's (fp32-class agreement, not bit equality). */
+int p3d_conv_fuses_torgb(int N, int I, int O, int H, int W, int rgb_channels);
+size_t p3d_torgb_partial_bytes(int N, int O, int H, int W, int rgb_channels);
+int p3d_torgb_combine_f32(const float* partial, int tiles, int N, int O, int H, int W, const float* bias, float clamp, const float* skip,
+                          const float* skip_fir, float* y, void* stream);
 
 /* The activation IMAGE of the two-term convolution path (csrc/p3d_synthesis.hip, "activation IMAGE"): the operand of a plain 3x3
  * layer prepared by the layer in front of it — 16-byte pieces of f16 hi parts and of lo parts of 16 * s[n][c] * x[n][c][y][x], laid out

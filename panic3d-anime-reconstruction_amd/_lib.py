@@ -14,7 +14,7 @@ P3D_FLAG_PAIR16 = 16384
 P3D_FLAG_QUAD8 = 32768
 P3D_FLAG_WEIGHTS_ONLY = 65536
 P3D_MAX_S = 192
-P3D_ABI_VERSION = 8  # include/panic3d_hip.h; lib() refuses a library built for another version
+P3D_ABI_VERSION = 9  # include/panic3d_hip.h; lib() refuses a library built for another version
 
 
 class Opts(C.Structure):
@@ -42,9 +42,10 @@ class PasteArgs(C.Structure):
 class ConvArgs(C.Structure):
     """p3d_conv_args"""
     _fields_ = [(n, C.c_void_p) for n in ("x", "w", "w_f16", "styles", "demod_coefs", "noise", "bias", "fir", "y", "workspace",
-                                          "saturated", "x_img", "y_img", "y_img_styles")] + [("workspace_bytes", C.c_size_t)] + \
+                                          "saturated", "x_img", "y_img", "y_img_styles", "rgb_w", "rgb_styles", "rgb_partial")] + \
+               [("workspace_bytes", C.c_size_t)] + \
                [(n, C.c_int32) for n in ("N", "I", "H", "W", "O", "ks", "up", "demodulate", "noise_per_sample", "act", "mma")] + \
-               [(n, C.c_float) for n in ("alpha", "gain", "clamp")]
+               [(n, C.c_float) for n in ("alpha", "gain", "clamp")] + [("rgb_channels", C.c_int32)]
 
 
 P3D_CONV_MMA_F32, P3D_CONV_MMA_F16, P3D_CONV_MMA_F16X2 = 0, 1, 2
@@ -81,6 +82,9 @@ SIGNATURES = {
     "p3d_conv_takes_image": (_I, [_I, _I, _I, _I]),
     "p3d_act_image_bytes": (_Z, [_I, _I, _I, _I]),
     "p3d_act_to_image_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "p3d_conv_fuses_torgb": (_I, [_I, _I, _I, _I, _I, _I]),
+    "p3d_torgb_partial_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "p3d_torgb_combine_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "p3d_torgb_weights_f32": (_I, [_P, _I, _I, _P, _P]),
     "p3d_torgb_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P]),
     "p3d_upfirdn2d_f32": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -54,6 +54,13 @@ struct ConvParams {
     long long yimg_lo;    // = N*O*OH*OW*2
     const float* ystyles;
     const float* fir;     // k_modconv_up3<true>: the 4x4 filter of the FIR pass it contains (flipped, times up^2)
+    // k_modconv_w3<true> only: the block's ToRGB layer (networks_stylegan2.py:366-380, <= 4 output channels) applied to the result in
+    // the epilogue — each 64-channel workgroup adds its channels' share into rgbp [O/64][N][rgbo][H][W] (p3d_torgb_combine_f32 sums
+    // the shares, adds the bias and the up-sampled skip image); y may then be null (nobody reads the fp32 activation)
+    const float* rgbw;    // [rgbo][O] ToRGB weights
+    const float* rgbs;    // [N][O] ToRGB styles (already multiplied by the layer's weight_gain)
+    float* rgbp;
+    int rgbo;
 };
 
 DEV float act_apply(float v, int act, float alpha, float gain, float clamp) {

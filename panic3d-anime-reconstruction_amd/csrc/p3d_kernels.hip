@@ -2084,11 +2084,12 @@ int p3d_struct_layout(int which, size_t* out, int cap) {
         P3D_OFF(p3d_conv_args, x); P3D_OFF(p3d_conv_args, w); P3D_OFF(p3d_conv_args, w_f16); P3D_OFF(p3d_conv_args, styles);
         P3D_OFF(p3d_conv_args, demod_coefs); P3D_OFF(p3d_conv_args, noise); P3D_OFF(p3d_conv_args, bias); P3D_OFF(p3d_conv_args, fir);
         P3D_OFF(p3d_conv_args, y); P3D_OFF(p3d_conv_args, workspace); P3D_OFF(p3d_conv_args, saturated); P3D_OFF(p3d_conv_args, x_img);
-        P3D_OFF(p3d_conv_args, y_img); P3D_OFF(p3d_conv_args, y_img_styles); P3D_OFF(p3d_conv_args, workspace_bytes);
+        P3D_OFF(p3d_conv_args, y_img); P3D_OFF(p3d_conv_args, y_img_styles);
+        P3D_OFF(p3d_conv_args, rgb_w); P3D_OFF(p3d_conv_args, rgb_styles); P3D_OFF(p3d_conv_args, rgb_partial); P3D_OFF(p3d_conv_args, workspace_bytes);
         P3D_OFF(p3d_conv_args, N); P3D_OFF(p3d_conv_args, I); P3D_OFF(p3d_conv_args, H); P3D_OFF(p3d_conv_args, W); P3D_OFF(p3d_conv_args, O);
         P3D_OFF(p3d_conv_args, ks); P3D_OFF(p3d_conv_args, up); P3D_OFF(p3d_conv_args, demodulate); P3D_OFF(p3d_conv_args, noise_per_sample);
         P3D_OFF(p3d_conv_args, act); P3D_OFF(p3d_conv_args, mma);
-        P3D_OFF(p3d_conv_args, alpha); P3D_OFF(p3d_conv_args, gain); P3D_OFF(p3d_conv_args, clamp);
+        P3D_OFF(p3d_conv_args, alpha); P3D_OFF(p3d_conv_args, gain); P3D_OFF(p3d_conv_args, clamp); P3D_OFF(p3d_conv_args, rgb_channels);
         break;
     default:
         return P3D_E_RANGE;

@@ -814,6 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w2(ConvParams p) {
 #define W3_EPI (W3_WBYTES + 2 * W3_PATCH)
 #define W3_LDS (W3_EPI + 768)
 
+template <bool RGB>
 __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[W3_LDS];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
@@ -836,6 +837,15 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
         epi[tid] = (p.epilogue && p.dcoef) ? p.dcoef[(size_t)n * p.O + ch] * HX_SPLIT_UNSCALE : HX_SPLIT_UNSCALE;
         epi[64 + tid] = (p.epilogue && p.bias) ? p.bias[ch] : 0.0f;
         epi[128 + tid] = p.yimg ? p.ystyles[(size_t)n * p.O + ch] : 0.0f;
+    }
+    // RGB: the ToRGB styles and weights of this workgroup's 64 channels, requested here, staged in LDS after the K loop
+    float rgb_s = 0.0f, rgb_w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (RGB) {
+        if (tid < 64) {
+            rgb_s = p.rgbs[(size_t)n * p.O + o0 + tid];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rgb_w[o] = o < p.rgbo ? p.rgbw[(size_t)o * p.O + o0 + tid] : 0.0f;
+        }
     }
     // ---- DMA plans.  Patch: wave w owns sub-image w = (hi|lo, k half); item = (row, column) of the 10 x 34 patch
     const int sub_which = wave >> 1, sub_kh = wave & 1;
@@ -950,6 +960,17 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
         }
     }
     W3_VMWAIT(0);  // nothing may land in LDS after this workgroup has given it back
+    // RGB: the ToRGB constants go into the patch buffer the last chunk read — every wave is past the loop's last barrier, i.e. done
+    // reading it, and none of the requests still in flight (zeros for the chunk after the last) targets it
+    float* rgbc = reinterpret_cast<float*>(lds + W3_WBYTES + ((nch + 1) & 1) * W3_PATCH);  // [5][64]: styles, weights of 4 channels
+    if constexpr (RGB) {
+        if (tid < 64) {
+            rgbc[tid] = rgb_s;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rgbc[64 + 64 * o + tid] = rgb_w[o];
+        }
+        __syncthreads();
+    }
     // ---- epilogue (branch-free): v = act((acc * d * 2^-10 + noise) + bias) * gain, clamped; raw partials: d = 2^-10, the rest neutral
     const bool ep = p.epilogue != 0;
     const float alpha = (ep && p.act == 1) ? p.alpha : 1.0f, gain = ep ? p.gain : 1.0f;
@@ -984,11 +1005,19 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
         ioff[b] = (gy < p.GH && gx < p.GW) ? ((o0 >> 3) * OHW + gy * p.OW + gx) * 16 + 8 * half : CONV_OOB;
     }
     bool bad = false;
+    const bool wy = !RGB || p.y != nullptr;  // (uniform)
+    float rgba[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};  // RGB: [row][ToRGB channel], this lane's 32 channels
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const f32x4 d4 = dq[(a * 32 + 8 * r4) >> 2], b4 = bq[(a * 32 + 8 * r4) >> 2], s4 = sq[(a * 32 + 8 * r4) >> 2];
+            f32x4 ts4, tw4[4];
+            if constexpr (RGB) {
+                ts4 = *reinterpret_cast<const f32x4*>(rgbc + a * 32 + 8 * r4 + 4 * half);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) tw4[o] = *reinterpret_cast<const f32x4*>(rgbc + 64 + 64 * o + a * 32 + 8 * r4 + 4 * half);
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float vv[4];
@@ -1001,7 +1030,12 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
                     v = v * gain;
                     v = __builtin_fminf(__builtin_fmaxf(v, -cl), cl);
                     vv[e] = v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[b], (a * 32 + 8 * r4 + e) * OHW * 4, 0);
+                    if (wy) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, yoff[b], (a * 32 + 8 * r4 + e) * OHW * 4, 0);
+                    if constexpr (RGB) {  // ToRGB's modulated input s * x (its own rounding, networks_stylegan2.py:68), then the 1x1 weights
+                        const float m = ts4[e] * v;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) rgba[b][o] = __builtin_fmaf(tw4[o][e], m, rgba[b][o]);
+                    }
                 }
                 if (wimg) {
                     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1020,8 +1054,22 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lv), ril, ioff[b], so, 0);
                 }
             }
+            if constexpr (RGB) __builtin_amdgcn_sched_barrier(0);  // (the ToRGB constants of one channel group at a time: hoisted together they filled the register file)
         }
     if (wimg && bad && p.sat) atomicOr(p.sat, 1u);
+    if constexpr (RGB) {
+        // the two channel halves of a pixel sit on lanes j and j + 32: lane (half, j) finishes row `half` of the wave's pair (it sends
+        // its share of the other row to its partner: a + b == b + a, so both rows are summed in the same order) and stores the
+        // workgroup's share of the ToRGB sum; p3d_torgb_combine_f32 adds the channel tiles in tile order
+        const int gy = gy0 + prow + half;
+        float* dst = p.rgbp + (((size_t)wo.otile * p.N + n) * p.rgbo) * OHW + (size_t)gy * p.OW + gx;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float other = half ? rgba[0][o] : rgba[1][o], own = half ? rgba[1][o] : rgba[0][o];
+            const float got = __shfl_xor(other, 32, 64);
+            if (o < p.rgbo && gy < p.GH && gx < p.GW) dst[(size_t)o * OHW] = own + got;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1684,6 +1732,39 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
     }
 }
 
+// The second half of a ToRGB layer whose channel sums came out of its conv1's epilogue (k_modconv_w3<true>): the shares of the
+// 64-channel tiles added in tile order, + bias, clamp, + the up-sampled skip image (k_torgb's epilogue: the same four polyphase taps in
+// the same order).  part [tiles][N][O][H][W]; one thread per output value.
+__global__ __launch_bounds__(256) void k_torgb_combine(const float* __restrict__ part, int tiles, int N, int O, int H, int W,
+                                                       const float* __restrict__ bias, float clamp, const float* __restrict__ skip,
+                                                       const float* __restrict__ skipf, float* __restrict__ y) {
+    const long long slice = (long long)N * O * H * W, idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= slice) return;
+    const int HW = H * W, px = (int)(idx % HW), o = (int)((idx / HW) % O);
+    const long long no = idx / HW;
+    float v = part[idx];
+    for (int t = 1; t < tiles; ++t) v += part[(size_t)t * slice + idx];
+    if (bias) v = v + bias[o];
+    v = act_apply(v, 0, 0.0f, 1.0f, clamp);
+    if (skip) {
+        const int Y = px / W, X = px - Y * W, H2 = H >> 1, W2 = W >> 1;
+        const float* sk = skip + no * (H2 * W2);
+        const int fy0 = Y & 1, fx0 = X & 1;
+        float up = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int fy = fy0 + 2 * a, fx = fx0 + 2 * b;
+                const int u = (Y + fy - 2) >> 1, w = (X + fx - 2) >> 1;
+                const bool in = u >= 0 && u < H2 && w >= 0 && w < W2;
+                up = __builtin_fmaf(in ? skipf[fy * 4 + fx] : 0.0f, sk[in ? u * W2 + w : 0], up);
+            }
+        v = up + v;
+    }
+    y[idx] = v;
+}
+
 // ToRGB weights [O][I] -> [I][OP] (transposed, channels padded with zeros to OP = 32 or 96), once per layer
 __global__ void k_torgb_weights(const float* __restrict__ w, int O, int I, int OP, float* __restrict__ wt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2229,7 +2310,10 @@ static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
     if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
         dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-        if (p.ximg && p.O % 64 == 0 && !env_no_w3()) hipLaunchKernelGGL(k_modconv_w3, gw, dim3(256), 0, st, p);
+        if (p.ximg && p.O % 64 == 0 && !env_no_w3()) {
+            if (p.rgbp) hipLaunchKernelGGL(k_modconv_w3<true>, gw, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(k_modconv_w3<false>, gw, dim3(256), 0, st, p);
+        }
         else if (p.ximg) hipLaunchKernelGGL(k_modconv_w2<true>, gw, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_modconv_w2<false>, gw, dim3(256), 0, st, p);
         return;
@@ -2299,7 +2383,20 @@ static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     return ks;
 }
 
+static bool rgb_fusable(int N, int I, int O, int H, int W, int rgbo) {
+    return rgbo >= 1 && rgbo <= 4 && I % 16 == 0 && O % 64 == 0 && W >= WX_TW && !env_no_w3() && !getenv("P3D_NO_RGB_FUSE") &&
+           choose_ksplit(N, I, O, H, W, WX_TW) == 1;
+}
+
 extern "C" {
+
+int p3d_conv_fuses_torgb(int N, int I, int O, int H, int W, int rgb_channels) {
+    if (N <= 0 || I <= 0 || O <= 0 || H <= 0 || W <= 0) return 0;
+    return rgb_fusable(N, I, O, H, W, rgb_channels) ? 1 : 0;
+}
+size_t p3d_torgb_partial_bytes(int N, int O, int H, int W, int rgb_channels) {
+    return (size_t)(O / 64) * N * rgb_channels * H * W * 4;
+}
 
 size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) {
     size_t b = (size_t)N * O * 4 + 256;  // demodulation coefficients
@@ -2328,14 +2425,26 @@ int p3d_conv_takes_image(int I, int O, int W, int up) {
     return 0;
 }
 
+// the block's ToRGB layer riding on its conv1 launch (p3d_conv_args.rgb_*)
+struct RgbFuse { const float* w; const float* styles; float* partial; int channels; };
+
+// The launch that takes the ToRGB layer along: the pipelined plain 3x3 kernel, unsplit (the activation image as input is the caller's
+// business: it is asked for p3d_conv_takes_image as well)
+static bool rgb_fusable(int N, int I, int O, int H, int W, int rgbo);
+
 static int modconv_impl(const float* x, int N, int I, int H, int W, const float* w, const void* wh, int wsplit, int O, int ks,
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                         size_t workspace_bytes, void* stream, unsigned int* sat = nullptr, const void* ximg = nullptr,
-                        void* yimg = nullptr, const float* ystyles = nullptr) {
-    if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg) || (y && yimg && up == 2) || (!y && up == 1) || !workspace || N <= 0 || I <= 0 || O <= 0 ||
-        H <= 0 || W <= 0)
+                        void* yimg = nullptr, const float* ystyles = nullptr, const RgbFuse* rgb = nullptr) {
+    if (rgb && !rgb->partial) rgb = nullptr;
+    if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg && !rgb) || (y && yimg && up == 2) || (!y && up == 1 && !rgb) || !workspace || N <= 0 ||
+        I <= 0 || O <= 0 || H <= 0 || W <= 0)
         return P3D_E_ARG;
+    if (rgb) {
+        if (!rgb->w || !rgb->styles) return P3D_E_ARG;
+        if (up != 1 || ks != 3 || !ximg || !wh || !wsplit || !rgb_fusable(N, I, O, H, W, rgb->channels)) return P3D_E_RANGE;
+    }
     if (ximg) {  // an image input (already modulated by its producer): the pipelined two-term kernels; demodulation must be precomputed
         if (!wh || !wsplit || (demodulate && !dcoef_in)) return P3D_E_ARG;
         if (ks != 3 || I % 16 != 0 || ((uintptr_t)ximg & 15)) return P3D_E_RANGE;
@@ -2389,6 +2498,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
     p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2; p.tox = up == 2 ? 1 : 0;
+    p.rgbw = rgb ? rgb->w : nullptr; p.rgbs = rgb ? rgb->styles : nullptr; p.rgbp = rgb ? rgb->partial : nullptr; p.rgbo = rgb ? rgb->channels : 0;
     static const bool xcd_order = !getenv("P3D_NO_XCD_ORDER");  // (A/B runs)
     p.xcd = xcd_order ? 1 : 0;
     // up = 1 with an image output: k_modconv_w3 writes it from its epilogue when it runs unsplit; otherwise a pass over y below
@@ -2518,9 +2628,10 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* a, void* stream) {
         wh = a->w_f16;
     }
     if (a->x_img && !wsplit) return P3D_E_RANGE;
+    const RgbFuse rgb = {a->rgb_w, a->rgb_styles, a->rgb_partial, a->rgb_channels};
     return modconv_impl(a->x, a->N, a->I, a->H, a->W, a->w, wh, wsplit, a->O, a->ks, a->styles, a->demodulate, a->demod_coefs, a->noise,
                         a->noise_per_sample, a->bias, a->up, a->act, a->alpha, a->gain, a->clamp, a->fir, a->y, a->workspace, a->workspace_bytes,
-                        stream, (wsplit || a->y_img) ? (unsigned int*)a->saturated : nullptr, a->x_img, a->y_img, a->y_img_styles);
+                        stream, (wsplit || a->y_img) ? (unsigned int*)a->saturated : nullptr, a->x_img, a->y_img, a->y_img_styles, &rgb);
 }
 
 size_t p3d_act_image_bytes(int N, int C, int H, int W) { return (size_t)N * C * H * W * 4; }
@@ -2574,6 +2685,17 @@ int p3d_torgb_f32(const float* x, int N, int I, int H, int W, const float* w_t, 
     if (MT == 1) { if (ks) P3D_TORGB(1, true); else P3D_TORGB(1, false); }
     else if (ms) hipLaunchKernelGGL((k_torgb<1, true, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else { if (ks) P3D_TORGB(3, true); else P3D_TORGB(3, false); }
+    return chk();
+}
+
+int p3d_torgb_combine_f32(const float* partial, int tiles, int N, int O, int H, int W, const float* bias, float clamp, const float* skip,
+                          const float* skip_fir, float* y, void* stream) {
+    if (!partial || !y || tiles <= 0 || N <= 0 || O <= 0 || H <= 0 || W <= 0 || (skip && !skip_fir)) return P3D_E_ARG;
+    if (skip && ((H | W) & 1)) return P3D_E_RANGE;
+    const long long total = (long long)N * O * H * W;
+    if (total * tiles >= (1ll << 40)) return P3D_E_RANGE;
+    hipLaunchKernelGGL(k_torgb_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, tiles, N, O, H, W, bias,
+                       clamp, skip, skip_fir, y);
     return chk();
 }
 

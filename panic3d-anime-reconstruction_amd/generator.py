@@ -79,9 +79,10 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
         pre = plan(ws, memo_of=ws_in)
         # block0.conv1 hands block1.conv0 its operand (an activation image next to the fp32 tensor ToRGB reads): no conversion pass
         ns = stylegan2._next_conv0_styles(self.block1, pre["block1"], self.block0.resolution)
-        out = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], next_styles=ns, **block_kwargs)
+        # (neither block's fp32 activation is read by anybody once block1 takes the image and ToRGB rides on conv1: need_x=False)
+        out = self.block0(x.contiguous(), rgb.contiguous(), ws, pre=pre["block0"], next_styles=ns, need_x=ns is None, **block_kwargs)
         x, rgb, x_image = out if ns is not None else (out[0], out[1], None)
-        x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], x_image=x_image, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, pre=pre["block1"], x_image=x_image, need_x=False, **block_kwargs)
         return rgb
 
     def __getstate__(self):

@@ -649,6 +649,42 @@ def torgb(x, weight_t, out_channels, styles, bias=None, clamp=None, skip=None, s
     return y
 
 
+_FUSES_TORGB = {}
+
+
+def conv_fuses_torgb(N, I, O, H, W, rgb_channels):
+    """The LIBRARY's rule (p3d_conv_fuses_torgb) for when a plain 3x3 layer of this shape takes its block's ToRGB layer along
+    (modulated_conv2d(..., rgb_weight=, rgb_styles=)); asked, not restated; memoised like takes_image."""
+    key = (int(N), int(I), int(O), int(H), int(W), int(rgb_channels))
+    r = _FUSES_TORGB.get(key)
+    if r is None:
+        r = _FUSES_TORGB[key] = bool(_lib.lib().p3d_conv_fuses_torgb(*key))
+    return r
+
+
+def torgb_combine(partial, bias=None, clamp=None, skip=None, skip_filter=None):
+    """The second half of a ToRGB layer whose channel sums came out of conv1's launch (modulated_conv2d(..., rgb_weight=...)):
+    partial [tiles,N,O,H,W] -> `upsample2d(skip, skip_filter) + (sum over tiles + bias)` [N,O,H,W] (p3d_torgb_combine_f32)."""
+    partial = _chk(partial, "partial")
+    T, N, O, H, W = partial.shape
+    if bias is not None:
+        bias = _chk(bias, "bias")
+    skipf = None
+    if skip is not None:
+        skip = _chk(skip, "skip")
+        if tuple(skip.shape) != (N, O, H // 2, W // 2) or H % 2 or W % 2:
+            raise RuntimeError("skip must be [N,O,H/2,W/2] (the previous block's image)")
+        skipf = prepared_filter(skip_filter, partial.device, 4.0, False)
+        if tuple(skipf.shape) != (4, 4):
+            raise NotImplementedError("skip_filter must be the 4x4 [1,3,3,1] filter")
+    y = torch.empty((N, O, H, W), dtype=torch.float32, device=partial.device)
+    with _on(partial.device):
+        rc = _lib.lib().p3d_torgb_combine_f32(_p(partial), T, N, O, H, W, _p(bias), float(clamp if clamp is not None else -1), _p(skip),
+                                              _p(skipf), _p(y), _stream())
+    _lib.check(rc, "p3d_torgb_combine_f32")
+    return y
+
+
 def conv_weights_to_f16(weight, split=False):
     """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer); split: the
     [2,O,k*k,I] hi / lo pair of the two-term variant (hi = f16(w), lo = f16(w - hi))."""
@@ -763,7 +799,7 @@ def act_to_image(x, styles=None, saturated=None):
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
                      bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None,
-                     next_styles=None):
+                     next_styles=None, rgb_weight=None, rgb_styles=None, want_y=True):
     """modulated_conv2d (networks_stylegan2.py:40-97) FUSED with the bias_act that follows it in SynthesisLayer.forward
     (:350-352) / ToRGBLayer.forward (:379).  Supported shapes are the generator's: 3x3 / padding 1 / up 1 or 2, and 1x1.
     noise: None, [H,W] (noise_const * strength) or [N,1,H,W] (random * strength).
@@ -772,7 +808,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     (conv_weights_to_f16(split=True)) selects the two-term variant: fp32-class results on the f16 matrix cores; `saturated`: an
     int32 [1] device tensor of the caller (conv_domain_flag) that the two-term kernels OR with 1 when |s*x| > 4094.
     x may be an ActImage (3x3, up 1, two-term weights, dcoef given: styles are already in it).  next_styles [N,O] (up 2 only):
-    return the result as the ActImage of a following layer with those styles instead of an fp32 tensor."""
+    return the result as the ActImage of a following layer with those styles instead of an fp32 tensor.
+    rgb_weight [R<=4,O] + rgb_styles [N,O] (plain 3x3 layer with an ActImage input, only where conv_fuses_torgb(...) says so): the
+    block's ToRGB layer rides on this launch — the call returns (y, image or None, partial [O/64,N,R,H,W]) and torgb_combine(partial,
+    ...) finishes the ToRGB layer; want_y=False: y is not written (None is returned in its place)."""
     ximg = x if isinstance(x, ActImage) else None
     if ximg is not None:
         if up == 2 and not takes_image_up(ximg.shape[1], weight.shape[0], ximg.shape[3]):
@@ -817,7 +856,17 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
         if tuple(next_styles.shape) != (N, O) or kh != 3:
             raise RuntimeError("next_styles [N,O] goes with a 3x3 layer")
     both = out_image and up == 1  # a plain layer writes the image NEXT TO the fp32 result (ToRGB reads the one, the next conv0 the other)
-    y = None if (out_image and not both) else torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=dev_)
+    rgb = rgb_weight is not None
+    rgbp = None
+    if rgb:
+        rgb_weight, rgb_styles = _chk(rgb_weight, "rgb_weight"), _chk(rgb_styles, "rgb_styles")
+        R = rgb_weight.shape[0]
+        if ximg is None or up != 1 or kh != 3 or tuple(rgb_weight.shape) != (R, O) or tuple(rgb_styles.shape) != (N, O) \
+                or not conv_fuses_torgb(N, I, O, H, W, R):
+            raise RuntimeError("modulated_conv2d: rgb_weight [R,O] / rgb_styles [N,O] go with a plain 3x3 layer fed by an ActImage whose "
+                               "shape conv_fuses_torgb accepts")
+        rgbp = torch.empty((O // 64, N, R, H, W), dtype=torch.float32, device=dev_)
+    y = None if ((out_image and not both) or (rgb and not want_y)) else torch.empty((N, O, H * up, W * up), dtype=torch.float32, device=dev_)
     yimg = ActImage.empty(N, O, H * up, W * up, dev_) if out_image else None
     L = _lib.lib()
     mma = _lib.P3D_CONV_MMA_F32
@@ -841,6 +890,11 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
                           fir.data_ptr() if fir is not None else None, y.data_ptr() if y is not None else None, ws.data_ptr(),
                           saturated.data_ptr() if (saturated is not None and (mma == _lib.P3D_CONV_MMA_F16X2 or yimg is not None)) else None,
                           ximg.data.data_ptr() if ximg is not None else None, yimg.data.data_ptr() if yimg is not None else None,
-                          next_styles.data_ptr() if yimg is not None else None, ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv)
+                          next_styles.data_ptr() if yimg is not None else None,
+                          rgb_weight.data_ptr() if rgb else None, rgb_styles.data_ptr() if rgb else None, rgbp.data_ptr() if rgb else None,
+                          ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv,
+                          int(rgb_weight.shape[0]) if rgb else 0)
         _lib.check(L.p3d_modconv2d_ex_f32(C.byref(a), _stream()), "p3d_modconv2d_ex_f32")
+    if rgb:
+        return y, yimg, rgbp
     return (y, yimg) if both else (yimg if out_image else y)

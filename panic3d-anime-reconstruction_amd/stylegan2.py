@@ -125,6 +125,10 @@ CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
 # (the pass timings of tools/bench_backbone.py, graph_backbone.py, profile_backbone.py are taken that way).
 STYLE_MEMO = os.environ.get("P3D_STYLE_MEMO", "1") != "0"
 IMG_MIN_RES = 32
+# A block of <= 4 image channels (the super-resolution's) computes its ToRGB sums in conv1's epilogue (ops.conv_fuses_torgb): the
+# activation is not read back — and not written when nobody else reads it.  fp32-class agreement with the stand-alone ToRGB launch
+# (another summation order); P3D_TORGB_RIDES=0 for A/B runs.
+TORGB_RIDES = os.environ.get("P3D_TORGB_RIDES", "1") != "0"
 # noise_mode='random': one draw per pass for all layers (NoisePool) instead of one per layer.  The pool consumes the device generator
 # in ONE randn call per pass, so under a fixed torch seed the noise VALUES differ from the reference's call-for-call sequence (same
 # distribution; INTEGRATION.md "seed compatibility").  Switches, all read at call time: P3D_NOISE_POOL=0 in the environment (the
@@ -234,11 +238,14 @@ class SynthesisLayer(_CacheFree):
             self._noise_cache = hit
         return hit[1]
 
-    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None, next_styles=None, noise_pool=None):
+    def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1, pre=None, next_styles=None, noise_pool=None, rgb=None,
+                want_y=True):
         """pre: (styles [N,I], demodulation coefficients [N,O]) already computed by a StylePlan for this layer, or None.
         x: fp32 [N,I,H,W], or the ops.ActImage the previous layer prepared for this one (its styles are in it).
         next_styles (up-sampling layers): return the ops.ActImage of the following layer, whose styles these are.
-        noise_pool: a NoisePool of the enclosing network — this layer's random noise is its next slice of ONE draw per pass."""
+        noise_pool: a NoisePool of the enclosing network — this layer's random noise is its next slice of ONE draw per pass.
+        rgb: (ToRGB weights [R,O], ToRGB styles [N,O]) — the block's ToRGB layer rides on this launch (ops.modulated_conv2d's
+        rgb_weight / rgb_styles: returns (y, image, partial)); want_y=False: the fp32 result is not written."""
         assert noise_mode in ["random", "const", "none"]
         styles, dcoef = pre if pre is not None else (self.affine(w), None)
         noise = None
@@ -251,10 +258,11 @@ class SynthesisLayer(_CacheFree):
             noise = self._const_noise()
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         prm = self._parameters
+        ride = {} if rgb is None else dict(rgb_weight=rgb[0], rgb_styles=rgb[1], want_y=want_y)
         return ops.modulated_conv2d(x, prm["weight"], styles, noise=noise, up=self.up, padding=self.padding,
                                     resample_filter=self._buffers["resample_filter"], demodulate=True, bias=prm["bias"],
                                     act=self.activation, gain=self.act_gain * gain, clamp=clamp, weight_f16=_f16_operand(self),
-                                    saturated=_domain_flag(self, x.device), dcoef=dcoef, next_styles=next_styles)
+                                    saturated=_domain_flag(self, x.device), dcoef=dcoef, next_styles=next_styles, **ride)
 
 
 class NoisePool:
@@ -319,6 +327,21 @@ class ToRGBLayer(_CacheFree):
         y = ops.modulated_conv2d(x, weight, styles, demodulate=False, bias=bias, act="linear", gain=1.0,
                                  clamp=self.conv_clamp, weight_f16=_f16_operand(self), saturated=_domain_flag(self, x.device))
         return ops.upsample2d_add(skip, skip_filter, y) if skip is not None else y
+
+
+def _torgb_rides(block, x, pre):
+    """(weights [R,O], styles [N,O]) when `block`'s ToRGB layer can ride on its conv1 launch (ops.conv_fuses_torgb: an image-fed
+    plain 3x3 layer on the pipelined kernel, <= 4 image channels — the super-resolution blocks), else None.  x: conv1's input."""
+    if not (CONV_IMG and TORGB_RIDES and isinstance(x, ops.ActImage)):
+        return None
+    t = block._modules["torgb"]
+    tw = t._parameters["weight"]
+    if tw.shape[0] > 4 or tw.shape[-1] != 1 or t.__dict__.get("mma_f16") or pre.get("torgb") is None:
+        return None
+    N, I, H, W = x.shape
+    if H % 2 or W % 2 or not ops.conv_fuses_torgb(N, I, block._modules["conv1"].out_channels, H, W, tw.shape[0]):
+        return None
+    return tw.detach().reshape(tw.shape[0], tw.shape[1]), pre["torgb"][0]
 
 
 class StylePlan:
@@ -466,12 +489,14 @@ class SynthesisBlock(torch.nn.Module):
         self.num_torgb += 1
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, pre=None, x_image=None, next_styles=None,
-                **layer_kwargs):
+                need_x=True, **layer_kwargs):
         """pre: {layer name: (styles, demod coefficients)} from a StylePlan (all affine layers of the network in one GEMM),
         or None: every layer runs its own affine like the reference (networks_stylegan2.py:342,377).
         x_image: x as the ops.ActImage the previous block's conv1 wrote for this block's conv0 (then x itself is not read by conv0);
         next_styles: the styles of the NEXT block's conv0 -> conv1 also writes its result as that layer's image and the block returns
-        (x, img, image) instead of (x, img)."""
+        (x, img, image) instead of (x, img).
+        need_x=False: the caller does not read the returned fp32 x (the next block takes the image, or this is the last block) — where
+        the ToRGB layer rides on conv1's launch (_torgb_rides) x is then not written and None is returned in its place."""
         w_iter = iter(ws.unbind(dim=1))
         pre = pre or {}
         if self.in_channels == 0:
@@ -486,6 +511,18 @@ class SynthesisBlock(torch.nn.Module):
             img_ok = p1 is not None and p1[1] is not None and _takes_image(self.conv1, self.resolution) and self.conv1.in_channels % 8 == 0
             x0 = x_image if (x_image is not None and pre.get("conv0") is not None and pre["conv0"][1] is not None) else x.to(torch.float32)
             x = self.conv0(x0, next(w_iter), pre=pre.get("conv0"), next_styles=p1[0] if img_ok else None, **layer_kwargs)
+            rides = _torgb_rides(self, x, pre)
+            if rides is not None:  # ToRGB's channel sums from conv1's epilogue, finished by one small launch
+                hand = next_styles if isinstance(x, ops.ActImage) else None
+                x, x_next, part = self.conv1(x, next(w_iter), pre=p1, next_styles=hand, rgb=rides, want_y=need_x or (next_styles is not None and hand is None),
+                                             **layer_kwargs)
+                next(w_iter)
+                t = self._modules["torgb"]
+                img = ops.torgb_combine(part, bias=t._parameters["bias"], clamp=t.conv_clamp, skip=None if img is None else img.to(torch.float32),
+                                        skip_filter=self._buffers["resample_filter"])
+                if next_styles is not None:
+                    return x, img, x_next
+                return x, img
             if next_styles is not None and isinstance(x, ops.ActImage):  # conv1 takes an image (the pipelined kernel) and hands one on
                 x, x_next = self.conv1(x, next(w_iter), pre=p1, next_styles=next_styles, **layer_kwargs)
             else:

@@ -1008,3 +1008,66 @@ def test_conv_domain_is_checked_once_per_set_of_weights(hip):
         warnings.simplefilter("error")
         out = _view(G, cond, 0.0, "const")
     assert torch.isfinite(out["image"]).all() and not G.__dict__.get("conv_domain_was_violated")
+
+
+@pytest.mark.parametrize("N,I,O,H,R,hand", [(1, 128, 128, 64, 3, False), (2, 64, 128, 32, 3, True), (1, 256, 256, 96, 4, True), (1, 64, 64, 40, 1, False)])
+def test_torgb_riding_on_conv1_equals_the_stand_alone_torgb(hip, N, I, O, H, R, hand):
+    """Round 6: a block of <= 4 image channels computes its ToRGB sums in conv1's epilogue (k_modconv_w3<true>) and finishes them with
+    p3d_torgb_combine_f32.  Against the stand-alone ToRGB launch on conv1's fp32 result: the same products, another summation order
+    (fp32-class: 1e-5 of the image's scale); conv1's own outputs (fp32 tensor, handed-over image) must not change by a bit, and the
+    launch that is told nobody reads the fp32 tensor must return the same sums."""
+    ops = hip.ops
+    torch.manual_seed(5)
+    d = torch.device("cuda")
+    x = torch.randn(N, I, H, H, device=d)
+    w = torch.randn(O, I, 3, 3, device=d) / np.sqrt(9 * I)
+    s, s2 = torch.randn(N, I, device=d) * 0.3 + 1.0, torch.randn(N, O, device=d) * 0.3 + 1.0
+    b, nz = torch.randn(O, device=d) * 0.1, torch.randn(H, H, device=d) * 0.05
+    dco = ((w[None] * s[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    tw, ts, tb = torch.randn(R, O, 1, 1, device=d), (torch.randn(N, O, device=d) * 0.3 + 1.0) / np.sqrt(O), torch.randn(R, device=d)
+    skip = torch.randn(N, R, H // 2, H // 2, device=d)
+    f = ops.setup_filter((1, 3, 3, 1)).to(d)
+    if not ops.conv_fuses_torgb(N, I, O, H, H, R):
+        pytest.skip("the library splits this launch")
+    kw = dict(padding=1, demodulate=True, bias=b, act="lrelu", dcoef=dco, noise=nz, weight_f16=ops.conv_weights_to_f16(w, split=True))
+    img = ops.act_to_image(x, s)
+    if hand:
+        y0, yi0 = ops.modulated_conv2d(img, w, None, next_styles=s2, **kw)
+    else:
+        y0, yi0 = ops.modulated_conv2d(img, w, None, **kw), None
+    ref = ops.torgb(y0, ops.torgb_weights(tw), R, ts, bias=tb, skip=skip, skip_filter=f)
+    y1, yi1, part = ops.modulated_conv2d(img, w, None, next_styles=s2 if hand else None, rgb_weight=tw.reshape(R, O), rgb_styles=ts, **kw)
+    got = ops.torgb_combine(part, bias=tb, skip=skip, skip_filter=f)
+    assert torch.equal(y1, y0) and (yi0 is None or torch.equal(yi1.data, yi0.data))
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    print(f"ToRGB on conv1 [{N}x{I}->{O}@{H}^2, {R} channels]: max abs diff {err:.2e} on a scale of {scale:.2f}")
+    assert err <= 1e-5 * scale
+    y2, yi2, part2 = ops.modulated_conv2d(img, w, None, next_styles=s2 if hand else None, rgb_weight=tw.reshape(R, O), rgb_styles=ts, want_y=False, **kw)
+    assert y2 is None and torch.equal(part2, part) and (yi0 is None or torch.equal(yi2.data, yi0.data))
+    # the double-precision statement of the layer bounds both forms
+    exact = torch.einsum("ro,no,nohw->nrhw", tw.reshape(R, O).double(), ts.double(), y0.double()) + tb.double()[None, :, None, None]
+    exact = exact + ops.upsample2d(skip, f).double()
+    assert float((got.double() - exact).abs().max()) <= 2e-5 * scale and float((ref.double() - exact).abs().max()) <= 2e-5 * scale
+
+
+def test_superresolution_with_torgb_on_conv1_matches_the_separate_launches(hip, monkeypatch):
+    """The full-width super-resolution module (32 -> 256 -> 128 channels, 128^2 -> 512^2) with and without the ToRGB layers riding
+    on conv1: images agree to fp32 round-off (PSNR >= 120 dB on [-1, 1]-scale images), and the riding form launches no k_torgb."""
+    from panic3d_amd import stylegan2 as sg
+    from panic3d_amd.generator import TriPlaneGenerator
+    G = T.fill_generator_params(TriPlaneGenerator(**T.FULL_KW), 11).cuda().eval()
+    torch.manual_seed(2)
+    rgb, feat = torch.randn(1, 3, 128, 128, device="cuda"), torch.randn(1, 32, 128, 128, device="cuda")
+    ws = torch.randn(1, 14, 512, device="cuda")
+    seen = []
+    real = hip.ops.torgb
+    monkeypatch.setattr(hip.ops, "torgb", lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        a = G.superresolution(rgb, feat, ws, noise_mode="const")
+        assert not seen, "the super-resolution blocks should not launch the stand-alone ToRGB kernel"
+        monkeypatch.setattr(sg, "TORGB_RIDES", False)
+        b = G.superresolution(rgb, feat, ws, noise_mode="const")
+        assert len(seen) == 2
+    mse = float(((a - b).double() ** 2).mean())
+    assert a.shape == (1, 3, 512, 512) and 10 * np.log10(4.0 / max(mse, 1e-30)) >= 120.0, mse

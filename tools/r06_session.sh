@@ -13,4 +13,6 @@ synth() { timeout 1500 python -m pytest tests/test_hip_synthesis.py -x -q ${SYNT
 gputests() { timeout 2400 python -m pytest tests -x -q -m gpu > "$OUT/gputests.log" 2>&1; tail -8 "$OUT/gputests.log"; }
 benchtest() { timeout 1500 python -m pytest tests/test_hip_bench_contract.py -x -q > "$OUT/benchtest.log" 2>&1; tail -8 "$OUT/benchtest.log"; }
 bench() { timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err"; }
+convpmc() { bash tools/pmc_backbone.sh "$TAG" > "$OUT/convpmc.log" 2>&1; python tools/summarize_conv_pmc.py "$TAG" > "$OUT/convpmc_summary.txt" 2>&1; tail -60 "$OUT/convpmc_summary.txt"; }
+rgbtest() { timeout 900 python -m pytest tests/test_hip_synthesis.py -x -q -s -k "torgb or superresolution or fullsize or generator_vs" > "$OUT/rgbtest.log" 2>&1; grep -i "ToRGB on\|passed\|failed\|Error" "$OUT/rgbtest.log" | tail -15; }
 for step in "$@"; do echo "== $step"; $step; done

@@ -15,7 +15,11 @@ N_SIMD = 1024
 
 
 def short(name):
-    return name.replace("void ", "").split("(")[0]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+
+def ours(name):
+    return short(name).startswith("k_")
 
 
 def last_pass(rows, key_start):
@@ -34,7 +38,7 @@ for what, first in (("bb", "k_demod_plan"), ("sr", "k_demod_plan")):
     if not tr:
         continue
     rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
-    seg = [r for r in last_pass(rows, first) if r["Kernel_Name"].startswith(("k_", "void k_"))]
+    seg = [r for r in last_pass(rows, first) if ours(r["Kernel_Name"])]
     launches = [{"kernel": short(r["Kernel_Name"]), "grid": f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]}',
                  "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "lds": int(r["LDS_Block_Size"]),
                  "vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"])} for r in seg]
@@ -45,7 +49,7 @@ for what, first in (("bb", "k_demod_plan"), ("sr", "k_demod_plan")):
             continue
         per = collections.OrderedDict()
         for r in csv.DictReader(open(fn[0])):
-            if not r["Kernel_Name"].startswith(("k_", "void k_")):
+            if not ours(r["Kernel_Name"]):
                 continue
             per.setdefault(int(r["Dispatch_Id"]), {"kernel": short(r["Kernel_Name"]), "grid": r["Grid_Size"]})[r["Counter_Name"]] = float(r["Counter_Value"])
         disp = [per[k] for k in sorted(per)][-len(launches):]
