@@ -19,6 +19,7 @@
 #include "p3d_conv_common.hpp"
 
 static bool env_no_w3();  // (defined with the other read-once environment switches, above up3_applies)
+static int w3_min_w();
 // =====================================================================================================================
 // The convolution kernels.  The f32 MFMA shares its SIMD with the VALU (tools/ubench/mfma_valu_overlap.hip), so the K loop is
 // written to contain ds_reads and MFMAs only:
@@ -1569,9 +1570,15 @@ struct TorgbParams {
 // MS (KS only, MT = 1): the workgroup multiplies ONE of the three 32-channel tiles of a 96-channel layer (blockIdx.z): on the
 // 4^2 .. 64^2 maps a launch is a handful of workgroups, each a serial chain of 192 f32 MFMAs per wave (64 clocks each) — three times
 // the workgroups, a third of the chain; the same sums in the same order.
-template <int MT, bool KS, bool MS = false>
+// PRE (KS, MT = 1, I <= 512; round 6): on the 4^2 .. 64^2 maps the launch is a few workgroups and the chunk loop below was eight
+// exposed round trips (load, wait, barrier: 9-10 us for microseconds of work).  Here a wave requests EVERYTHING it multiplies up front —
+// its 64 activation values and its 64 weight values per lane, the weights straight from global memory into MFMA operand registers
+// (128 contiguous bytes per half wave; no LDS ring) — and multiplies as the data lands: one exposed round trip per launch.  The same
+// products in the same order (chunk, channel pair; then the waves' partial sums in wave order): bit-identical to the loop.
+template <int MT, bool KS, bool MS = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
     static_assert(!MS || (KS && MT == 1), "the channel-tile split is a variant of the small-map shape");
+    static_assert(!PRE || (KS && MT == 1), "the all-up-front variant is a variant of the small-map shape");
     constexpr int OP = 32 * MT, ABUF = TG_KC * OP;  // floats per A chunk
     constexpr int OPW = MS ? 96 : OP;               // floats per row of wt
     const int chb = MS ? 32 * blockIdx.z : 0;       // first output channel of this workgroup
@@ -1584,7 +1591,7 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
     const int px = p0 + j;
     const bool pvalid = px < HW;
     const int pxc = pvalid ? px : HW - 1;
-    for (int i = tid; i < ((p.I + TG_KC - 1) / TG_KC) * TG_KC; i += 256) Ss[i] = i < p.I ? p.styles[(size_t)n * p.I + i] : 0.0f;  // zero tail: no predicate in the K loop
+    for (int i = tid; i < (PRE ? 8 * TG_KC : ((p.I + TG_KC - 1) / TG_KC) * TG_KC); i += 256) Ss[i] = i < p.I ? p.styles[(size_t)n * p.I + i] : 0.0f;  // zero tail: no predicate in the K loop
     // x of this image through a buffer resource: per-lane offset = ((channel pair + h) * HW + pixel) * 4
     auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.I * HW), 0, p.I * HW * 4, CONV_RSRC_FLAGS);
     auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.I * OPW * 4, CONV_RSRC_FLAGS);
@@ -1615,11 +1622,33 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int nchunks = (p.I + TG_KC - 1) / TG_KC;
+    if constexpr (PRE) {
+        float xall[8][NC], aall[8][NC];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {  // (rows beyond I: outside the resources, zeros)
+                const int k = q * TG_KC + 2 * (c0 + c);
+                xall[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff + k * HW * 4, 0, 0));
+                aall[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, ((k + h) * OPW + chb + j) * 4, 0, 0));
+            }
+        __syncthreads();  // the styles are staged
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = q * TG_KC + 2 * (c0 + c);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aall[q][c], Ss[k + h] * xall[q][c], acc[0], 0, 0, 0);
+            }
+        __syncthreads();  // (the styles' region is part of what the partial sums overwrite below)
+    }
     float xa[NC], xb[NC];
+    if constexpr (!PRE) {
     load_a(0, 0);
     load_x(0, xa);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    }
     auto chunk_mma = [&](int chunk, int buf, const float (&xv)[NC]) {
         const float* A = As + buf * ABUF + j;
         const float* S = Ss + chunk * TG_KC + h;
@@ -1631,7 +1660,7 @@ __global__ __launch_bounds__(256, 2) void k_torgb(TorgbParams p) {
             for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(k + h) * OP + 32 * t], b, acc[t], 0, 0, 0);
         }
     };
-    for (int q = 0; q < nchunks; q += 2) {  // two chunks per iteration: the register prefetch buffers alternate by name
+    for (int q = 0; q < (PRE ? 0 : nchunks); q += 2) {  // two chunks per iteration: the register prefetch buffers alternate by name
         if (q + 1 < nchunks) { load_a(q + 1, 1); load_x(q + 1, xb); }
         chunk_mma(q, 0, xa);
         __builtin_amdgcn_sched_barrier(0);
@@ -1841,6 +1870,45 @@ __global__ void k_splitk_reduce(ReduceParams p) {
         v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
     }
     p.y[idx] = v;
+}
+
+// k_splitk_reduce of a plain layer whose result is ALSO wanted as the activation image of the layer that follows (round 6: the
+// separate k_act_to_image launch after every split layer of the 4^2 .. 64^2 blocks).  One thread per output value like
+// k_splitk_reduce — the same slice-ordered sum, eight slices in flight, the same epilogue — with the eight channels of a 16-byte piece
+// on eight CONSECUTIVE lanes (the thread index runs channel-in-group fastest, then pixel): their 2-byte hi and lo parts are adjacent
+// stores that fill whole pieces (128 contiguous bytes per eight pixels), the arithmetic of k_act_to_image on the stored value (same bits).
+__global__ __launch_bounds__(256) void k_splitk_reduce_img(ReduceParams p, int N, const float* __restrict__ ystyles, _Float16* __restrict__ yimg,
+                                                           long long lo_halfs, unsigned int* sat) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= p.per_slice) return;
+    const int c = (int)(tid & 7);
+    const long long q = tid >> 3;                 // (n, c8, pixel), pixel fastest
+    const long long g = q / p.OHW;                // (n, c8)
+    const int pix = (int)(q - g * p.OHW);
+    const long long no = g * 8 + c, idx = no * p.OHW + pix;
+    float v = p.part[idx];
+    int k = 1;
+    for (; k + 8 <= p.ksplit; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p.part[(size_t)(k + u) * p.per_slice + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; k < p.ksplit; ++k) v += p.part[(size_t)k * p.per_slice + idx];
+    const long long n = no / p.O;
+    if (p.dcoef) v = v * p.dcoef[no];
+    if (p.noise) v = v + p.noise[(p.noise_per_sample ? n * p.OHW : 0) + pix];
+    if (p.bias) v = v + p.bias[(int)(no % p.O)];
+    v = act_apply(v, p.act, p.alpha, p.gain, p.clamp);
+    if (p.y) p.y[idx] = v;
+    float m = ystyles[no] * v * HX_SPLIT_SCALE_X;
+    const bool bad = !(__builtin_fabsf(m) <= 65504.0f);
+    m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+    const _Float16 hi = (_Float16)m;
+    yimg[q * 8 + c] = hi;
+    yimg[lo_halfs + q * 8 + c] = (_Float16)(m - (float)hi);
+    if (bad && sat) atomicOr(sat, 1u);
 }
 
 // d[n,o] = rsqrt(sum_i (sum_t w[o,i,t]^2) * s[n,i]^2 + 1e-8).  One wave per (n,o).
@@ -2308,7 +2376,7 @@ static inline int chk() {
 template <int MODE>
 static void launch_conv(ConvParams p, hipStream_t st) {
     dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
-    if (p.wh && p.wsplit && MODE == 0 && p.GW >= WX_TW) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
+    if (p.wh && p.wsplit && MODE == 0 && p.GW >= w3_min_w()) {  // the wide tile (the split-K factor was chosen for it: modconv_impl)
         dim3 gw(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
         if (p.ximg && p.O % 64 == 0 && !env_no_w3()) {
             if (p.rgbp) hipLaunchKernelGGL(k_modconv_w3<true>, gw, dim3(256), 0, st, p);
@@ -2357,6 +2425,11 @@ static int up3_min_w() {  // (P3D_UP3_MIN_W in the environment: A/B runs)
 }
 // The kernel-selection switches of the environment (A/B runs) are read ONCE per process: what p3d_modconv2d_workspace_bytes
 // answered for a shape stays the size the launch of that shape needs (a caller may cache the query).
+// narrowest map the pipelined plain 3x3 kernel (k_modconv_w3, a 32-column tile) takes; P3D_W3_MIN_W in the environment: A/B runs
+#ifndef P3D_W3_MIN_W
+#define P3D_W3_MIN_W 32
+#endif
+static int w3_min_w() { static const int v = getenv("P3D_W3_MIN_W") ? atoi(getenv("P3D_W3_MIN_W")) : P3D_W3_MIN_W; return v; }
 static bool env_no_up3() { static const bool v = getenv("P3D_NO_UP3") != nullptr; return v; }
 static bool env_no_w3() { static const bool v = getenv("P3D_NO_W3") != nullptr; return v; }
 static bool up3_applies(int I, int O, int W) { return I % 16 == 0 && O % 32 == 0 && W >= up3_min_w() && !env_no_up3(); }
@@ -2403,12 +2476,12 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     size_t out_elems = (up == 2) ? (size_t)N * O * (2 * H + 1) * (2 * W + 4) : (size_t)N * O * H * W;  // (up = 2: the intermediate's row pitch)
     if (up == 2) b += out_elems * 4;  // transposed-conv intermediate
     int ks = choose_ksplit(N, I, O, up == 2 ? H + 1 : H, up == 2 ? W + 1 : W);
-    if (up == 1 && W >= WX_TW) {  // the wide tile of the two-term kernel may split deeper
+    if (up == 1 && W >= w3_min_w()) {  // the wide tile of the two-term kernel may split deeper
         const int kw = choose_ksplit(N, I, O, H, W, WX_TW);
         ks = kw > ks ? kw : ks;
     }
     if (ks > 1) b += (size_t)ks * out_elems * 4;  // split-K partial sums
-    if (up == 1 && W >= WX_TW && I % 16 == 0 && O % 64 == 0) b += (size_t)N * I * H * W * 4 + 256;  // the activation image an fp32 input is turned into (k_modconv_w3)
+    if (up == 1 && W >= w3_min_w() && I % 16 == 0 && O % 64 == 0) b += (size_t)N * I * H * W * 4 + 256;  // the activation image an fp32 input is turned into (k_modconv_w3)
     if (up == 2 && up3_applies(I, O, W)) {  // k_modconv_up3: its own split-K depth, and the activation image of an fp32 input
         const int k3 = choose_ksplit_up3(N, I, O, H, W);
         if (k3 > ks) b += (size_t)(k3 - (ks > 1 ? ks : 0)) * out_elems * 4;
@@ -2420,7 +2493,7 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
 // the rule by which an image-consuming layer is accepted (p3d_conv_args.x_img): exported so that a binding cannot drift from it
 int p3d_conv_takes_image(int I, int O, int W, int up) {
     if (I <= 0 || O <= 0 || W <= 0 || I % 16 != 0) return 0;
-    if (up == 1) return W >= WX_TW ? 1 : 0;
+    if (up == 1) return W >= w3_min_w() ? 1 : 0;
     if (up == 2) return up3_applies(I, O, W) ? 1 : 0;
     return 0;
 }
@@ -2448,7 +2521,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     if (ximg) {  // an image input (already modulated by its producer): the pipelined two-term kernels; demodulation must be precomputed
         if (!wh || !wsplit || (demodulate && !dcoef_in)) return P3D_E_ARG;
         if (ks != 3 || I % 16 != 0 || ((uintptr_t)ximg & 15)) return P3D_E_RANGE;
-        if (up == 1 ? W < WX_TW : !up3_applies(I, O, W)) return P3D_E_RANGE;  // (an up-sampling layer reads images only through k_modconv_up3)
+        if (up == 1 ? W < w3_min_w() : !up3_applies(I, O, W)) return P3D_E_RANGE;  // (an up-sampling layer reads images only through k_modconv_up3)
     }
     if (yimg) {      // an image output for a consumer with styles ystyles [N][O]: up = 2: written by the FIR pass INSTEAD of y; up = 1: next to y
         if (!ystyles) return P3D_E_ARG;
@@ -2475,7 +2548,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         int waves = N * O;
         hipLaunchKernelGGL(k_demod, dim3((waves * 64 + 255) / 256), dim3(256), 0, st, w, styles, N, O, I, ks * ks, dco);
     }
-    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= WX_TW;  // k_modconv_w3 / k_modconv_up3
+    const bool wide = wh && wsplit && ks == 3 && up == 1 && W >= w3_min_w();  // k_modconv_w3 / k_modconv_up3
     const bool up3 = wh && wsplit && ks == 3 && up == 2 && up3_applies(I, O, W);  // k_modconv_up3 / k_modconv_up4
     // k_modconv_up4 (round 6): transposed convolution + FIR pass + epilogue in one launch, no intermediate and no split-K — every
     // up-sampling layer whose 8-row tiling alone gives the chip enough workgroups (the 64^2 .. 512^2 maps of the backbone and of
@@ -2547,6 +2620,11 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
         r.part = part; r.y = (up == 2) ? tmp : y; r.dcoef = p.dcoef; r.noise = noise; r.bias = bias;
         r.per_slice = (long long)out_elems; r.ksplit = ksplit; r.O = O; r.OHW = OH * OW; r.noise_per_sample = noise_per_sample;
         r.act = act; r.epilogue = (up == 1) ? 1 : 0; r.alpha = alpha; r.gain = gain; r.clamp = clamp;
+        if (up == 1 && yimg && !w3_img && !getenv("P3D_NO_REDUCE_IMG")) {  // the sums, the epilogue and the next layer's image in one launch
+            hipLaunchKernelGGL(k_splitk_reduce_img, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, r, N, ystyles, (_Float16*)yimg,
+                               (long long)N * O * H * W, sat);
+            return chk();
+        }
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((out_elems + 255) / 256)), dim3(256), 0, st, r);
     }
     if (up == 1) {
@@ -2678,11 +2756,13 @@ int p3d_torgb_f32(const float* x, int N, int I, int H, int W, const float* w_t, 
     const bool ks = (long long)N * ((HW + 127) / 128) < 512;
     // small maps of a 96-channel layer: one workgroup per 32-channel tile while that still leaves the chip underfilled
     const bool ms = ks && MT == 3 && (long long)N * ((HW + 31) / 32) * 3 <= 1024 && !getenv("P3D_NO_TORGB_MS");
-    const size_t lds = (size_t)(2 * TG_KC * 32 * (ms ? 1 : MT) + ((I + 63) / 64) * 64) * 4;
+    const bool pre = ms && I <= 8 * TG_KC && !getenv("P3D_NO_TORGB_PRE");  // everything requested up front (k_torgb<..., PRE>)
+    const size_t lds = (size_t)(2 * TG_KC * 32 * (ms ? 1 : MT) + (pre ? 8 * TG_KC : ((I + 63) / 64) * 64)) * 4;
     dim3 grid((unsigned)(ks ? (HW + 31) / 32 : (HW + 127) / 128), (unsigned)N, ms ? 3u : 1u);
     if (lds > 64 * 1024) return P3D_E_RANGE;  // (53 KB at I = 1024, O = 96: inside the default dynamic-LDS limit, no per-device attribute to set)
 #define P3D_TORGB(MTV, KSV) hipLaunchKernelGGL((k_torgb<MTV, KSV>), grid, dim3(256), lds, (hipStream_t)stream, p)
     if (MT == 1) { if (ks) P3D_TORGB(1, true); else P3D_TORGB(1, false); }
+    else if (pre) hipLaunchKernelGGL((k_torgb<1, true, true, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else if (ms) hipLaunchKernelGGL((k_torgb<1, true, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else { if (ks) P3D_TORGB(3, true); else P3D_TORGB(3, false); }
     return chk();

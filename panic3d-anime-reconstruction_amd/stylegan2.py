@@ -124,7 +124,7 @@ CONV_IMG = os.environ.get("P3D_CONV_IMG", "1") != "0"
 # StylePlan returns the previous call's result for the same ws object (views of one subject).  Off: every pass computes its styles
 # (the pass timings of tools/bench_backbone.py, graph_backbone.py, profile_backbone.py are taken that way).
 STYLE_MEMO = os.environ.get("P3D_STYLE_MEMO", "1") != "0"
-IMG_MIN_RES = 32
+IMG_MIN_RES = int(os.environ.get("P3D_W3_MIN_W", "32"))  # (the library's own rule is asked as well: ops.takes_image)
 # A block of <= 4 image channels (the super-resolution's) computes its ToRGB sums in conv1's epilogue (ops.conv_fuses_torgb): the
 # activation is not read back — and not written when nobody else reads it.  fp32-class agreement with the stand-alone ToRGB launch
 # (another summation order); P3D_TORGB_RIDES=0 for A/B runs.
@@ -166,6 +166,15 @@ def _next_conv0_styles(next_block, next_pre, res):
     if mode != "x2" or not ops.takes_image_up(layer.in_channels, layer.out_channels, res):
         return None
     return next_pre["conv0"][0]
+
+
+def _hands_image(layer):
+    """A plain two-term 3x3 layer fed an fp32 tensor can still write its result as the next layer's activation image (the library
+    does it from the launch that finishes the layer)."""
+    mode = layer.__dict__.get("mma_f16")
+    if mode is None:
+        mode = "x2" if DEFAULT_CONV_MMA == "x2" else False
+    return CONV_IMG and mode == "x2" and layer.up == 1 and layer.in_channels % 16 == 0 and layer.out_channels % 8 == 0
 
 
 def _f16_operand(layer):
@@ -503,7 +512,10 @@ class SynthesisBlock(torch.nn.Module):
             x = self._parameters["const"].to(torch.float32).unsqueeze(0)
             if ws.shape[0] != 1:  # (batch 1: the convolution only reads x — no copy of the constant, networks_stylegan2.py:456-457)
                 x = x.repeat([ws.shape[0], 1, 1, 1])
-            x = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs)
+            if next_styles is not None and _hands_image(self.conv1):
+                x, x_next = self.conv1(x, next(w_iter), pre=pre.get("conv1"), next_styles=next_styles, **layer_kwargs)
+            else:
+                x, x_next = self.conv1(x, next(w_iter), pre=pre.get("conv1"), **layer_kwargs), None
         else:
             # conv0 hands conv1 its operand (activation image) when conv1 can stage from one and its styles / demodulation
             # coefficients are known up front (a StylePlan)
@@ -523,7 +535,9 @@ class SynthesisBlock(torch.nn.Module):
                 if next_styles is not None:
                     return x, img, x_next
                 return x, img
-            if next_styles is not None and isinstance(x, ops.ActImage):  # conv1 takes an image (the pipelined kernel) and hands one on
+            if next_styles is not None and (isinstance(x, ops.ActImage) or _hands_image(self.conv1)):
+                # conv1 hands the next block's conv0 its operand: from the pipelined kernel's epilogue, or (split-K layers of the small
+                # maps) from the launch that sums the slices — no conversion pass in front of conv0 either way
                 x, x_next = self.conv1(x, next(w_iter), pre=p1, next_styles=next_styles, **layer_kwargs)
             else:
                 x, x_next = self.conv1(x, next(w_iter), pre=p1, **layer_kwargs), None
@@ -531,7 +545,7 @@ class SynthesisBlock(torch.nn.Module):
         img = self.torgb(x, next(w_iter), pre=pre.get("torgb"), skip=None if img is None else img.to(torch.float32),
                          skip_filter=self.resample_filter)
         if next_styles is not None:
-            return x, img, (x_next if self.in_channels != 0 else None)
+            return x, img, x_next
         return x, img
 
 

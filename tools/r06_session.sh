@@ -15,4 +15,7 @@ benchtest() { timeout 1500 python -m pytest tests/test_hip_bench_contract.py -x 
 bench() { timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json"; tail -3 "$OUT/bench.err"; }
 convpmc() { bash tools/pmc_backbone.sh "$TAG" > "$OUT/convpmc.log" 2>&1; python tools/summarize_conv_pmc.py "$TAG" > "$OUT/convpmc_summary.txt" 2>&1; tail -60 "$OUT/convpmc_summary.txt"; }
 rgbtest() { timeout 900 python -m pytest tests/test_hip_synthesis.py -x -q -s -k "torgb or superresolution or fullsize or generator_vs" > "$OUT/rgbtest.log" 2>&1; grep -i "ToRGB on\|passed\|failed\|Error" "$OUT/rgbtest.log" | tail -15; }
+torgbtime() { timeout 600 python tools/torgb_time.py > "$OUT/torgb_time.jsonl" 2> "$OUT/torgb_time.err"; cat "$OUT/torgb_time.jsonl"; tail -3 "$OUT/torgb_time.err"; }
+trace() { bash tools/trace_passes.sh "$TAG" > "$OUT/trace.txt" 2>&1; grep -v "^$" "$OUT/trace.txt" | cut -c1-110 | tail -70; }
+graphbb() { timeout 600 python tools/graph_backbone.py > "$OUT/graph_backbone.txt" 2>&1; tail -5 "$OUT/graph_backbone.txt"; }
 for step in "$@"; do echo "== $step"; $step; done
