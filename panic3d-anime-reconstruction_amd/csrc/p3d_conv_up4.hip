@@ -11,7 +11,7 @@
 //               1.22 x the MFMA work of the un-fused form (k_modconv_up3<true>'s 8 x 32 tile: 1.42 x); 152 KB of LDS, one workgroup per CU
 //   <4, 2, 2>   8 x 32 grid points (12 x 60 outputs) on four waves, the patch double buffered: 78 KB, two workgroups per CU
 //   pipeline    per 16-channel chunk a wave issues 9 taps x RPW rows x 3 two-term products = 27 RPW MFMAs (32x32x16 f16); the weights
-//               of a chunk (18 KB: [hi|lo][tap][k half][32 o][8]) are double buffered, the patch ([hi|lo][k half][GR+1][34][8]) sits
+//               of a chunk (18 KB: [hi|lo][tap][k half][32 o][8]) are double buffered, the patch ([hi|lo][k half][GR+1][33][8]) sits
 //               in a ring of NP = 3 buffers: the weights of chunk k+1 and the patch of chunk k+2 are requested under the MFMAs of
 //               chunk k (inline-asm LDS-DMA, one piece after each of the first taps), the ONE barrier per chunk waits with a counted
 //               vmcnt that leaves the youngest patch in flight — a patch has more than a whole chunk to land, the weights
@@ -34,10 +34,11 @@ struct Up4 {
     static constexpr int GR = NW * RPW;             // grid rows of a tile
     static constexpr int PR = GR + 1;               // patch rows
     static constexpr int OR = 2 * GR - 4;           // output rows of a tile (12 / 28); 60 output columns
-    static constexpr int ITEMS = PR * WX_ROW;       // 16-byte items of one (hi|lo, k half) sub-image of the patch: 306 / 578
-    static constexpr int SUB = ITEMS * 16;
-    static constexpr int PSZ = 4 * SUB;             // one patch buffer: 19 584 / 36 992
-    static constexpr int NPS = (ITEMS + 63) / 64;   // DMA pieces per sub-image: 5 / 10 (the last one partial)
+    static constexpr int PW = WX_TW + 1;            // patch columns = LDS row pitch: dx in {-1, 0} only (k_modconv_w3's 34 holds dx = +1 as well)
+    static constexpr int ITEMS = PR * PW;           // 16-byte items of one (hi|lo, k half) sub-image of the patch: 297 / 561
+    static constexpr int NPS = (ITEMS + 63) / 64;   // DMA pieces per sub-image: 5 / 9; a sub-image is padded to whole pieces, so the last
+    static constexpr int SUB = NPS * 1024;          // piece runs with every lane (the lanes past ITEMS request nothing and zero the padding)
+    static constexpr int PSZ = 4 * SUB;             // one patch buffer: 20 480 / 36 864
     static constexpr int PARTS = NW / 4;            // waves per sub-image: they take its pieces alternately
     static constexpr int NPW = (NPS + PARTS - 1) / PARTS;  // patch pieces per wave at most
     static constexpr int WPW = (18 + NW - 1) / NW;  // weight pieces per wave at most (18 per chunk)
@@ -58,7 +59,7 @@ struct Up4 {
 template <int NW, int RPW, int NP>
 __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     using C = Up4<NW, RPW, NP>;
-    static_assert(C::LDS <= 160 * 1024, "LDS of one CU");
+    static_assert(C::LDS <= 160 * 1024 && (NW == 8 || C::LDS <= 80 * 1024), "LDS of one CU (four waves: two workgroups per CU)");
     static_assert(NW == 4 || NW == 8, "four sub-images of the patch on four or eight waves");
     __shared__ __attribute__((aligned(16))) char lds[C::LDS];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
@@ -73,9 +74,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     const int nch = p.I >> 4;
     const int HW = p.H * p.W;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    // timing experiments (P3D_UP4_DBG in the environment -> p.tox; results are garbage with any bit set): 1 = no FIR / epilogue,
-    // 2 = no DMA inside the K loop, 4 = no MFMAs, 8 = no barrier inside the K loop
-    const int dbg = p.tox;
 
     // ---- DMA plans.  Patch: sub-image s = (hi|lo, k half) belongs to waves s and s + 4, which take its pieces alternately
     const int sub = wave & 3, part = wave >> 2;
@@ -83,12 +81,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     int pvoff[C::NPW];
 #pragma unroll
     for (int i = 0; i < C::NPW; ++i) {
-        const int it = (part + C::PARTS * i) * 64 + lane;
-        const int r = it / WX_ROW, c = it - r * WX_ROW;
+        // (eight waves, nine pieces: the second wave of a sub-image requests the last piece once more instead of skipping a turn — the same
+        // bytes to the same place, and every wave issues the same number of requests: no branch in the K loop, one counted wait)
+        const int pc = part + C::PARTS * i < C::NPS ? part + C::PARTS * i : C::NPS - 1;
+        const int it = pc * 64 + lane;
+        const int r = it / C::PW, c = it - r * C::PW;
         const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
         pvoff[i] = (it < C::ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? ((sub_kh * p.H + iy) * p.W + ix) * 16 : CONV_OOB;
     }
-    const bool tail_lane = lane < C::ITEMS - (C::NPS - 1) * 64;  // the lanes of a sub-image's last piece that hold items
     const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
     // Weights: 1152 pieces (hi|lo, tap, k half, o) = 18 instructions: wave w issues instructions w, w + NW, ... (the last round: waves 0, 1)
     const int LO = p.O * 9 * p.I * 2;
@@ -109,14 +109,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
         const int ic0 = in ? 16 * chunk : 0;
         return w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
     };
+    uint32_t pdst[C::NPW];  // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < C::NPW; ++i) {
+        const int pc = part + C::PARTS * i < C::NPS ? part + C::PARTS * i : C::NPS - 1;
+        pdst[i] = lds0 + 2 * U3_WB + sub * C::SUB + pc * 1024;
+    }
     auto patch_piece = [&](const i32x4& rs, int buf, int i) {  // i: compile-time after unrolling
-        if (part + C::PARTS * i >= C::NPS) return;             // (wave-uniform: NW = 8, RPW = 1: the second wave of a sub-image has two pieces)
-        const uint32_t dst = lds0 + 2 * U3_WB + buf * C::PSZ + sub * C::SUB + (part + C::PARTS * i) * 1024;
-        if (part + C::PARTS * i == C::NPS - 1) { if (tail_lane) w3_dma16(dst, rs, pvoff[i]); }  // (the other lanes would write into the next sub-image)
-        else w3_dma16(dst, rs, pvoff[i]);
+        w3_dma16(pdst[i] + buf * C::PSZ, rs, pvoff[i]);
     };
     auto weight_piece = [&](const i32x4& rs, int buf, int i) {
-        if (wave + NW * i >= 18) return;                       // (wave-uniform)
+        if (NW * i + NW > 18 && wave + NW * i >= 18) return;   // (wave-uniform; only the last round — pieces 16, 17 — is not shared by all waves)
         w3_dma16(lds0 + buf * U3_WB + (wave + NW * i) * 1024, rs, wvoff[i]);
     };
     // piece s of a chunk's requests: 0 .. WPW-1 the weights of the next chunk, then this wave's patch pieces; PPT of them are issued
@@ -126,7 +129,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
         else if (s < C::WPW + C::NPW) patch_piece(rp, pbuf, s - C::WPW);
     };
     auto issue = [&](const i32x4& rw, int wbuf, const i32x4& rp, int pbuf, int q) {
-        if (dbg & 2) return;
 #pragma unroll
         for (int e = 0; e < C::PPT; ++e) issue1(rw, wbuf, rp, pbuf, q * C::PPT + e);
     };
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
     // patch row RPW w + 1 + t is grid row gy0 + RPW w + t; column j + 1 is grid column gx0 + j
-    const int blane = half * C::SUB + ((RPW * wave) * WX_ROW + j) * 16;
+    const int blane = half * C::SUB + ((RPW * wave) * C::PW + j) * 16;
     const int alane = (half * 32 + j) * 16;
     // (phase, tap, input) of the nine products: input 0 = x[y][x], 1 = x[y][x-1], 2 = x[y-1][x], 3 = x[y-1][x-1] (k_modconv_up3's order)
     const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
@@ -182,11 +184,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     }
     auto wait_chunk = [&]() {  // everything but the youngest patch has landed (this wave's pieces; the barrier covers the others')
         if constexpr (C::PD < 2) W3_VMWAIT(0);
-        else if constexpr (NW == 8 && RPW == 2) W3_VMWAIT(5);
-        else { if (part) W3_VMWAIT(2); else W3_VMWAIT(3); }
+        else W3_VMWAIT(5);
     };
-    static_assert(RPW == 1 || RPW == 2, "the counted waits above are written for 5 / 10 pieces per sub-image");
-    static_assert(C::PD < 2 || (NW == 8 && ((RPW == 2 && C::NPS == 10) || (RPW == 1 && C::NPS == 5))), "pieces per sub-image");
+    static_assert(C::PD < 2 || C::NPW == 5, "the counted wait above leaves one patch = five requests of this wave in flight");
     wait_chunk();
     __builtin_amdgcn_s_barrier();
 
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
             for (int r = 0; r < RPW + 1; ++r)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * WX_ROW + c) * 16);
-                    bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * C::SUB + (r * WX_ROW + c) * 16);
+                    bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * C::PW + c) * 16);
+                    bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * C::SUB + (r * C::PW + c) * 16);
                 }
             f16x8 ah[2], al[2];
             ah[0] = *reinterpret_cast<const f16x8*>(wb + TP[0] * 64 * 16);
@@ -223,11 +223,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
 #pragma unroll
                 for (int t = 0; t < RPW; ++t) {
                     const int r = 1 + t - (BO[q] >> 1), c = 1 - (BO[q] & 1);
-                    if (!(dbg & 4)) {
                     acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[r][c], acc[PH[q]][t], 0, 0, 0);
                     acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[r][c], acc[PH[q]][t], 0, 0, 0);
                     acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[r][c], acc[PH[q]][t], 0, 0, 0);
-                    }
                     if (t == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(rw, wnext, rp, pnext, q);
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             wait_chunk();
-            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             pcur = pcur + 1 == NP ? 0 : pcur + 1;
         }
     } else {
@@ -248,24 +246,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
 #pragma unroll
             for (int s = 0; s < 9; ++s) issue(rw, (k + 1) & 1, rp, pnext, s);
             wait_chunk();
-            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             pcur = pcur + 1 == NP ? 0 : pcur + 1;
         }
     }
     W3_VMWAIT(0);  // nothing may land in LDS once the buffers are reused
     __builtin_amdgcn_s_barrier();
-    if (dbg & 1) {
-        float v = 0.0f;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-            for (int t = 0; t < RPW; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v += acc[ph][t][r];
-        if (v == 12345.678f && p.sat) atomicOr(p.sat, 2u);  // (keeps the accumulators alive)
-        return;
-    }
-
     // ---- FIR + epilogue.  Output (Y, X) = (2 gy0 + 1 + ly, 2 gx0 + 1 + lx), ly in [1, OR], lx in [1, 60], reads the local intermediate
     // rows ly .. ly + 3, columns lx .. lx + 3 (= T[Y - 1 + fy][X - 1 + fx]); grid points outside the map gave exact zeros (the FIR
     // pass's zero padding).  Sixteen channels at a time through LDS.
@@ -385,10 +371,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
                         hv[ch] = (_Float16)a;
                         lv[ch] = (_Float16)(a - (float)hv[ch]);
                     }
-                    if (dbg & 16) {  // (timing experiment: the arithmetic without the stores)
-                        const uint32_t q = __builtin_bit_cast(uint32_t, (float)hv[0] + (float)lv[7]) & 0x3FFFFFFFu;
-                        badbits = q > badbits ? q : badbits;
-                    } else if (inside) {
+                    if (inside) {
                         *reinterpret_cast<f16x8*>(dst + jj * 16) = hv;
                         *reinterpret_cast<f16x8*>(dst + lo_off + jj * 16) = lv;
                     }
@@ -436,9 +419,7 @@ int p3d_up4_shape(int N, int O, int H, int W) {
 
 // up = 2, image-fed (p.ximg), unsplit, I % 16 == 0, O % 32 == 0; writes p.yimg (activation image, needs p.ystyles) or p.y (fp32 [N][O][2H][2W])
 int p3d_up4_launch(const ConvParams& p0, int shape, hipStream_t st) {
-    ConvParams p = p0;
-    const char* dbg = getenv("P3D_UP4_DBG");
-    p.tox = dbg ? atoi(dbg) : 0;
+    const ConvParams& p = p0;
     if (shape == 2) hipLaunchKernelGGL((k_modconv_up4<8, 2, 3>), up4_grid(p, 16), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((k_modconv_up4<4, 2, 2>), up4_grid(p, 8), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();

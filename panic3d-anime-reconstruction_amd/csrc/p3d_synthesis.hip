@@ -2614,7 +2614,11 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     // same slice-ordered sum.  Deep splits (the 4^2 .. 32^2 layers, up to 64 slices) keep the separate, chip-wide reduction:
     // measured (profiles/history/r03_notes.txt) both a per-element slice loop inside the FIR pass (4.8 + 5.8 -> 37 us at 64 slices) and an
     // in-launch last-arriver reduction of the plain convolutions (release / ticket / acquire: +15 .. +50 us per layer) lose to it.
-    const bool fir_sums = up == 2 && ksplit > 1 && ksplit <= 8;
+    // ... unless the FIR launch itself is a handful of workgroups (one per 32 x 32 tile and eight channels: 64 for 512 channels at 32^2,
+    // each then pulling eight slices of its tile through one CU: 17.9 us) — there the chip-wide reduction + a plain FIR pass are faster
+    static const long long fir_sums_min_wgs = getenv("P3D_FIR_SUMS_MIN_WGS") ? atoll(getenv("P3D_FIR_SUMS_MIN_WGS")) : 0;  // (measured with 128: 6.5 + 10.2 us instead of 18.2 at 32^2 — one more launch for 1.5 us: left off)
+    const long long fir_wgs = (long long)((2 * W + 31) / 32) * ((2 * H + 31) / 32) * ((long long)N * O / (yimg ? 8 : 1));
+    const bool fir_sums = up == 2 && ksplit > 1 && ksplit <= 8 && fir_wgs >= fir_sums_min_wgs;
     if (ksplit > 1 && !fir_sums) {
         ReduceParams r;
         r.part = part; r.y = (up == 2) ? tmp : y; r.dcoef = p.dcoef; r.noise = noise; r.bias = bias;

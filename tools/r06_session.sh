@@ -7,7 +7,6 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 up4test() { timeout 900 python -m pytest tests/test_hip_synthesis.py -x -q -k "up4 or fir_pass_inside or activation_image" > "$OUT/up4test.log" 2>&1; tail -5 "$OUT/up4test.log"; }
-up4dbg() { timeout 600 python tools/up4_ab.py --n 20 --dbg > "$OUT/up4dbg.jsonl" 2> "$OUT/up4dbg.err"; cat "$OUT/up4dbg.jsonl"; tail -3 "$OUT/up4dbg.err"; }
 up4ab() { timeout 600 python tools/up4_ab.py --n 30 > "$OUT/up4ab.jsonl" 2> "$OUT/up4ab.err"; cat "$OUT/up4ab.jsonl"; tail -3 "$OUT/up4ab.err"; }
 synth() { timeout 1500 python -m pytest tests/test_hip_synthesis.py -x -q ${SYNTH_K:+-k "$SYNTH_K"} > "$OUT/synth.log" 2>&1; tail -5 "$OUT/synth.log"; }
 gputests() { timeout 2400 python -m pytest tests -x -q -m gpu > "$OUT/gputests.log" 2>&1; tail -8 "$OUT/gputests.log"; }

@@ -46,15 +46,11 @@ def main():
         row = dict(layer=name, I=I, O=O, H=H)
         outs = {}
         variants = [("r05", {"P3D_UP4": "0"}), ("up4_rpw2", {"P3D_UP4": "1", "P3D_UP4_RPW": "2"}), ("up4_rpw0", {"P3D_UP4": "1", "P3D_UP4_RPW": "0"})]
-        if "--dbg" in sys.argv:  # timing experiments: parts of the kernel switched off (garbage results)
-            variants += [(f"rpw{r}_dbg{d}", {"P3D_UP4": "1", "P3D_UP4_RPW": str(r), "P3D_UP4_DBG": str(d)}) for r in (0, 2) for d in (1, 16)]
         for tag, env in variants:
-            os.environ["P3D_UP4_DBG"] = "0"
             os.environ.update(env)
             call = lambda: ops.modulated_conv2d(img, w, None, next_styles=s2, **kw)
             outs[tag] = call().data.clone()
             row["us_" + tag] = round(timeit(call, n), 2)
-        os.environ["P3D_UP4_DBG"] = "0"
         row["rpw2_equals_r05"] = bool(torch.equal(outs["r05"], outs["up4_rpw2"]))
         row["rpw0_equals_rpw2"] = bool(torch.equal(outs["up4_rpw0"], outs["up4_rpw2"]))
         row["max_abs_diff_vs_r05"] = float((outs["r05"].float() - outs["up4_rpw2"].float()).abs().max())
