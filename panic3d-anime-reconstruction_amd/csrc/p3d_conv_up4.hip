@@ -408,7 +408,10 @@ static dim3 up4_grid(const ConvParams& p, int rows) {
 //   256 -> 128 @128^2 -> 256^2 (200 / 440):              r05 68    shape 2 65    shape 0 64
 //   512 -> 256 @ 64^2 -> 128^2 (120 / 264):              r05 64    shape 2 84    shape 0 101   (the chip is underfilled: split-K wins)
 //    32 -> 256 @128^2 -> 256^2 (720 / 1760, 2 chunks):   r05 51    shape 2 62    shape 0 53    (k_modconv_up3<true>: its epilogue alone)
-// An eight-wave one-row shape (8 x 32 grid points, one workgroup per CU) was built and dropped: never the fastest.
+// An eight-wave one-row shape (8 x 32 grid points, one workgroup per CU) was built and dropped: never the fastest.  So was (round 6) a
+// four-wave four-row shape — the 16 x 32 tile on ONE wave per SIMD, 256 accumulator + 256 other registers, 108 MFMAs per chunk and
+// 0.35 instead of 0.55 LDS reads per MFMA: bit-identical and slower everywhere (256^2 -> 512^2: 209 us against 197; 32 -> 256: 73 / 65;
+// the small maps 84-113 against 52-88): without a second wave on the SIMD every LDS round trip of the loop and of the filter is exposed.
 // P3D_UP4_RPW = 0 / 2 in the environment forces a shape (A/B runs, tests).
 int p3d_up4_shape(int N, int O, int H, int W) {
     const char* e = getenv("P3D_UP4_RPW");
