@@ -59,12 +59,13 @@ static int layouts_agree() {
                                offsetof(p3d_conv_args, styles), offsetof(p3d_conv_args, demod_coefs), offsetof(p3d_conv_args, noise),
                                offsetof(p3d_conv_args, bias), offsetof(p3d_conv_args, fir), offsetof(p3d_conv_args, y),
                                offsetof(p3d_conv_args, workspace), offsetof(p3d_conv_args, saturated), offsetof(p3d_conv_args, x_img),
-                               offsetof(p3d_conv_args, y_img), offsetof(p3d_conv_args, y_img_styles), offsetof(p3d_conv_args, workspace_bytes),
+                               offsetof(p3d_conv_args, y_img), offsetof(p3d_conv_args, y_img_styles), offsetof(p3d_conv_args, rgb_w),
+                               offsetof(p3d_conv_args, rgb_styles), offsetof(p3d_conv_args, rgb_partial), offsetof(p3d_conv_args, workspace_bytes),
                                offsetof(p3d_conv_args, N), offsetof(p3d_conv_args, I), offsetof(p3d_conv_args, H), offsetof(p3d_conv_args, W),
                                offsetof(p3d_conv_args, O), offsetof(p3d_conv_args, ks), offsetof(p3d_conv_args, up),
                                offsetof(p3d_conv_args, demodulate), offsetof(p3d_conv_args, noise_per_sample), offsetof(p3d_conv_args, act),
                                offsetof(p3d_conv_args, mma), offsetof(p3d_conv_args, alpha), offsetof(p3d_conv_args, gain),
-                               offsetof(p3d_conv_args, clamp)};
+                               offsetof(p3d_conv_args, clamp), offsetof(p3d_conv_args, rgb_channels)};
         const int n = p3d_struct_layout(P3D_STRUCT_CONV_ARGS, lib, 64);
         if (n != (int)(sizeof(mine) / sizeof(mine[0]))) return 0;
         for (int i = 0; i < n; ++i) if (lib[i] != mine[i]) return 0;
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
     a.y = y; a.workspace = ws; a.saturated = sat; a.x_img = nullptr; a.y_img = nullptr; a.y_img_styles = nullptr; a.workspace_bytes = wsb;
     a.N = N; a.I = I; a.H = H; a.W = W; a.O = O; a.ks = 3; a.up = up; a.demodulate = 1; a.noise_per_sample = 0; a.act = 1; a.mma = P3D_CONV_MMA_F16X2;
     a.alpha = 0.2f; a.gain = 1.41421356237309515f; a.clamp = -1.0f;
+    a.rgb_w = nullptr; a.rgb_styles = nullptr; a.rgb_partial = nullptr; a.rgb_channels = 0;  // (ABI 9: no ToRGB riding on this launch)
     CHECK_P3D(p3d_modconv2d_ex_f32(&a, st));
     // ToRGBLayer.forward + img = upsample2d(img) + y
     CHECK_P3D(p3d_torgb_f32(y, N, O, OH, OW, wrgb_t, ORGB, srgb, brgb, -1.0f, skip, fir, img, st));

@@ -5,8 +5,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpanic3d_hip.so")
-SOURCES = ["p3d_kernels.hip", "p3d_synthesis.hip", "p3d_conv_up4.hip", "p3d_mcubes.hip", "p3d_paste.hip"]
-HEADERS = ["p3d_math.hpp", "p3d_decode.hpp", "p3d_conv_common.hpp", os.path.join("..", "..", "include", "panic3d_hip.h"),
+SOURCES = ["p3d_kernels.hip", "p3d_synthesis.hip", "p3d_conv_plain.hip", "p3d_conv_up.hip", "p3d_conv_up4.hip", "p3d_fir.hip", "p3d_torgb.hip",
+           "p3d_mcubes.hip", "p3d_paste.hip"]
+HEADERS = ["p3d_math.hpp", "p3d_decode.hpp", "p3d_conv_common.hpp", "p3d_conv_stage.hpp", os.path.join("..", "..", "include", "panic3d_hip.h"),
            os.path.join("..", "..", "include", "p3d_numerics.h"), os.path.join("..", "..", "include", "p3d_mc_table.h")]
 # -fno-slp-vectorize: v_pk_fma_f32 runs at ~0.4x the flop rate of v_fma_f32 on gfx950 (tools/ubench/valu_rates.hip).
 # -ffp-contract=off: the arithmetic contract (include/p3d_numerics.h) names every fma explicitly.
@@ -50,7 +51,8 @@ def render_source_hash():
     return h.hexdigest()[:16]
 
 
-SYNTHESIS_UNIT = ["p3d_synthesis.hip", "p3d_conv_up4.hip", "p3d_conv_common.hpp", os.path.join("..", "..", "include", "panic3d_hip.h")]
+SYNTHESIS_UNIT = ["p3d_synthesis.hip", "p3d_conv_plain.hip", "p3d_conv_up.hip", "p3d_conv_up4.hip", "p3d_fir.hip", "p3d_torgb.hip", "p3d_conv_common.hpp",
+                  "p3d_conv_stage.hpp", os.path.join("..", "..", "include", "panic3d_hip.h")]
 
 
 def synthesis_source_hash():

@@ -129,3 +129,40 @@ DEV void w3_dma16(uint32_t lds_addr, i32x4 rsrc, int voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
 }
 #define W3_VMWAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+struct FirParams {
+    const float* x;  // [NC][H][W]
+    const float* f;  // [fh][fw], already flipped for convolution and multiplied by gain
+    float* y;        // [NC][OH][OW]
+    const float* dcoef;  // [NC] (= [N][C]) or null
+    const float* noise;  // [OH*OW] or [N][OH*OW] or null
+    const float* bias;   // [C] or null
+    long long NC;
+    int C, H, W, OH, OW, fh, fw, up, down, padx0, pady0;
+    int noise_per_sample, act, epilogue;
+    float alpha, gain, clamp;
+    const float* nstyles; // k_fir4x4_img: the consuming layer's styles [N][C] (the image holds split(16 * s * y))
+    int ksplit;           // k_fir4x4_tiled: x holds ksplit split-K partial tensors, `slice` elements apart, summed in slice order
+    long long slice;      // while the tile is loaded (shallow splits only: see modconv_impl); 1 / 0 otherwise
+    int pitch, xoff;      // k_fir4x4_*: x rows are `pitch` floats apart and column v sits at index v + xoff (ConvParams::tox); the generic
+                          // operator ignores them (pitch = W, xoff = 0)
+};
+
+// ---- host side: shared by the translation units of the synthesis operators
+static inline int chk_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? P3D_OK : (int)e;
+}
+// The kernel-selection switches of the environment (A/B runs) are read ONCE per process: what p3d_modconv2d_workspace_bytes
+// answered for a shape stays the size the launch of that shape needs (a caller may cache the query).
+// narrowest map the pipelined plain 3x3 kernel (k_modconv_w3, a 32-column tile) takes; P3D_W3_MIN_W in the environment: A/B runs
+#ifndef P3D_W3_MIN_W
+#define P3D_W3_MIN_W 32
+#endif
+static inline int p3d_w3_min_w() { static const int v = getenv("P3D_W3_MIN_W") ? atoi(getenv("P3D_W3_MIN_W")) : P3D_W3_MIN_W; return v; }
+static inline bool p3d_env_no_w3() { static const bool v = getenv("P3D_NO_W3") != nullptr; return v; }
+void p3d_launch_conv_plain(const ConvParams& p, hipStream_t st);            // p3d_conv_plain.hip
+void p3d_launch_conv_up(const ConvParams& p, int kind, hipStream_t st);     // p3d_conv_up.hip
+void p3d_launch_fir_pass(const FirParams& q, char* yimg, long long lo_off, unsigned int* sat, hipStream_t st);  // p3d_fir.hip
+int p3d_up4_shape(int N, int O, int H, int W);                               // p3d_conv_up4.hip
+int p3d_up4_launch(const ConvParams& p, int rpw, hipStream_t st);
