@@ -65,7 +65,7 @@ static int layouts_agree() {
                                offsetof(p3d_conv_args, O), offsetof(p3d_conv_args, ks), offsetof(p3d_conv_args, up),
                                offsetof(p3d_conv_args, demodulate), offsetof(p3d_conv_args, noise_per_sample), offsetof(p3d_conv_args, act),
                                offsetof(p3d_conv_args, mma), offsetof(p3d_conv_args, alpha), offsetof(p3d_conv_args, gain),
-                               offsetof(p3d_conv_args, clamp), offsetof(p3d_conv_args, rgb_channels)};
+                               offsetof(p3d_conv_args, clamp), offsetof(p3d_conv_args, rgb_channels), offsetof(p3d_conv_args, w_f16_layout)};
         const int n = p3d_struct_layout(P3D_STRUCT_CONV_ARGS, lib, 64);
         if (n != (int)(sizeof(mine) / sizeof(mine[0]))) return 0;
         for (int i = 0; i < n; ++i) if (lib[i] != mine[i]) return 0;
@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
     a.N = N; a.I = I; a.H = H; a.W = W; a.O = O; a.ks = 3; a.up = up; a.demodulate = 1; a.noise_per_sample = 0; a.act = 1; a.mma = P3D_CONV_MMA_F16X2;
     a.alpha = 0.2f; a.gain = 1.41421356237309515f; a.clamp = -1.0f;
     a.rgb_w = nullptr; a.rgb_styles = nullptr; a.rgb_partial = nullptr; a.rgb_channels = 0;  // (ABI 9: no ToRGB riding on this launch)
+    a.w_f16_layout = P3D_WLAYOUT_OIK;  // (the copy p3d_conv_weights_to_f16x2 made)
     CHECK_P3D(p3d_modconv2d_ex_f32(&a, st));
     // ToRGBLayer.forward + img = upsample2d(img) + y
     CHECK_P3D(p3d_torgb_f32(y, N, O, OH, OW, wrgb_t, ORGB, srgb, brgb, -1.0f, skip, fir, img, st));

@@ -26,7 +26,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an argument list or a workspace size changes: the binding checks p3d_abi_version() against
  * the value it was written for, so that a stale libpanic3d_hip.so is refused instead of being called with the wrong layout. */
-#define P3D_ABI_VERSION 9  /* 9: p3d_conv_args rgb_* (a block's ToRGB on its conv1 launch), p3d_conv_fuses_torgb, p3d_torgb_partial_bytes, p3d_torgb_combine_f32; 8: p3d_conv_takes_image, the convolution workspace must be 256-byte aligned; 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
+#define P3D_ABI_VERSION 9  /* 9: p3d_conv_args rgb_* (a block's ToRGB on its conv1 launch), p3d_conv_fuses_torgb, p3d_torgb_partial_bytes, p3d_torgb_combine_f32; p3d_conv_args.w_f16_layout, p3d_conv_weight_layout, p3d_conv_weights_to_f16x2_layout; 8: p3d_conv_takes_image, the convolution workspace must be 256-byte aligned; 7: p3d_struct_layout, p3d_decode_features_f32; 6: p3d_conv_args x_img / y_img / y_img_styles, p3d_act_to_image_f32; 5: caller-owned saturation flag, p3d_modconv2d_ex_f32, p3d_torgb_f32 */
 
 #define P3D_OK 0
 #define P3D_E_ARG (-1)       /* null pointer / non-positive size */
@@ -286,6 +286,7 @@ typedef struct p3d_conv_args {
     int32_t N, I, H, W, O, ks, up, demodulate, noise_per_sample, act, mma;
     float alpha, gain, clamp;
     int32_t rgb_channels;      /* ToRGB output channels (1 .. 4) with rgb_partial */
+    int32_t w_f16_layout;      /* P3D_WLAYOUT_* of w_f16 (mma = F16X2, ks = 3); 0 = P3D_WLAYOUT_OIK */
 } p3d_conv_args;
 int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
 
@@ -298,6 +299,22 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* args, void* stream);
  * and the up-sampled skip image (p3d_torgb_f32's epilogue: same taps, same order): y [N][O][H][W].  The channel sum runs in another
  * order than p3d_torgb_f32's (fp32-class agreement, not bit equality). */
 int p3d_conv_fuses_torgb(int N, int I, int O, int H, int W, int rgb_channels);
+
+/* Layouts of the two-term f16 copy of a 3x3 layer's weights (ABI 9).  P3D_WLAYOUT_OIK: [hi | lo][O][9][I] (p3d_conv_weights_to_f16x2;
+ * every kernel reads it).  The pipelined kernels stage a 16-channel chunk of weights with buffer_load ... lds; out of the OIK layout a
+ * request gathers 64 16-byte pieces 9 * I * 2 bytes apart — 64 cache lines, each shared with other slices' workgroups.  The two image
+ * layouts store, per (chunk, channel tile), exactly the bytes the consuming kernel keeps in LDS, consecutively, so a request is 1 KB of
+ * consecutive memory (measured: -10 % on the 256 -> 256 @256^2 layer, -5 .. -20 % on the smaller ones; bit-identical results):
+ *   P3D_WLAYOUT_PLAIN  [I/16][O/64][dx 3][hi | lo][dy 3][k half 2][64 o][8]   plain 3x3 layers on k_modconv_w3 (O % 64 == 0)
+ *   P3D_WLAYOUT_UP     [I/16][O/32][hi | lo][tap 9][k half 2][32 o][8]        up-sampling layers on k_modconv_up3 / _up4 (O % 32 == 0)
+ * p3d_conv_weight_layout(I, O, W, up): the layout the library wants for a layer of that shape (W: the INPUT map's width) — the one its
+ * dispatch can consume; a copy in another layout than OIK handed to a layer that does not run on the matching kernel is P3D_E_RANGE.
+ * p3d_conv_weights_to_f16x2_layout converts into any of the three (same bytes, another order; same size). */
+#define P3D_WLAYOUT_OIK 0
+#define P3D_WLAYOUT_PLAIN 1
+#define P3D_WLAYOUT_UP 2
+int p3d_conv_weight_layout(int I, int O, int W, int up);
+int p3d_conv_weights_to_f16x2_layout(const float* w, int O, int I, int ks, int layout, void* w_f16x2, void* stream);
 size_t p3d_torgb_partial_bytes(int N, int O, int H, int W, int rgb_channels);
 int p3d_torgb_combine_f32(const float* partial, int tiles, int N, int O, int H, int W, const float* bias, float clamp, const float* skip,
                           const float* skip_fir, float* y, void* stream);

@@ -45,10 +45,11 @@ class ConvArgs(C.Structure):
                                           "saturated", "x_img", "y_img", "y_img_styles", "rgb_w", "rgb_styles", "rgb_partial")] + \
                [("workspace_bytes", C.c_size_t)] + \
                [(n, C.c_int32) for n in ("N", "I", "H", "W", "O", "ks", "up", "demodulate", "noise_per_sample", "act", "mma")] + \
-               [(n, C.c_float) for n in ("alpha", "gain", "clamp")] + [("rgb_channels", C.c_int32)]
+               [(n, C.c_float) for n in ("alpha", "gain", "clamp")] + [("rgb_channels", C.c_int32), ("w_f16_layout", C.c_int32)]
 
 
 P3D_CONV_MMA_F32, P3D_CONV_MMA_F16, P3D_CONV_MMA_F16X2 = 0, 1, 2
+P3D_WLAYOUT_OIK, P3D_WLAYOUT_PLAIN, P3D_WLAYOUT_UP = 0, 1, 2
 
 # symbol -> (restype, argtypes); every function include/panic3d_hip.h declares
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -83,6 +84,8 @@ SIGNATURES = {
     "p3d_act_image_bytes": (_Z, [_I, _I, _I, _I]),
     "p3d_act_to_image_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "p3d_conv_fuses_torgb": (_I, [_I, _I, _I, _I, _I, _I]),
+    "p3d_conv_weight_layout": (_I, [_I, _I, _I, _I]),
+    "p3d_conv_weights_to_f16x2_layout": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "p3d_torgb_partial_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "p3d_torgb_combine_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "p3d_torgb_weights_f32": (_I, [_P, _I, _I, _P, _P]),

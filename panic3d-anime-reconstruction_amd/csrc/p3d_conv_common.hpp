@@ -28,6 +28,8 @@ struct ConvParams {
     const float* w;       // [O][I][ks][ks]
     const void* wh;       // f16 copy [O][ks*ks][I] (f16-operand kernels) or null
     int wsplit;           // wh holds hi parts followed by lo parts (two-term operands)
+    int wlayout;          // P3D_WLAYOUT_*: how the two-term copy of the 3x3 weights is laid out (round 6): 0 = [hi|lo][O][9][I]; 1 / 2 = the
+                          // consuming kernel's own LDS image per (16-channel chunk, channel tile), see include/panic3d_hip.h
     const float* styles;  // [N][I]
     const float* dcoef;   // [N][O] or null
     const float* noise;   // [OH*OW] (shared) or [N][OH*OW] or null; already multiplied by noise_strength

@@ -414,20 +414,25 @@ __global__ __launch_bounds__(256, 2) void k_modconv_w3(ConvParams p) {
     };
     // Weights: piece q = u * 256 + tid of a group = (hi|lo, dy, k half, o); group g (dx = g - 1) adds g * I * 2 bytes
     const int LO = p.O * 9 * p.I * 2;  // bytes of the hi tensor (the lo parts follow it)
+    // P3D_WLAYOUT_PLAIN: the weights arrive as this kernel's LDS image [chunk][O/64][dx][hi|lo][dy][k half][64 o][8] — a group of a
+    // chunk is 12 KB of consecutive bytes and a request 1 KB of them, instead of 64 16-byte pieces 9 * I * 2 bytes apart (64 cache lines
+    // a request, each shared with other slices' workgroups on other XCDs): measured -10 % on the 256 -> 256 @256^2 layer, bit-identical
+    const bool wlds = p.wlayout == P3D_WLAYOUT_PLAIN;
     int wvoff[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int q = u * 256 + tid, which = q / 384, rem = q - which * 384;
         const int dyi = rem >> 7, kh = (rem >> 6) & 1, o = rem & 63;
-        wvoff[u] = which * LO + (((o0 + o) * 9 + dyi * 3) * p.I + 8 * kh) * 2;
+        wvoff[u] = wlds ? q * 16 : which * LO + (((o0 + o) * 9 + dyi * 3) * p.I + 8 * kh) * 2;
     }
     auto w_rsrc = [&](int chunk) {
         const int ic0 = ic_beg + 16 * chunk;
         const bool in = chunk < nch;
+        if (wlds) return w3_rsrc((const char*)p.wh + (size_t)(((in ? ic0 >> 4 : 0) * (p.O >> 6) + (o0 >> 6)) * 3) * W3_GROUP_BYTES, in ? 3u * W3_GROUP_BYTES : 0u);
         return w3_rsrc((const char*)p.wh + (size_t)(in ? ic0 : 0) * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
     };
     auto w_piece = [&](const i32x4& rs, int g, int u) {
-        w3_dma16(lds0 + g * W3_GROUP_BYTES + wave * 1024 + u * 4096, rs, wvoff[u] + g * p.I * 2);
+        w3_dma16(lds0 + g * W3_GROUP_BYTES + wave * 1024 + u * 4096, rs, wvoff[u] + g * (wlds ? W3_GROUP_BYTES : p.I * 2));
     };
 
     f32x16 acc[2][2];  // [channel tile][row of the wave's row pair]

@@ -180,12 +180,15 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
     // Weights: 1152 pieces (hi|lo, tap, k half, o) = 18 instructions; wave w issues instructions w, w + 4, ...
     const int LO = p.O * 9 * p.I * 2;
+    const bool wlds = p.wlayout == P3D_WLAYOUT_UP;
     int wvoff[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int q = (wave + 4 * i) * 64 + lane, which = q / 576, rem = q - which * 576;
         const int tap = rem >> 6, kh = (rem >> 5) & 1, o = rem & 31;
-        wvoff[i] = (q < 1152 && o0 + o < p.O) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
+        // P3D_WLAYOUT_UP: the weights arrive as this kernel's LDS image [chunk][O/32][hi|lo][tap][k half][32 o][8] (18 KB of consecutive bytes
+        // per chunk and channel tile, a request = 1 KB of them); else 16-byte pieces gathered out of [hi|lo][O][9][I]
+        wvoff[i] = q >= 1152 ? CONV_OOB : wlds ? q * 16 : (o0 + o < p.O) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
     }
     const bool five = wave < 2;  // instructions 16, 17 exist for waves 0, 1 only
     // piece i of chunk `chunk` into buffer `buf`: 0 .. 4 the patch (4: partial), 5 .. 9 the weights (9: waves 0, 1).  chunk >= nch: a
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
         const int ic0 = in ? ic_beg + 16 * chunk : 0;
         U3Rs r;
         r.rp = w3_rsrc(img_base + (size_t)(ic0 >> 3) * HW * 16, in ? 2u * HW * 16u : 0u);
-        r.rw = w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
+        if (wlds) r.rw = w3_rsrc((const char*)p.wh + (size_t)((ic0 >> 4) * (p.O >> 5) + (o0 >> 5)) * U3_WB, in ? (uint32_t)U3_WB : 0u);
+        else r.rw = w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
         return r;
     };
     auto piece = [&](const U3Rs& r, int buf, int i) {  // i: compile-time after unrolling

@@ -92,12 +92,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
     // Weights: 1152 pieces (hi|lo, tap, k half, o) = 18 instructions: wave w issues instructions w, w + NW, ... (the last round: waves 0, 1)
     const int LO = p.O * 9 * p.I * 2;
+    const bool wlds = p.wlayout == P3D_WLAYOUT_UP;
     int wvoff[C::WPW];
 #pragma unroll
     for (int i = 0; i < C::WPW; ++i) {
         const int q = (wave + NW * i) * 64 + lane, which = q / 576, rem = q - which * 576;
         const int tap = rem >> 6, kh = (rem >> 5) & 1, o = rem & 31;
-        wvoff[i] = (q < 1152) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
+        wvoff[i] = q >= 1152 ? CONV_OOB : wlds ? q * 16 : which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2;  // (P3D_WLAYOUT_UP: k_modconv_up3's image)
     }
     // chunk >= nch: a zero-length resource (zeros into an idle buffer, no traffic, the same instruction count)
     auto patch_rsrc = [&](int chunk) {
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_modconv_up4(ConvParams p) {
     auto weight_rsrc = [&](int chunk) {
         const bool in = chunk < nch;
         const int ic0 = in ? 16 * chunk : 0;
+        if (wlds) return w3_rsrc((const char*)p.wh + (size_t)((in ? chunk : 0) * (p.O >> 5) + (o0 >> 5)) * U3_WB, in ? (uint32_t)U3_WB : 0u);
         return w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
     };
     uint32_t pdst[C::NPW];  // (wave-uniform)

@@ -2089,7 +2089,7 @@ int p3d_struct_layout(int which, size_t* out, int cap) {
         P3D_OFF(p3d_conv_args, N); P3D_OFF(p3d_conv_args, I); P3D_OFF(p3d_conv_args, H); P3D_OFF(p3d_conv_args, W); P3D_OFF(p3d_conv_args, O);
         P3D_OFF(p3d_conv_args, ks); P3D_OFF(p3d_conv_args, up); P3D_OFF(p3d_conv_args, demodulate); P3D_OFF(p3d_conv_args, noise_per_sample);
         P3D_OFF(p3d_conv_args, act); P3D_OFF(p3d_conv_args, mma);
-        P3D_OFF(p3d_conv_args, alpha); P3D_OFF(p3d_conv_args, gain); P3D_OFF(p3d_conv_args, clamp); P3D_OFF(p3d_conv_args, rgb_channels);
+        P3D_OFF(p3d_conv_args, alpha); P3D_OFF(p3d_conv_args, gain); P3D_OFF(p3d_conv_args, clamp); P3D_OFF(p3d_conv_args, rgb_channels); P3D_OFF(p3d_conv_args, w_f16_layout);
         break;
     default:
         return P3D_E_RANGE;

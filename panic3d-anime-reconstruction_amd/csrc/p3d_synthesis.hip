@@ -10,16 +10,36 @@
 #include "p3d_conv_common.hpp"
 #define chk chk_launch
 
-// w [O][I][kk] f32 -> wh [O][kk][I] f16 (RNE), once per layer; split: followed by the lo parts f16(w - hi) in the same layout
-__global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int kk, _Float16* __restrict__ wh, int split) {
+// w [O][I][kk] f32 -> wh [O][kk][I] f16 (RNE), once per layer; split: followed by the lo parts f16(w - hi) in the same layout.
+// layout (split, kk = 9): P3D_WLAYOUT_PLAIN / _UP — the same values in the order the pipelined kernels keep them in LDS
+// (include/panic3d_hip.h): element (which, o, tap = 3 dy + dx, i) goes to
+//   PLAIN: ((((((c OT + ot) 3 + dx) 2 + which) 3 + dy) 2 + kh) 64 + ol) 8 + e,  c = i / 16, kh = (i / 8) % 2, e = i % 8, ot = o / 64, ol = o % 64
+//   UP:    (((((c OT + ot) 2 + which) 9 + tap) 2 + kh) 32 + ol) 8 + e,           ot = o / 32, ol = o % 32
+__global__ void k_weights_to_f16(const float* __restrict__ w, int O, int I, int kk, _Float16* __restrict__ wh, int split, int layout) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)O * I * kk;
     if (idx >= total) return;
     const int i = (int)(idx % I), t = (int)((idx / I) % kk), o = (int)(idx / ((long long)I * kk));
     float v = w[((long long)o * I + i) * kk + t];
     if (split) v = fminf(fmaxf(v * HX_SPLIT_SCALE_W, -65504.0f), 65504.0f);
-    const _Float16 hi = (_Float16)v;
-    wh[idx] = hi;
-    if (split) wh[total + idx] = (_Float16)(v - (float)hi);
+    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+    if (layout == P3D_WLAYOUT_OIK) {
+        wh[idx] = hi;
+        if (split) wh[total + idx] = lo;
+        return;
+    }
+    const int c = i >> 4, kh = (i >> 3) & 1, e = i & 7;
+    long long d0, dlo;  // destination of the hi part, distance to the lo part
+    if (layout == P3D_WLAYOUT_PLAIN) {
+        const int ot = o >> 6, ol = o & 63, dy = t / 3, dx = t - 3 * dy;
+        d0 = (((((((long long)c * (O >> 6) + ot) * 3 + dx) * 2 + 0) * 3 + dy) * 2 + kh) * 64 + ol) * 8 + e;
+        dlo = 3 * 2 * 64 * 8;
+    } else {
+        const int ot = o >> 5, ol = o & 31;
+        d0 = ((((((long long)c * (O >> 5) + ot) * 2 + 0) * 9 + t) * 2 + kh) * 32 + ol) * 8 + e;
+        dlo = 9 * 2 * 32 * 8;
+    }
+    wh[d0] = hi;
+    wh[d0 + dlo] = lo;
 }
 
 // fp32 activation [N][C][H][W] -> image for a consumer with styles s [N][C] (null: 1): split(16 * s * x); C % 8 == 0.  One thread
@@ -250,6 +270,17 @@ size_t p3d_modconv2d_workspace_bytes(int N, int I, int O, int H, int W, int up) 
     return b + 256;
 }
 
+// the layout of the two-term weight copy the dispatch of a 3x3 layer can consume (W: the input map's width): the image layouts where
+// the layer runs on the pipelined kernels whatever its batch size and split-K depth, OIK elsewhere; P3D_WLAYOUT=0 in the environment
+// (read once): OIK everywhere (A/B runs)
+int p3d_conv_weight_layout(int I, int O, int W, int up) {
+    static const bool off = getenv("P3D_WLAYOUT") && atoi(getenv("P3D_WLAYOUT")) == 0;
+    if (off || I <= 0 || O <= 0 || W <= 0 || I % 16 != 0) return P3D_WLAYOUT_OIK;
+    if (up == 1 && O % 64 == 0 && W >= p3d_w3_min_w() && !p3d_env_no_w3()) return P3D_WLAYOUT_PLAIN;
+    if (up == 2 && up3_applies(I, O, W)) return P3D_WLAYOUT_UP;
+    return P3D_WLAYOUT_OIK;
+}
+
 // the rule by which an image-consuming layer is accepted (p3d_conv_args.x_img): exported so that a binding cannot drift from it
 int p3d_conv_takes_image(int I, int O, int W, int up) {
     if (I <= 0 || O <= 0 || W <= 0 || I % 16 != 0) return 0;
@@ -269,8 +300,11 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
                         const float* styles, int demodulate, const float* dcoef_in, const float* noise, int noise_per_sample, const float* bias,
                         int up, int act, float alpha, float gain, float clamp, const float* fir, float* y, void* workspace,
                         size_t workspace_bytes, void* stream, unsigned int* sat = nullptr, const void* ximg = nullptr,
-                        void* yimg = nullptr, const float* ystyles = nullptr, const RgbFuse* rgb = nullptr) {
+                        void* yimg = nullptr, const float* ystyles = nullptr, const RgbFuse* rgb = nullptr, int wlayout = P3D_WLAYOUT_OIK) {
     if (rgb && !rgb->partial) rgb = nullptr;
+    // a weight copy in one of the image layouts: only for a layer that runs on the kernel whose LDS image it is (an fp32 input is
+    // turned into an activation image first, so the pipelined kernels take those layers whichever way their input arrives)
+    if (wlayout != P3D_WLAYOUT_OIK && (!wh || !wsplit || ks != 3 || wlayout != p3d_conv_weight_layout(I, O, W, up))) return P3D_E_RANGE;
     if ((!x && !ximg) || !w || (!styles && !ximg) || (!y && !yimg && !rgb) || (y && yimg && up == 2) || (!y && up == 1 && !rgb) || !workspace || N <= 0 ||
         I <= 0 || O <= 0 || H <= 0 || W <= 0)
         return P3D_E_ARG;
@@ -330,7 +364,7 @@ static int modconv_impl(const float* x, int N, int I, int H, int W, const float*
     p.x = x; p.w = w; p.wh = wh; p.wsplit = wsplit; p.styles = styles; p.dcoef = demodulate ? dco : nullptr; p.noise = noise; p.bias = bias;
     p.N = N; p.I = I; p.O = O; p.H = H; p.W = W; p.ks = ks; p.noise_per_sample = noise_per_sample;
     p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp; p.ksplit = ksplit; p.OH = OH; p.OW = OW; p.sat = sat;
-    p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2; p.tox = up == 2 ? 1 : 0;
+    p.ximg = ximg; p.ximg_lo = (long long)N * I * H * W * 2; p.tox = up == 2 ? 1 : 0; p.wlayout = wlayout;
     p.rgbw = rgb ? rgb->w : nullptr; p.rgbs = rgb ? rgb->styles : nullptr; p.rgbp = rgb ? rgb->partial : nullptr; p.rgbo = rgb ? rgb->channels : 0;
     static const bool xcd_order = !getenv("P3D_NO_XCD_ORDER");  // (A/B runs)
     p.xcd = xcd_order ? 1 : 0;
@@ -420,13 +454,18 @@ int p3d_demod_coefs_f32(const float* w2, const float* styles, const int32_t* tab
     return chk();
 }
 
-static int weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, int split, void* stream) {
+static int weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, int split, void* stream, int layout = P3D_WLAYOUT_OIK) {
     if (!w || !w_f16 || O <= 0 || I <= 0) return P3D_E_ARG;
     if (ks != 1 && ks != 3) return P3D_E_RANGE;
+    if (layout != P3D_WLAYOUT_OIK && (!split || ks != 3 || I % 16 != 0 || (layout == P3D_WLAYOUT_PLAIN ? O % 64 != 0 : layout == P3D_WLAYOUT_UP ? O % 32 != 0 : true)))
+        return P3D_E_RANGE;
     const long long total = (long long)O * I * ks * ks;
     hipLaunchKernelGGL(k_weights_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, O, I, ks * ks,
-                       (_Float16*)w_f16, split);
+                       (_Float16*)w_f16, split, layout);
     return chk();
+}
+int p3d_conv_weights_to_f16x2_layout(const float* w, int O, int I, int ks, int layout, void* w_f16x2, void* stream) {
+    return weights_to_f16(w, O, I, ks, w_f16x2, 1, stream, layout);
 }
 int p3d_conv_weights_to_f16(const float* w, int O, int I, int ks, void* w_f16, void* stream) {
     return weights_to_f16(w, O, I, ks, w_f16, 0, stream);
@@ -459,7 +498,7 @@ int p3d_modconv2d_ex_f32(const p3d_conv_args* a, void* stream) {
     const RgbFuse rgb = {a->rgb_w, a->rgb_styles, a->rgb_partial, a->rgb_channels};
     return modconv_impl(a->x, a->N, a->I, a->H, a->W, a->w, wh, wsplit, a->O, a->ks, a->styles, a->demodulate, a->demod_coefs, a->noise,
                         a->noise_per_sample, a->bias, a->up, a->act, a->alpha, a->gain, a->clamp, a->fir, a->y, a->workspace, a->workspace_bytes,
-                        stream, (wsplit || a->y_img) ? (unsigned int*)a->saturated : nullptr, a->x_img, a->y_img, a->y_img_styles, &rgb);
+                        stream, (wsplit || a->y_img) ? (unsigned int*)a->saturated : nullptr, a->x_img, a->y_img, a->y_img_styles, &rgb, a->w_f16_layout);
 }
 
 size_t p3d_act_image_bytes(int N, int C, int H, int W) { return (size_t)N * C * H * W * 4; }

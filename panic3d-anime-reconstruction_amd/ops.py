@@ -685,12 +685,41 @@ def torgb_combine(partial, bias=None, clamp=None, skip=None, skip_filter=None):
     return y
 
 
-def conv_weights_to_f16(weight, split=False):
+class WeightOperand(torch.Tensor):
+    """The two-term copy of a layer's weights in one of the image layouts (P3D_WLAYOUT_PLAIN / _UP: the consuming kernel's LDS image per
+    chunk and channel tile, include/panic3d_hip.h): the same [2,O,9,I] float16 storage size, ANOTHER element order — the subclass
+    carries which one (`p3d_layout`) so that modulated_conv2d can tell the library."""
+    p3d_layout = 0
+
+
+_WLAYOUT = {}
+
+
+def conv_weight_layout(I, O, W, up):
+    """The layout of the two-term weight copy the LIBRARY wants for a 3x3 layer of this shape (p3d_conv_weight_layout; W: the input
+    map's width): asked, not restated; fixed for the life of the process."""
+    key = (int(I), int(O), int(W), int(up))
+    r = _WLAYOUT.get(key)
+    if r is None:
+        r = _WLAYOUT[key] = int(_lib.lib().p3d_conv_weight_layout(*key))
+    return r
+
+
+def conv_weights_to_f16(weight, split=False, layout=0):
     """[O,I,k,k] f32 -> the [O,k*k,I] f16 operand copy of the f16-operand convolution (made once per layer); split: the
-    [2,O,k*k,I] hi / lo pair of the two-term variant (hi = f16(w), lo = f16(w - hi))."""
+    [2,O,k*k,I] hi / lo pair of the two-term variant (hi = f16(w), lo = f16(w - hi)).  layout (split, 3x3): conv_weight_layout(...) of
+    the layer the copy is for — non-zero: a WeightOperand in that image layout (same bytes, the pipelined kernels' own order)."""
     weight = _chk(weight, "weight")
     O, I, kh, kw = weight.shape
     wh = torch.empty((2, O, kh * kw, I) if split else (O, kh * kw, I), dtype=torch.float16, device=weight.device)
+    if layout:
+        if not split:
+            raise RuntimeError("conv_weights_to_f16: the image layouts are two-term layouts (split=True)")
+        with _on(weight.device):
+            _lib.check(_lib.lib().p3d_conv_weights_to_f16x2_layout(_p(weight), O, I, kh, int(layout), _p(wh), _stream()), "p3d_conv_weights_to_f16x2_layout")
+        wh = wh.as_subclass(WeightOperand)
+        wh.p3d_layout = int(layout)
+        return wh
     with _on(weight.device):
         if split:
             _lib.check(_lib.lib().p3d_conv_weights_to_f16x2(_p(weight), O, I, kh, _p(wh), _stream()), "p3d_conv_weights_to_f16x2")
@@ -893,7 +922,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
                           next_styles.data_ptr() if yimg is not None else None,
                           rgb_weight.data_ptr() if rgb else None, rgb_styles.data_ptr() if rgb else None, rgbp.data_ptr() if rgb else None,
                           ws.numel(), N, I, H, W, O, kh, int(up), int(bool(demodulate)), nps, idx, mma, float(da), gain, clampv,
-                          int(rgb_weight.shape[0]) if rgb else 0)
+                          int(rgb_weight.shape[0]) if rgb else 0, int(getattr(weight_f16, "p3d_layout", 0)))
         _lib.check(L.p3d_modconv2d_ex_f32(C.byref(a), _stream()), "p3d_modconv2d_ex_f32")
     if rgb:
         return y, yimg, rgbp

@@ -191,7 +191,10 @@ def _f16_operand(layer):
     key = (w.data_ptr(), w._version, mode)
     d = layer.__dict__
     if d.get("_wh_key") != key or not memo.enabled():
-        d["_wh"], d["_wh_key"] = ops.conv_weights_to_f16(w.detach(), split=(mode == "x2")), key
+        # (two-term 3x3 layers: in the layout the library's dispatch of THIS layer consumes — the pipelined kernels' own LDS image)
+        up = layer.__dict__.get("up", 1)
+        lay = ops.conv_weight_layout(layer.in_channels, w.shape[0], layer.__dict__.get("resolution", 0) // up, up) if (mode == "x2" and w.shape[-1] == 3 and "resolution" in layer.__dict__) else 0
+        d["_wh"], d["_wh_key"] = ops.conv_weights_to_f16(w.detach(), split=(mode == "x2"), layout=lay), key
         f = d.get("conv_domain_flag")
         if isinstance(f, DomainFlags):  # new weights (load_state_dict, copy_params_and_buffers, an optimiser step): check their domain once
             f.dirty = True

@@ -103,6 +103,7 @@ def install(monkeypatch, ops):
 
     for name, fn in dict(act_to_image=act_to_image, modulated_conv2d=modulated_conv2d, torgb=torgb, demod_coefs=demod_coefs,
                          torgb_weights=lambda w: w.to(torch.float32), bias_act=bias_act, upsample2d=upsample2d, upsample2d_add=upsample2d_add,
-                         conv_weights_to_f16=lambda w, split=False: torch.zeros((2,) + (w.shape[0], w.shape[2] * w.shape[3], w.shape[1]) if split
-                                                                                  else (w.shape[0], w.shape[2] * w.shape[3], w.shape[1]), dtype=torch.float16)).items():
+                         conv_weight_layout=lambda I, O, W, up: 0,
+                         conv_weights_to_f16=lambda w, split=False, layout=0: torch.zeros((2,) + (w.shape[0], w.shape[2] * w.shape[3], w.shape[1]) if split
+                                                                                            else (w.shape[0], w.shape[2] * w.shape[3], w.shape[1]), dtype=torch.float16)).items():
         monkeypatch.setattr(ops, name, fn)

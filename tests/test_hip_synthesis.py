@@ -1072,3 +1072,39 @@ def test_superresolution_with_torgb_on_conv1_matches_the_separate_launches(hip, 
         assert len(seen) == 2
     mse = float(((a - b).double() ** 2).mean())
     assert a.shape == (1, 3, 512, 512) and 10 * np.log10(4.0 / max(mse, 1e-30)) >= 120.0, mse
+
+
+@pytest.mark.parametrize("N,I,O,H,up", [(1, 256, 256, 64, 1), (2, 64, 128, 40, 1), (1, 512, 512, 32, 1), (1, 256, 128, 128, 2), (1, 512, 512, 8, 2),
+                                        (2, 64, 96, 24, 2), (1, 32, 256, 64, 2), (1, 512, 256, 64, 2)])
+def test_weight_image_layouts_are_bit_identical_to_the_oik_layout(hip, N, I, O, H, up):
+    """Round 6: the two-term weight copy in the consuming kernel's own LDS image order (P3D_WLAYOUT_PLAIN for k_modconv_w3, _UP for
+    k_modconv_up3 / _up4: 1 KB of consecutive memory per staging request instead of 64 scattered 16-byte pieces).  Another element
+    order of the same values: every path (unsplit, split-K, the one-launch up layer, image in / image out) must give the same bits
+    as the [hi|lo][O][9][I] copy; a copy in the wrong image layout is refused."""
+    ops = hip.ops
+    torch.manual_seed(3)
+    d = torch.device("cuda")
+    x = torch.randn(N, I, H, H, device=d)
+    w = torch.randn(O, I, 3, 3, device=d) / np.sqrt(9 * I)
+    s, s2 = torch.randn(N, I, device=d) * 0.3 + 1.0, torch.randn(N, O, device=d) * 0.3 + 1.0
+    b, nz = torch.randn(O, device=d) * 0.1, torch.randn(H * up, H * up, device=d) * 0.05
+    dco = ((w[None] * s[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    f = ops.setup_filter((1, 3, 3, 1)).to(d)
+    lay = ops.conv_weight_layout(I, O, H, up)
+    assert lay == (1 if up == 1 else 2)
+    w0, w1 = ops.conv_weights_to_f16(w, split=True), ops.conv_weights_to_f16(w, split=True, layout=lay)
+    assert w1.p3d_layout == lay and w1.shape == w0.shape and not torch.equal(w0, w1) and torch.equal(w0.flatten().sort()[0], w1.flatten().sort()[0])
+    kw = dict(up=up, padding=1, resample_filter=f, demodulate=True, bias=b, act="lrelu", dcoef=dco, noise=nz)
+    img = ops.act_to_image(x, s)
+    for inp, st in ((x, s), (img, None)):
+        a = ops.modulated_conv2d(inp, w, st, weight_f16=w0, **kw)
+        c = ops.modulated_conv2d(inp, w, st, weight_f16=w1, **kw)
+        assert torch.equal(a, c)
+        a = ops.modulated_conv2d(inp, w, st, weight_f16=w0, next_styles=s2, **kw)
+        c = ops.modulated_conv2d(inp, w, st, weight_f16=w1, next_styles=s2, **kw)
+        a, c = (a, c) if up == 2 else (a[1], c[1])
+        assert torch.equal(a.data, c.data)
+    wrong = ops.conv_weights_to_f16(w, split=True, layout=3 - lay) if O % 64 == 0 else None
+    if wrong is not None:
+        with pytest.raises(RuntimeError):
+            ops.modulated_conv2d(img, w, None, weight_f16=wrong, **kw)
