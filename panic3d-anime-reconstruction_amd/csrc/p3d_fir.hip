@@ -425,6 +425,143 @@ __global__ void k_bias_act(const float* __restrict__ x, const float* __restrict_
     y[idx] = act_apply(v, act, alpha, gain, clamp);
 }
 
+// k_fir4x4_img2<RB> (round 6): k_fir4x4_img for the aligned intermediate (pitch % 4 == 0, xoff == padx0 == pady0 == 1, 4x4 filter,
+// up = down = 1) with k_modconv_up4's filter stage: a row of the tile is read by SIXTEEN lanes (4-pixel windows 16 bytes apart), so
+// that every 16-lane group of a ds_read_b128 covers 256 consecutive bytes of one row: no bank conflicts at any pitch (k_fir4x4_img:
+// 8 lanes per 40-float row, two rows per group: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 3.2-4.4).  A workgroup = 8 channels (one
+// 16-byte piece per pixel) x RB output rows x 64 columns: the intermediate's rows Y0 - 1 .. Y0 + RB + 1, columns X0 - 1 .. X0 + 66 (68
+// floats per row) — at index X0 + i of a row of the padded intermediate (column v sits at index v + 1): an aligned copy, masked
+// outside [0, W) x [0, H).
+// Split-K partials are summed in slice order while the tile is loaded (as k_fir4x4_img); the same 16-term fma chain and the same
+// epilogue: bit-identical to k_fir4x4_img.  RB = 32 (35 rows x 68 floats x 8 channels = 76 160 B: two workgroups per CU) / 8 (small maps: more
+// workgroups).
+template <int RB>
+__global__ __launch_bounds__(256, 2) void k_fir4x4_img2(FirParams p, char* __restrict__ yimg, long long lo_off, unsigned int* sat) {
+    constexpr int TR = RB + 3, RP = 68, C4 = RP / 4, PLANE = TR * RP;  // RP: floats per tile row
+    __shared__ __attribute__((aligned(16))) float tile[8 * PLANE];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.OW + 63) / 64;
+    const int X0 = (blockIdx.x % tiles_x) * 64, Y0 = (blockIdx.x / tiles_x) * RB;
+    const long long g = blockIdx.y;  // (n, c8)
+    const long long n = g / (p.C >> 3);
+    const int c0 = (int)(g - n * (p.C >> 3)) * 8;
+    const int HP = p.H * p.pitch;
+    const float* xg = p.x + (n * p.C + c0) * (long long)HP;
+    float fs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.f[i])));
+    // ---- the tile: item = (channel, row, 4-column group); rows / columns outside the intermediate are zeros (the filter's padding).
+    // Nine items per thread are requested together (and then each further split-K slice of the nine): two rounds of loads per slice
+    // instead of one exposed round trip per item
+    constexpr int ITEMS = 8 * TR * C4, NIT = (ITEMS + 255) / 256, BATCH = NIT > 10 ? 10 : NIT;
+#pragma unroll 1
+    for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+        f32x4 v[BATCH];
+        const float* src[BATCH];
+        int dst[BATCH], colb[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int it = tid + (b0 + i) * 256;
+            const int ch = it / (TR * C4), rem = it - ch * (TR * C4), r = rem / C4, c4 = rem - r * C4;
+            const int u = Y0 - 1 + r;
+            ok[i] = it < ITEMS && u >= 0 && u < p.H && X0 + 4 * c4 < p.pitch;
+            src[i] = ok[i] ? xg + (size_t)ch * HP + (size_t)u * p.pitch + X0 + 4 * c4 : xg;  // (a valid address either way: no branch around the load)
+            dst[i] = it < ITEMS ? ch * PLANE + r * RP + 4 * c4 : -1;
+            colb[i] = X0 - 1 + 4 * c4;
+            v[i] = *reinterpret_cast<const f32x4*>(src[i]);
+        }
+        for (int k = 1; k < p.ksplit; ++k) {  // split-K partials, slice order (= k_splitk_reduce)
+            f32x4 t[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) t[i] = *reinterpret_cast<const f32x4*>(src[i] + (size_t)k * p.slice);
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) { v[i].x += t[i].x; v[i].y += t[i].y; v[i].z += t[i].z; v[i].w += t[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = colb[i] + e;
+                if (!ok[i] || col < 0 || col >= p.W) v[i][e] = 0.0f;
+            }
+            if (dst[i] >= 0) *reinterpret_cast<f32x4*>(&tile[dst[i]]) = v[i];
+        }
+    }
+    __syncthreads();
+    bool bad = false;
+#pragma unroll 1
+    for (int it = tid; it < RB * 16; it += 256) {
+        const int ly = it >> 4, m = it & 15;
+        const int Y = Y0 + ly, Xb = X0 + 4 * m;
+        if (Y >= p.OH || Xb >= p.OW) continue;
+        const float* Tc = tile + ly * RP + 4 * m;
+        float out[8][4];
+        f32x4 wa[2][4][2];
+        auto request = [&](int set, int ch) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wa[set][r][0] = *reinterpret_cast<const f32x4*>(Tc + ch * PLANE + r * RP);
+                wa[set][r][1] = *reinterpret_cast<const f32x4*>(Tc + ch * PLANE + r * RP + 4);
+            }
+        };
+        request(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int set = ch & 1;
+            if (ch < 7) request(set ^ 1, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+                for (int fx = 0; fx < 4; ++fx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = j + fx;
+                        o[j] = __builtin_fmaf(fs[fy * 4 + fx], wa[set][fy][c >> 2][c & 3], o[j]);
+                    }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[ch][j] = o[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.noise) {
+            const float* nz = p.noise + (p.noise_per_sample ? n * p.OH * p.OW : 0) + (long long)Y * p.OW + Xb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nv[j] = (Xb + j < p.OW) ? nz[j] : 0.0f;
+        }
+        float dco[8], bs[8], ns[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            dco[ch] = p.dcoef ? p.dcoef[n * p.C + c0 + ch] : 1.0f;
+            bs[ch] = p.bias ? p.bias[c0 + ch] : 0.0f;
+            ns[ch] = p.nstyles[n * p.C + c0 + ch];
+        }
+        const size_t piece0 = ((size_t)g * p.OH + Y) * p.OW + Xb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x8 hv, lv;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                float a = out[ch][j] * dco[ch];
+                if (p.noise) a = a + nv[j];
+                a = a + bs[ch];
+                a = ns[ch] * act_apply(a, p.act, p.alpha, p.gain, p.clamp) * HX_SPLIT_SCALE_X;  // (k_fir4x4_img's epilogue, bit for bit)
+                bad = bad || (Xb + j < p.OW && !(__builtin_fabsf(a) <= 65504.0f));
+                a = __builtin_fminf(__builtin_fmaxf(a, -65504.0f), 65504.0f);
+                hv[ch] = (_Float16)a;
+                lv[ch] = (_Float16)(a - (float)hv[ch]);
+            }
+            if (Xb + j < p.OW) {
+                *reinterpret_cast<f16x8*>(yimg + (piece0 + j) * 16) = hv;
+                *reinterpret_cast<f16x8*>(yimg + lo_off + (piece0 + j) * 16) = lv;
+            }
+        }
+    }
+    if (bad && sat) atomicOr(sat, 1u);
+}
+
 // the FIR pass of an up-sampling layer (modconv_impl): q describes the (2H+1) x (2W+1) intermediate; yimg: write the next layer's image
 void p3d_launch_fir_pass(const FirParams& q, char* yimg, long long lo_off, unsigned int* sat, hipStream_t st) {
     dim3 grid(((q.OW + 31) / 32) * ((q.OH + 31) / 32), (unsigned)q.NC);
@@ -432,7 +569,17 @@ void p3d_launch_fir_pass(const FirParams& q, char* yimg, long long lo_off, unsig
         dim3 gi(grid.x, (unsigned)(q.NC / 8));
         const bool rows_aligned = (q.pitch & 3) == 0 && q.xoff == q.padx0 && (((uintptr_t)q.x | (uintptr_t)(q.slice * 4)) & 15) == 0;
         // two channels per stage: 125 VGPRs, four waves per SIMD (four per stage: 195, two; measured 2-5 % slower)
-        if (rows_aligned) hipLaunchKernelGGL((k_fir4x4_img<true, 2, 3>), gi, dim3(256), 0, st, q, yimg, lo_off, sat);
+        // k_fir4x4_img2 where k_fir4x4_img's 32 x 32 tiles are too few workgroups for the chip (512 channels at 32^2: 64 of them, 17.6 us;
+        // 8-row tiles: 256, 13.8 us).  On the larger maps the older kernel — which requests its next stage while it filters — stays ahead
+        // despite its bank conflicts (64^2: 13.3 against 15.9 us, 128^2: 20.2 against 27.8 - 30.9: measured, profiles/r06_notes.txt).
+        // P3D_FIR_IMG2=0 / 8 / 32 in the environment: never / always with that tile height (tests, A/B runs).
+        const char* e2 = getenv("P3D_FIR_IMG2");
+        const int force = e2 ? atoi(e2) : -1;
+        const bool can2 = rows_aligned && q.xoff == 1 && q.pady0 == 1 && q.fh == 4 && q.fw == 4 && force != 0;
+        if (can2 && (force == 8 || force == 32 || (long long)gi.x * gi.y < 128)) {
+            if (force == 32) hipLaunchKernelGGL((k_fir4x4_img2<32>), dim3((unsigned)(((q.OW + 63) / 64) * ((q.OH + 31) / 32)), (unsigned)(q.NC / 8)), dim3(256), 0, st, q, yimg, lo_off, sat);
+            else hipLaunchKernelGGL((k_fir4x4_img2<8>), dim3((unsigned)(((q.OW + 63) / 64) * ((q.OH + 7) / 8)), (unsigned)(q.NC / 8)), dim3(256), 0, st, q, yimg, lo_off, sat);
+        } else if (rows_aligned) hipLaunchKernelGGL((k_fir4x4_img<true, 2, 3>), gi, dim3(256), 0, st, q, yimg, lo_off, sat);
         else hipLaunchKernelGGL((k_fir4x4_img<false, 4, 2>), gi, dim3(256), 0, st, q, yimg, lo_off, sat);
     } else hipLaunchKernelGGL(k_fir4x4_tiled, grid, dim3(256), 0, st, q);
 }

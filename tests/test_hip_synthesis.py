@@ -1108,3 +1108,34 @@ def test_weight_image_layouts_are_bit_identical_to_the_oik_layout(hip, N, I, O, 
     if wrong is not None:
         with pytest.raises(RuntimeError):
             ops.modulated_conv2d(img, w, None, weight_f16=wrong, **kw)
+
+
+@pytest.mark.parametrize("N,I,O,H", [(1, 512, 512, 16), (2, 64, 128, 44), (1, 128, 64, 64), (1, 32, 40, 20)])
+def test_fir_pass_on_64_column_tiles_is_bit_identical(hip, monkeypatch, N, I, O, H):
+    """Round 6: k_fir4x4_img2 (the FIR pass that ends an up-sampling layer and writes the next layer's image, on conflict-free
+    64-column LDS rows; chosen for launches too small for k_fir4x4_img's 32 x 32 tiles) against k_fir4x4_img: both tile heights, split-K
+    partials summed inside (shallow splits), batch 2 with per-sample noise and a clamp, ragged maps (88^2, 40^2): the same image bits
+    and the same domain flag."""
+    ops = hip.ops
+    filt = ops.setup_filter([1, 3, 3, 1]).cuda()
+    g = torch.Generator().manual_seed(I * 7 + H)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    x, w0 = rn(N, I, H, H), rn(O, I, 3, 3)
+    s0, s1 = rn(N, I) * 0.4 + 1.0, rn(N, O) * 0.4 + 1.0
+    d0 = ((w0[None] * s0[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    nz = rn(N, 1, 2 * H, 2 * H) * 0.1 if N > 1 else rn(2 * H, 2 * H) * 0.1
+    kw = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz,
+              weight_f16=ops.conv_weights_to_f16(w0, split=True), clamp=1.5 if N > 1 else None, next_styles=s1)
+    monkeypatch.setenv("P3D_UP4", "0")        # the two-pass form: transposed convolution (+ reduction), then the FIR pass
+    monkeypatch.setenv("P3D_UP3_FUSED", "0")
+    out = {}
+    for mode in ("0", "8", "32"):
+        monkeypatch.setenv("P3D_FIR_IMG2", mode)
+        flag = ops.conv_domain_flag(x.device)
+        out[mode] = ops.modulated_conv2d(x, w0, s0, saturated=flag, **kw).data.clone()
+        assert not ops.conv_domain_violated(flag)
+    assert torch.equal(out["0"], out["8"]) and torch.equal(out["0"], out["32"])
+    monkeypatch.setenv("P3D_FIR_IMG2", "8")
+    flag = ops.conv_domain_flag(x.device)
+    ops.modulated_conv2d(x * 3e4, w0, s0, saturated=flag, **dict(kw, clamp=None))
+    assert ops.conv_domain_violated(flag)
