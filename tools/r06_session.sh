@@ -17,4 +17,6 @@ rgbtest() { timeout 900 python -m pytest tests/test_hip_synthesis.py -x -q -s -k
 torgbtime() { timeout 600 python tools/torgb_time.py > "$OUT/torgb_time.jsonl" 2> "$OUT/torgb_time.err"; cat "$OUT/torgb_time.jsonl"; tail -3 "$OUT/torgb_time.err"; }
 trace() { bash tools/trace_passes.sh "$TAG" > "$OUT/trace.txt" 2>&1; grep -v "^$" "$OUT/trace.txt" | cut -c1-110 | tail -70; }
 graphbb() { timeout 600 python tools/graph_backbone.py > "$OUT/graph_backbone.txt" 2>&1; tail -5 "$OUT/graph_backbone.txt"; }
+renderprof() { bash tools/collect_profile.sh "$TAG" "surface canonical" > "$OUT/renderprof.log" 2>&1; ls "$OUT" | head -50; }
+secondary() { bash tools/secondary_benchmarks.sh > "$OUT/secondary.txt" 2>&1; cat "$OUT/secondary.txt" | cut -c1-400; }
 for step in "$@"; do echo "== $step"; $step; done

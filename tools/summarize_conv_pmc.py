@@ -15,6 +15,11 @@ N_SIMD = 1024
 
 
 def short(name):
+    import re
+    m = re.match(r"_Z(\d+)", name)  # (rocprofv3 leaves some non-template kernels mangled: _Z19k_splitk_reduce_img12ReduceParams...)
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
     return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
