@@ -413,6 +413,240 @@ __global__ __launch_bounds__(256, 2) void k_modconv_up3(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_modconv_up5 (round 6): k_modconv_up3<false> — the image-fed transposed two-term convolution that stores the raw four phases
+// (intermediate or split-K partials) — for what that kernel is used for since k_modconv_up4 took the filled launches: the 4^2 .. 128^2
+// maps of a batch-1 pass, launches that leave ONE multiplying wave per SIMD.  There k_modconv_up3's chunk is a serial chain (measured
+// per 16-channel chunk, profiles/r06_notes.txt: LDS reads + barrier 0.65 us, + 54 MFMAs 0.58, + DMA 0.30): a buffer_load ... lds costs
+// the issuing wave ~150 clocks and ten of them per chunk are as long as the chunk's MFMAs — with a second workgroup on the CU the other
+// wave multiplies meanwhile, alone nobody does.  Here the workgroup brings its own second wave per SIMD:
+//   * waves 0-3 multiply (k_modconv_up3's tile: wave w = grid rows 2w, 2w + 1, four phases) and never issue a request;
+//   * waves 4-7 request (wave 4 + s: sub-image s of the patch, every fourth weight piece), wait for their requests and meet the others
+//     at the chunk's one barrier: the patch ring holds FOUR chunks, requested three ahead, the weights THREE, requested two ahead, and the
+//     counted wait leaves the chunk's own requests in flight (a request lands ~1 us after its issue: longer than a chunk's MFMAs);
+//   * the A operands of tap q + 1 are read under the MFMAs of tap q; patch rows of 33 items, sub-images padded to whole 1 KB pieces.
+// Same products, the same per-accumulator summation order as k_modconv_up3 (chunk, tap, a_hi*b_lo, a_lo*b_hi, a_hi*b_hi): bit-identical.
+// LDS 3 x 18 432 + 4 x 20 480 = 137 216 B: one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+#define U5_PW 33
+#define U5_SUB 5120
+#define U5_PSZ (4 * U5_SUB)
+#define U5_NP 4
+#define U5_NW 3
+#define U5_LDS (U5_NW * U3_WB + U5_NP * U5_PSZ)
+__global__ __launch_bounds__(512, 2) void k_modconv_up5(ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[U5_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
+    // ---- which tile.  One workgroup per CU: what matters is that the FULL tiles all start in the first round.  The (H + 1) x (W + 1)
+    // grid has a last row / column of its own whenever H % 8 == 0 / W % 32 == 0 — light tiles (3 or 1 of 9 taps) that in row-major tile
+    // order alternate with the full ones and take half of the first round's CUs (512 -> 512 @32^2 -> 64^2: 128 full + 192 light
+    // workgroups on 256 CUs: the full tiles of the second round doubled the launch).  The launch is a 1-D grid; the dispatcher deals
+    // workgroup L to XCD L % 8 as that XCD's (L / 8)-th: every XCD first gets its share of the full tiles, then of the light ones, each
+    // share a contiguous run of (K slice, tile, channel tile) with the channel tile fastest (the tiles of a run meet in one L2).
+    const int tiles_x = (p.GW + WX_TW - 1) / WX_TW, tiles_y = (p.GH + 7) / 8, OT = p.O >> 5, Z = p.N * p.ksplit;
+    const int txf = tiles_x - (p.W % WX_TW == 0 ? 1 : 0), tyf = tiles_y - (p.H % 8 == 0 ? 1 : 0);  // full tile columns / rows
+    int tile, otile, zz;
+    {
+        const int T = gridDim.x, L = blockIdx.x, x = L & 7, m = L >> 3;
+        const int nH = txf * tyf, Th = nH * OT * Z;                       // full items
+        const int cx = T / 8 + (x < T % 8 ? 1 : 0);                       // workgroups of XCD x
+        const int hx = Th / 8 + (x < Th % 8 ? 1 : 0);                     // full items of XCD x ...
+        const int hpre = x * (Th / 8) + (x < Th % 8 ? x : Th % 8);        // ... and before it
+        const int lpre = (x * (T / 8) + (x < T % 8 ? x : T % 8)) - hpre;  // light items before XCD x (every XCD: cx - hx of them)
+        (void)cx;
+        int u;
+        if (m < hx) {
+            u = hpre + m;
+            otile = u % OT; u /= OT;
+            const int th = u % nH;
+            zz = u / nH;
+            tile = (th / txf) * tiles_x + th % txf;
+        } else {
+            u = lpre + (m - hx);
+            otile = u % OT; u /= OT;
+            const int nL = tiles_x * tiles_y - nH;
+            const int tl = u % nL;
+            zz = u / nL;
+            const int ncol = txf < tiles_x ? tiles_y : 0;                 // the light column first (top to bottom), then the light row
+            tile = tl < ncol ? tl * tiles_x + txf : tyf * tiles_x + (tl - ncol);
+        }
+    }
+    const int gy0 = (tile / tiles_x) * 8, gx0 = (tile % tiles_x) * WX_TW;
+    const int o0 = otile * 32;
+    const int n = zz / p.ksplit, kz = zz - n * p.ksplit;
+    const int ic_per = ((p.I + p.ksplit - 1) / p.ksplit + 31) / 32 * 32;
+    const int ic_beg = kz * ic_per, ic_end = (ic_beg + ic_per < p.I) ? ic_beg + ic_per : p.I;
+    const int nch = ic_end > ic_beg ? (ic_end - ic_beg) >> 4 : 0;
+    const int HW = p.H * p.W;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const bool col_edge = gx0 == p.W, row_edge = gy0 == p.H;  // (uniform) the light tiles of the (H + 1) x (W + 1) grid
+    if (loader) {
+        // ---- the requesting waves.  Patch: wave 4 + s owns sub-image s = (hi|lo, k half): 9 x 33 items in five full pieces
+        const int sub_which = wave >> 1, sub_kh = wave & 1;
+        int pvoff[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int it = u * 64 + lane;
+            const int r = it / U5_PW, c = it - r * U5_PW;
+            const int iy = gy0 - 1 + r, ix = gx0 - 1 + c;
+            pvoff[u] = (it < 9 * U5_PW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? ((sub_kh * p.H + iy) * p.W + ix) * 16 : CONV_OOB;
+        }
+        const char* img_base = (const char*)p.ximg + (sub_which ? p.ximg_lo : 0) + (size_t)n * (p.I >> 3) * HW * 16;
+        // Weights: 1152 pieces (hi|lo, tap, k half, o) = 18 requests; wave 4 + s issues requests s, s + 4, ... (the fifth round: s = 0, 1)
+        const int LO = p.O * 9 * p.I * 2;
+        const bool wlds = p.wlayout == P3D_WLAYOUT_UP;
+        int wvoff[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = (wave + 4 * i) * 64 + lane, which = q / 576, rem = q - which * 576;
+            const int tap = rem >> 6, kh = (rem >> 5) & 1, o = rem & 31;
+            wvoff[i] = q >= 1152 ? CONV_OOB : wlds ? q * 16 : (o0 + o < p.O) ? which * LO + (((o0 + o) * 9 + tap) * p.I + 8 * kh) * 2 : CONV_OOB;
+        }
+        const bool five = wave < 2;
+        // chunk >= nch: zero-length resources (zeros into an idle buffer, no traffic, the same request count)
+        auto patch_rsrc = [&](int chunk) {
+            const bool in = chunk < nch;
+            const int ic0 = in ? ic_beg + 16 * chunk : 0;
+            return w3_rsrc(img_base + (size_t)(ic0 >> 3) * HW * 16, in ? 2u * HW * 16u : 0u);
+        };
+        auto weight_rsrc = [&](int chunk) {
+            const bool in = chunk < nch;
+            const int ic0 = in ? ic_beg + 16 * chunk : 0;
+            if (wlds) return w3_rsrc((const char*)p.wh + (size_t)((ic0 >> 4) * (p.O >> 5) + (o0 >> 5)) * U3_WB, in ? (uint32_t)U3_WB : 0u);
+            return w3_rsrc((const char*)p.wh + (size_t)ic0 * 2, in ? (uint32_t)(2 * LO - ic0 * 2) : 0u);
+        };
+        auto patch_chunk = [&](int chunk, int buf) {
+            const i32x4 rp = patch_rsrc(chunk);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) w3_dma16(lds0 + U5_NW * U3_WB + buf * U5_PSZ + wave * U5_SUB + u * 1024, rp, pvoff[u]);
+        };
+        auto weight_chunk = [&](int chunk, int buf) {
+            const i32x4 rw = weight_rsrc(chunk);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < 4 || five) w3_dma16(lds0 + buf * U3_WB + (wave + 4 * i) * 1024, rw, wvoff[i]);
+        };
+        // A request lands ~1 us after it was issued (MI355X_MICROARCH.md: LDS-DMA issued -> landed) — longer than a chunk's 54 MFMAs
+        // (0.7 us): whatever a chunk reads is requested at least a whole chunk before the barrier that publishes it.  Chunk k: the
+        // weights of chunk k + 2 (three buffers), the patch of chunk k + 3 (four); the counted wait leaves exactly this chunk's own
+        // requests (nine or ten) in flight.  Prologue: patch(0), weights(0) must have landed; patch(1), patch(2), weights(1) may fly.
+        patch_chunk(0, 0);
+        weight_chunk(0, 0);
+        patch_chunk(1, 1);
+        patch_chunk(2, 2);
+        weight_chunk(1, 1);
+        if (five) W3_VMWAIT(15); else W3_VMWAIT(14);
+        __builtin_amdgcn_s_barrier();
+        for (int k = 0; k < nch; ++k) {
+            int wb2 = k + 2;
+            wb2 = wb2 - (wb2 / U5_NW) * U5_NW;
+            weight_chunk(k + 2, wb2);
+            patch_chunk(k + 3, (k + 3) & 3);
+            if (five) W3_VMWAIT(10); else W3_VMWAIT(9);
+            __builtin_amdgcn_s_barrier();
+        }
+        W3_VMWAIT(0);  // nothing may land in LDS after this workgroup has given it back
+        return;
+    }
+
+    // ---- the multiplying waves
+    f32x16 acc[4][2];  // [phase = 2 py + px][row of the wave's pair]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][t][r] = 0.0f;
+    const int blane = half * U5_SUB + ((2 * wave) * U5_PW + j) * 16;
+    const int alane = (half * 32 + j) * 16;
+    // (phase, tap, input) of the nine products: input 0 = x[y][x], 1 = x[y][x-1], 2 = x[y-1][x], 3 = x[y-1][x-1] (k_modconv_up3's order)
+    const int PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0}, TP[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}, BO[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+    __builtin_amdgcn_s_barrier();  // (the prologue's)
+    auto run = [&](auto QMc, auto NTc, auto W0c) {
+        constexpr int QM = decltype(QMc)::value, NT = decltype(NTc)::value;
+        constexpr bool W0 = decltype(W0c)::value;
+        constexpr int QF = QM & -QM;  // (lowest valid tap)
+        for (int k = 0; k < nch; ++k) {
+            if (!W0 || wave == 0) {
+                const char* pb = lds + U5_NW * U3_WB + (k & 3) * U5_PSZ + blane;
+                const char* wb = lds + (k - (k / U5_NW) * U5_NW) * U3_WB + alane;
+                // rows 2w, 2w + 1, 2w + 2 of the patch x columns j (dx = -1), j + 1 (dx = 0), hi and lo
+                f16x8 bh[3][2], bl[3][2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        bh[r][c] = *reinterpret_cast<const f16x8*>(pb + (r * U5_PW + c) * 16);
+                        bl[r][c] = *reinterpret_cast<const f16x8*>(pb + 2 * U5_SUB + (r * U5_PW + c) * 16);
+                    }
+                f16x8 ah[2], al[2];
+                int cu = 0;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    if (!((QM >> q) & 1)) continue;
+                    if ((1 << q) == QF) {
+                        ah[0] = *reinterpret_cast<const f16x8*>(wb + TP[q] * 64 * 16);
+                        al[0] = *reinterpret_cast<const f16x8*>(wb + (9 + TP[q]) * 64 * 16);
+                    }
+                    int qn = -1;  // the next valid tap: its weights are read under this tap's MFMAs
+#pragma unroll
+                    for (int z = 8; z > q; --z)
+                        if ((QM >> z) & 1) qn = z;
+                    if (qn >= 0) {
+                        ah[cu ^ 1] = *reinterpret_cast<const f16x8*>(wb + TP[qn] * 64 * 16);
+                        al[cu ^ 1] = *reinterpret_cast<const f16x8*>(wb + (9 + TP[qn]) * 64 * 16);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int r = 1 + t - (BO[q] >> 1), c = 1 - (BO[q] & 1);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu], bl[r][c], acc[PH[q]][t], 0, 0, 0);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cu], bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                        acc[PH[q]][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cu], bh[r][c], acc[PH[q]][t], 0, 0, 0);
+                    }
+                    cu ^= 1;
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    {
+        using std::integral_constant;
+        if (!col_edge && !row_edge) run(integral_constant<int, 0x1FF>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else if (!row_edge) run(integral_constant<int, 0x130>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else if (!col_edge) run(integral_constant<int, 0x1C0>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        else run(integral_constant<int, 0x100>{}, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    }
+    // ---- raw store (k_modconv_up3's): a lane owns both column phases (ox = 2 gx, 2 gx + 1) of its grid point: one 8-byte store per
+    // (row phase, channel), 32 lanes = 256 contiguous bytes; the last grid column (gx = W) has only px = 0: a 4-byte store of its own
+    float* yout = p.y + (p.ksplit > 1 ? (size_t)kz * p.N * p.O * p.OH * p.OW : 0) + (size_t)n * p.O * p.OH * p.OW;
+    const int OHW = p.OH * p.OW;
+    auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, p.O * OHW * 4, CONV_RSRC_FLAGS);
+    const int gx = gx0 + j;
+    const bool edge_tile = gx0 + WX_TW > p.W;  // (uniform) this tile holds the column gx = W
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int gy = gy0 + 2 * wave + t;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const bool row_ok = gy <= p.H - py;
+            const int base = ((o0 + 4 * half) * OHW + (2 * gy + py) * p.OW + 2 * gx + p.tox) * 4;
+            const int off2 = (row_ok && gx < p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
+            const int off1 = (row_ok && gx == p.W && o0 + 4 * half < p.O) ? base : CONV_OOB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ((r & 3) + 8 * (r >> 2)) * OHW * 4;
+                const float v0 = acc[2 * py][t][r] * HX_SPLIT_UNSCALE, v1 = acc[2 * py + 1][t][r] * HX_SPLIT_UNSCALE;
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64((i32x2){__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1)}, ry, off2, so, 0);
+                if (edge_tile) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), ry, off1, so, 0);
+            }
+        }
+    }
+}
+
 // the fused four-phase transposed convolution (see k_modconv_up) on f16 operands
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_modconv_up_h(ConvParams p) {
@@ -560,7 +794,16 @@ void p3d_launch_conv_up(const ConvParams& p, int kind, hipStream_t st) {
         hipLaunchKernelGGL(k_modconv_up3<true>, gf, dim3(256), 0, st, p);
     } else if (kind == 1) {
         dim3 g3(((p.GW + WX_TW - 1) / WX_TW) * ((p.GH + 7) / 8), p.O / 32, p.N * p.ksplit);
-        hipLaunchKernelGGL(k_modconv_up3<false>, g3, dim3(256), 0, st, p);
+        // k_modconv_up5 (one workgroup per CU, deep prefetch) while the launch leaves the chip under-filled anyway: up to two workgroups
+        // per CU in k_modconv_up3's terms; P3D_UP5=0 / 1 in the environment: never / always (tests, A/B runs)
+        const char* e5 = getenv("P3D_UP5");  // (read per call: tests switch it)
+        const int up5 = e5 ? atoi(e5) : -1;
+        const long long wgs = (long long)g3.x * g3.y * g3.z;
+        // ... and a K slice is at least eight chunks: the deep ring's prologue requests three patches and two weight chunks before the first
+        // MFMA — on the four-chunk slices of the 16^2 -> 32^2 layer it costs more than it hides (23.7 against 19.5 us, same lease);
+        // 512 -> 512 @32^2 -> 64^2: 41.5 -> 30.5 us, 512 -> 256 @64^2 -> 128^2: 45.2 -> 42.8
+        if (up5 != 0 && p.O % 32 == 0 && (up5 == 1 || (wgs <= 640 && p.I / p.ksplit >= 128))) hipLaunchKernelGGL(k_modconv_up5, dim3((unsigned)wgs), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(k_modconv_up3<false>, g3, dim3(256), 0, st, p);
     } else {
         dim3 grid(((p.GW + CONV_TW - 1) / CONV_TW) * ((p.GH + CONV_TH - 1) / CONV_TH), (p.O + 63) / 64, p.N * p.ksplit);
         if (p.wh && p.wsplit) hipLaunchKernelGGL(k_modconv_up_h<true>, grid, dim3(256), 0, st, p);

@@ -231,8 +231,10 @@ static bool up4_applies(int N, int I, int O, int H, int W) {
 }
 static int choose_ksplit_up3(int N, int I, int O, int H, int W) {
     long long wgs = (long long)((W + 1 + WX_TW - 1) / WX_TW) * ((H + 1 + 7) / 8) * (O / 32) * N;
+    static const int target_up = getenv("P3D_KSPLIT_TARGET_UP") ? atoi(getenv("P3D_KSPLIT_TARGET_UP")) : 0;  // (A/B runs; 0: the image kernels' target)
+    const int target = target_up > 0 ? target_up : ksplit_target_image();
     int ks = 1;
-    while (ks < 64 && wgs * ks < ksplit_target_image() && I / (ks * 2) >= 16) ks *= 2;
+    while (ks < 64 && wgs * ks < target && I / (ks * 2) >= 16) ks *= 2;
     return ks;
 }
 

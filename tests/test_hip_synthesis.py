@@ -1139,3 +1139,31 @@ def test_fir_pass_on_64_column_tiles_is_bit_identical(hip, monkeypatch, N, I, O,
     flag = ops.conv_domain_flag(x.device)
     ops.modulated_conv2d(x * 3e4, w0, s0, saturated=flag, **dict(kw, clamp=None))
     assert ops.conv_domain_violated(flag)
+
+
+@pytest.mark.parametrize("N,I,O,H", [(1, 512, 512, 32), (1, 512, 256, 64), (2, 64, 96, 24), (1, 512, 512, 8), (1, 48, 32, 33), (3, 32, 64, 16), (1, 512, 512, 4)])
+@pytest.mark.parametrize("layout", [0, 2])
+def test_up5_deep_prefetch_transposed_conv_equals_up3(hip, monkeypatch, N, I, O, H, layout):
+    """Round 6: k_modconv_up5 (the split-K / raw-store transposed convolution for under-filled launches: one workgroup per CU, a ring of
+    four patches, operands of the next chunk prefetched into registers) against k_modconv_up3<false> (P3D_UP5=0): the same image and
+    the same fp32 tensor, bit for bit — full tiles and the light tiles of the last grid row / column (H + 1 = 33, 34, 65 ...), one-chunk
+    and odd chunk counts, batch > 1, both weight layouts, deep and shallow splits."""
+    ops = hip.ops
+    filt = ops.setup_filter([1, 3, 3, 1]).cuda()
+    g = torch.Generator().manual_seed(I * 3 + O + H)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    x, w0 = rn(N, I, H, H), rn(O, I, 3, 3)
+    s0, s1 = rn(N, I) * 0.4 + 1.0, rn(N, O) * 0.4 + 1.0
+    d0 = ((w0[None] * s0[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt().contiguous()
+    nz = rn(N, 1, 2 * H, 2 * H) * 0.1 if N > 1 else rn(2 * H, 2 * H) * 0.1
+    if layout and ops.conv_weight_layout(I, O, H, 2) != layout:
+        pytest.skip("the library keeps this shape on the OIK layout")
+    kw = dict(up=2, padding=1, resample_filter=filt, demodulate=True, bias=rn(O) * 0.1, act="lrelu", dcoef=d0, noise=nz,
+              weight_f16=ops.conv_weights_to_f16(w0, split=True, layout=layout))
+    monkeypatch.setenv("P3D_UP4", "0")
+    monkeypatch.setenv("P3D_UP3_FUSED", "0")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("P3D_UP5", mode)
+        out[mode] = (ops.modulated_conv2d(x, w0, s0, **kw).clone(), ops.modulated_conv2d(x, w0, s0, next_styles=s1, **kw).data.clone())
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
