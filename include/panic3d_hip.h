@@ -335,6 +335,12 @@ int p3d_torgb_combine_f32(const float* partial, int tiles, int N, int O, int H, 
 int p3d_conv_takes_image(int I, int O, int W, int up);
 size_t p3d_act_image_bytes(int N, int C, int H, int W);
 int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int H, int W, void* img, uint32_t* saturated, void* stream);
+/* (ABI 9) the same fused with the in-place conditioning add that PAniC-3D's SynthesisNetwork.forward applies to x between two blocks
+ * (networks_stylegan2.py:554-560 the resnet "chonk" on the first channels of the 8x8 map, :600-622 `add_4` / `add_shuffle2_4` on the last
+ * quarter): x[:, c0 : c0 + Ca] += add (add [Na][Ca][H][W], Na = 1 or N; c0, Ca multiples of 8), written back to x, and the image of the
+ * updated x — one launch instead of an elementwise add and a conversion pass; the same bits as the two. */
+int p3d_act_to_image_add_f32(float* x, const float* styles, int N, int C, int H, int W, const float* add, int c0, int Ca, int Na, void* img,
+                             uint32_t* saturated, void* stream);
 
 /* ToRGBLayer.forward (networks_stylegan2.py:366-380: 1x1 modulated convolution without demodulation + bias [+ clamp]) fused with
  * the skip connection of SynthesisBlock.forward (:476-478: img = upsample2d(img) + y) — ONE launch that reads the activation

@@ -83,6 +83,7 @@ SIGNATURES = {
     "p3d_conv_takes_image": (_I, [_I, _I, _I, _I]),
     "p3d_act_image_bytes": (_Z, [_I, _I, _I, _I]),
     "p3d_act_to_image_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "p3d_act_to_image_add_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "p3d_conv_fuses_torgb": (_I, [_I, _I, _I, _I, _I, _I]),
     "p3d_conv_weight_layout": (_I, [_I, _I, _I, _I]),
     "p3d_conv_weights_to_f16x2_layout": (_I, [_P, _I, _I, _I, _I, _P, _P]),

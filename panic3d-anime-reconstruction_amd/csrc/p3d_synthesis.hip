@@ -66,6 +66,40 @@ __global__ void k_act_to_image(const float* __restrict__ x, const float* __restr
     if (bad && sat) atomicOr(sat, 1u);
 }
 
+// k_act_to_image fused with the in-place conditioning add of SynthesisNetwork.forward (networks_stylegan2.py:554-560, :600-622:
+// `x[:, c0 : c0 + Ca] += t` between two blocks): x <- x + add on the channel range [c0, c0 + Ca) (Ca, c0 multiples of 8; add [Na][Ca][HW],
+// Na = 1: shared by the batch), written back, and the image of the UPDATED x for the next block's conv0 — one launch where the
+// conditioned generator ran an elementwise add and a conversion pass per block (round 6).  Same arithmetic, same bits.
+__global__ void k_act_to_image_add(float* __restrict__ x, const float* __restrict__ s, int N, int C, int HW, const float* __restrict__ add,
+                                   int c0, int Ca, int Na, char* __restrict__ img, long long lo_off, unsigned int* sat) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x, total = (long long)N * (C >> 3) * HW;
+    if (idx >= total) return;
+    const long long g = idx / HW;  // (n, c8)
+    const int pix = (int)(idx - g * HW);
+    const int n = (int)(g / (C >> 3)), ch0 = (int)(g - (long long)n * (C >> 3)) * 8;
+    float* xp = x + g * 8 * HW + pix;
+    const bool in = ch0 >= c0 && ch0 < c0 + Ca;  // (whole groups: c0 % 8 == Ca % 8 == 0)
+    const float* ap = add + ((size_t)(Na > 1 ? n : 0) * Ca + (in ? ch0 - c0 : 0)) * HW + pix;
+    f16x8 v, l;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float xv = xp[(size_t)i * HW];
+        if (in) {
+            xv = xv + ap[(size_t)i * HW];
+            xp[(size_t)i * HW] = xv;
+        }
+        float m = (s ? s[g * 8 + i] : 1.0f) * xv * HX_SPLIT_SCALE_X;
+        bad = bad || !(__builtin_fabsf(m) <= 65504.0f);
+        m = __builtin_fminf(__builtin_fmaxf(m, -65504.0f), 65504.0f);
+        v[i] = (_Float16)m;
+        l[i] = (_Float16)(m - (float)v[i]);
+    }
+    *reinterpret_cast<f16x8*>(img + idx * 16) = v;
+    *reinterpret_cast<f16x8*>(img + lo_off + idx * 16) = l;
+    if (bad && sat) atomicOr(sat, 1u);
+}
+
 // sum the split-K partials in slice order (deterministic) and apply the epilogue.  part [KS][N][O][OH][OW]
 struct ReduceParams {
     const float* part; float* y; const float* dcoef; const float* noise; const float* bias;
@@ -511,6 +545,16 @@ int p3d_act_to_image_f32(const float* x, const float* styles, int N, int C, int 
     const long long total = (long long)N * (C / 8) * H * W;
     hipLaunchKernelGGL(k_act_to_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, styles, N, C, H * W,
                        (char*)img, (long long)N * C * H * W * 2, (unsigned int*)saturated);
+    return chk();
+}
+
+int p3d_act_to_image_add_f32(float* x, const float* styles, int N, int C, int H, int W, const float* add, int c0, int Ca, int Na, void* img,
+                             uint32_t* saturated, void* stream) {
+    if (!x || !img || !add || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Ca <= 0 || c0 < 0 || (Na != 1 && Na != N)) return P3D_E_ARG;
+    if (C % 8 != 0 || c0 % 8 != 0 || Ca % 8 != 0 || c0 + Ca > C || ((uintptr_t)img & 15)) return P3D_E_RANGE;
+    const long long total = (long long)N * (C / 8) * H * W;
+    hipLaunchKernelGGL(k_act_to_image_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, styles, N, C, H * W, add,
+                       c0, Ca, Na, (char*)img, (long long)N * C * H * W * 2, (unsigned int*)saturated);
     return chk();
 }
 

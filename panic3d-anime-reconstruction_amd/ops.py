@@ -826,6 +826,22 @@ def act_to_image(x, styles=None, saturated=None):
     return img
 
 
+def act_to_image_add(x, styles, add, c0, saturated=None):
+    """p3d_act_to_image_add_f32: `x[:, c0 : c0 + add.shape[1]] += add` IN PLACE (add [1 or N, Ca, H, W]) and the ActImage of the updated
+    x for a consumer with `styles` — the conditioning add between two synthesis blocks and the conversion pass in one launch."""
+    if not (isinstance(x, torch.Tensor) and x.is_contiguous()):
+        raise RuntimeError("act_to_image_add: x is updated in place and must be contiguous")
+    x, styles, add = _chk(x, "x"), _chk(styles, "styles"), _chk(add, "add")
+    N, C, H, W = x.shape
+    if add.ndim != 4 or tuple(add.shape[2:]) != (H, W) or add.shape[0] not in (1, N) or tuple(styles.shape) != (N, C):
+        raise RuntimeError("act_to_image_add: x [N,C,H,W], styles [N,C], add [1|N,Ca,H,W]")
+    img = ActImage.empty(N, C, H, W, x.device)
+    with _on(x.device):
+        _lib.check(_lib.lib().p3d_act_to_image_add_f32(_p(x), _p(styles), N, C, H, W, _p(add), int(c0), int(add.shape[1]), int(add.shape[0]),
+                                                       _p(img.data), _p(saturated), _stream()), "p3d_act_to_image_add_f32")
+    return img
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True,
                      bias=None, act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None,
                      next_styles=None, rgb_weight=None, rgb_styles=None, want_y=True):

@@ -617,16 +617,34 @@ class SynthesisNetwork(_CacheFree):
         self.__dict__.pop("_noise_pool", None)
         return super()._apply(fn)
 
-    def _condition(self, lvl, res, x, img, cond, cm, chonkadd):
+    def _condition(self, lvl, res, x, img, cond, cm, chonkadd, image_styles=None, flag=None):
         """x, img: the block's FRESH outputs — owned by this call, written in place below.  (Inference only: under autograd, or if a
-        caller ever aliased a block output, the in-place adds would be visible through the alias; the blocks return new tensors.)"""
+        caller ever aliased a block output, the in-place adds would be visible through the alias; the blocks return new tensors.)
+        image_styles: the styles of the next block's conv0 when that layer stages from an activation image — where the level's only
+        edit of x is ONE in-place add (the resnet chonk, `add_4`, `add_shuffle2_4`: the released model's modes) the add and the image
+        of the edited x come from one launch (ops.act_to_image_add) and the image is returned as the third value (else None)."""
+        x, img = self._condition_impl(lvl, res, x, img, cond, cm, chonkadd, image_styles, flag)
+        ximg = self.__dict__.pop("_cond_image", None)
+        return x, img, ximg
+
+    def _add_to(self, x, t, c0, image_styles, flag, fuse):
+        """x[:, c0 : c0 + C_t] += t, with the next conv0's image from the same launch where asked for and possible."""
+        if fuse and image_styles is not None and x.is_contiguous() and x.dtype == torch.float32 and t.dtype == torch.float32 \
+                and c0 % 8 == 0 and t.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and t.shape[0] in (1, x.shape[0]) and tuple(t.shape[2:]) == tuple(x.shape[2:]):
+            self.__dict__["_cond_image"] = ops.act_to_image_add(x, image_styles, t, c0, saturated=flag)
+        else:
+            x[:, c0:c0 + t.shape[1]].add_(t)
+
+    def _condition_impl(self, lvl, res, x, img, cond, cm, chonkadd, image_styles, flag):
+        self.__dict__.pop("_cond_image", None)
         if self.cond_mode == "none":
             return x, img
         assert not (torch.is_grad_enabled() and (x.requires_grad or img.requires_grad)), "inference only: the conditioning is applied in place"
         if res == 8 and chonkadd > 0:  # resnet "chonk" added to the first channels of the 8x8 activations (:554-560)
             k = chonkadd
             chonk = cond["resnet_chonk"]
-            x[:, :k].add_(self._cond_prepared(("chonk", k), [chonk], lambda: chonk[:, :k].to(x.dtype).clone()))  # (a copy: an address that outlives the subject)
+            t = self._cond_prepared(("chonk", k), [chonk], lambda: chonk[:, :k].to(x.dtype).clone())  # (a copy: an address that outlives the subject)
+            self._add_to(x, t, 0, image_styles, flag, True)
             return x, img
         interp = torch.nn.functional.interpolate
         if self.cond_mode.startswith("ortho_front."):
@@ -658,9 +676,11 @@ class SynthesisNetwork(_CacheFree):
                     return t.repeat(1, int((x.shape[1] / 4) // t.shape[1]), 1, 1).contiguous()
                 return self._cond_prepared((tag, lvl, tuple(x.shape[1:]), unshuffle), srcs, make)
 
+            # (one add and nothing else that edits x at this level: the add may carry the next conv0's image along)
+            only_add = ("add_4" in cm) != ("add_shuffle2_4" in cm) and not ({"concatfront", "mult_shuffle2_4", "crossavg_4", "crossavgt_38"} & cm)
             if "add_4" in cm:
                 t = resized("add_4")
-                x[:, -t.shape[1]:].add_(t)
+                self._add_to(x, t, x.shape[1] - t.shape[1], image_styles, flag, only_add)
             if "concatfront" in cm:
                 t = self._cond_prepared(("concatfront", lvl, tuple(x.shape[2:])), srcs,
                                         lambda: interp(self._cond_prepared("cimg", srcs, make_cimg), size=x.shape[-2:], mode="bilinear"))
@@ -668,7 +688,7 @@ class SynthesisNetwork(_CacheFree):
             if "add_shuffle2_4" in cm or "mult_shuffle2_4" in cm:
                 t = resized("shuffle2_4", unshuffle=not (lvl < len(self.block_resolutions) - 2))
                 if "add_shuffle2_4" in cm:
-                    x[:, -t.shape[1]:].add_(t)
+                    self._add_to(x, t, x.shape[1] - t.shape[1], image_styles, flag, only_add)
                 else:
                     x[:, -t.shape[1]:].mul_(t)
             if "inj_6b_4" in cm and res == self.block_resolutions[-1]:
@@ -721,11 +741,17 @@ class SynthesisNetwork(_CacheFree):
             # conv1 of this block writes its result also as the image the next block's conv0 stages from (no conversion pass in
             # front of that layer) — unless something between the blocks edits x: the conditioning of this level, a latent injection
             nxt = getattr(self, f"b{self.block_resolutions[lvl + 1]}") if lvl + 1 < len(self.block_resolutions) else None
-            x_untouched = self.cond_mode == "none" and not (latent_injection is not None and f"da_{lvl}" in latent_injection)
-            ns = _next_conv0_styles(nxt, pre.get(f"b{self.block_resolutions[lvl + 1]}") if nxt is not None else None, res) if x_untouched else None
+            injected = latent_injection is not None and f"da_{lvl}" in latent_injection
+            x_untouched = self.cond_mode == "none" and not injected
+            ns_any = _next_conv0_styles(nxt, pre.get(f"b{self.block_resolutions[lvl + 1]}") if nxt is not None else None, res) if not injected else None
+            ns = ns_any if x_untouched else None
             out = getattr(self, f"b{res}")(x, img, cur_ws, pre=pre[f"b{res}"], x_image=x_image, next_styles=ns, **block_kwargs)
             x, img, x_image = out if ns is not None else (out[0], out[1], None)
-            x, img = self._condition(lvl, res, x, img, cond, cm, chonk)
+            # a conditioned level edits x between the blocks: the edit (where it is one in-place add) writes the next conv0's image itself
+            x, img, cimg = self._condition(lvl, res, x, img, cond, cm, chonk, image_styles=None if x_untouched else ns_any,
+                                           flag=_domain_flag(nxt._modules["conv0"], x.device) if (nxt is not None and not x_untouched) else None)
+            if cimg is not None:
+                x_image = cimg
             x, img = x.contiguous(), img.contiguous()
             ximgs.append((x, img))
             if latent_injection is not None:

@@ -59,6 +59,10 @@ def install(monkeypatch, ops):
     def act_to_image(x, styles=None, saturated=None):
         return ActImage(x if styles is None else x * styles[:, :, None, None], x.shape)
 
+    def act_to_image_add(x, styles, add, c0, saturated=None):
+        x[:, c0:c0 + add.shape[1]].add_(add)
+        return ActImage(x * styles[:, :, None, None], x.shape)
+
     def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_filter=None, demodulate=True, bias=None,
                          act="linear", gain=None, clamp=None, weight_f16=None, dcoef=None, saturated=None, next_styles=None):
         """networks_stylegan2.py:40-97 in its non-fused form (:76-85: shared weights, x * styles in, * dcoefs out) + the bias_act of
@@ -101,7 +105,7 @@ def install(monkeypatch, ops):
             out[o_off:o_off + N * O] = (s.square() @ w2.t() + 1e-8).rsqrt().reshape(-1)
         return out
 
-    for name, fn in dict(act_to_image=act_to_image, modulated_conv2d=modulated_conv2d, torgb=torgb, demod_coefs=demod_coefs,
+    for name, fn in dict(act_to_image=act_to_image, act_to_image_add=act_to_image_add, modulated_conv2d=modulated_conv2d, torgb=torgb, demod_coefs=demod_coefs,
                          torgb_weights=lambda w: w.to(torch.float32), bias_act=bias_act, upsample2d=upsample2d, upsample2d_add=upsample2d_add,
                          conv_weight_layout=lambda I, O, W, up: 0,
                          conv_weights_to_f16=lambda w, split=False, layout=0: torch.zeros((2,) + (w.shape[0], w.shape[2] * w.shape[3], w.shape[1]) if split

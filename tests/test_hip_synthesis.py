@@ -1167,3 +1167,37 @@ def test_up5_deep_prefetch_transposed_conv_equals_up3(hip, monkeypatch, N, I, O,
         monkeypatch.setenv("P3D_UP5", mode)
         out[mode] = (ops.modulated_conv2d(x, w0, s0, **kw).clone(), ops.modulated_conv2d(x, w0, s0, next_styles=s1, **kw).data.clone())
     assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+
+
+def test_conditioning_add_with_the_next_image_in_one_launch(hip, monkeypatch):
+    """Round 6: a conditioned SynthesisNetwork (the released model's mode: resnet chonk at 8^2, `add_shuffle2_4` elsewhere) edits x between
+    two blocks; ops.act_to_image_add does that in-place add and the next conv0's activation image in one launch.  (1) the op against
+    `x[:, c0:c0+Ca] += t` followed by act_to_image: the same x and the same image, bit for bit, shared and per-sample terms; (2) a
+    conditioned network takes it at every level and its planes do not change by a bit when the hand-over is switched off."""
+    ops, sg = hip.ops, hip.stylegan2
+    torch.manual_seed(7)
+    d = torch.device("cuda")
+    for N, C, H, c0, Ca, Na in ((2, 64, 16, 48, 16, 2), (1, 512, 8, 0, 64, 1), (3, 32, 20, 24, 8, 1)):
+        x, s, t = torch.randn(N, C, H, H, device=d), torch.randn(N, C, device=d), torch.randn(Na, Ca, H, H, device=d)
+        x1 = x.clone()
+        x1[:, c0:c0 + Ca].add_(t)
+        ref = ops.act_to_image(x1, s)
+        x2 = x.clone()
+        got = ops.act_to_image_add(x2, s, t, c0)
+        assert torch.equal(x2, x1) and torch.equal(got.data, ref.data)
+    with pytest.raises(RuntimeError):
+        ops.act_to_image_add(torch.randn(1, 16, 8, 8, device=d)[:, :, ::2], torch.randn(1, 16, device=d), torch.randn(1, 8, 4, 8, device=d), 0)
+    net = sg.SynthesisNetwork(w_dim=512, img_resolution=64, img_channels=96, cond_mode="ortho_front.add_shuffle2_4.inj_6b_4.reschonk_add_64",
+                              channel_base=8192, channel_max=128, num_fp16_res=0).cuda()
+    ws = torch.randn(1, net.num_ws, 512, device=d)
+    cond = {"image_ortho_front": torch.rand(1, 4, 64, 64, device=d), "resnet_chonk": torch.randn(1, 128, 8, 8, device=d)}
+    calls = []
+    real = ops.act_to_image_add
+    monkeypatch.setattr(ops, "act_to_image_add", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        a = net(ws, cond, noise_mode="const")
+        n_fused = len(calls)
+        monkeypatch.setattr(sg, "CONV_IMG", False)
+        net.clear_cond_cache()
+        b = net(ws, cond, noise_mode="const")
+    assert n_fused >= 3 and len(calls) == n_fused and torch.equal(a, b), n_fused
