@@ -11,6 +11,12 @@
 //   ./synthesis_c_abi <dir>   reads  <dir>/{meta.txt,x.bin,w.bin,styles.bin,noise.bin,bias.bin,fir.bin,wrgb.bin,srgb.bin,brgb.bin,skip.bin}
 //                             writes <dir>/{y.bin,img.bin}
 // meta.txt: N I O H W up ORGB          (ORGB <= 96 image channels; skip is [N][ORGB][H*up/2][W*up/2])
+//   ./synthesis_c_abi <dir> ride     the ABI-9 path of a super-resolution block's tail (superresolution.py:277-293): the input as an activation
+//                             image (p3d_act_to_image_f32), the weights in the layout the library asks for (p3d_conv_weight_layout +
+//                             p3d_conv_weights_to_f16x2_layout), conv1 with the block's 3-channel ToRGB riding on its launch (p3d_conv_args.rgb_*,
+//                             no fp32 activation written), p3d_torgb_combine_f32 with bias and skip image.  Reads <dir>/{meta.txt (N I O H W),
+//                             x.bin, w.bin, styles.bin, dcoef.bin, noise.bin, bias.bin, fir.bin, wrgb.bin [3][O], srgb.bin, brgb.bin,
+//                             skip.bin [N][3][H/2][W/2]}, writes <dir>/rgb.bin
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdio>
@@ -76,12 +82,68 @@ static int layouts_agree() {
     return 1;
 }
 
+// conv1 of a block with <= 4 image channels the way the super-resolution runs it (ABI 9)
+static int ride(const std::string& dir) {
+    int N, I, O, H, W;
+    FILE* m = std::fopen((dir + "meta.txt").c_str(), "r");
+    if (!m || std::fscanf(m, "%d %d %d %d %d", &N, &I, &O, &H, &W) != 5) { std::fprintf(stderr, "bad meta.txt\n"); return 1; }
+    std::fclose(m);
+    const int R = 3;
+    if (!p3d_conv_takes_image(I, O, W, 1) || !p3d_conv_fuses_torgb(N, I, O, H, W, R)) { std::fprintf(stderr, "the library does not take the ToRGB along for this shape\n"); return 8; }
+    float* x = upload(read_f32(dir + "x.bin", (size_t)N * I * H * W));
+    float* w = upload(read_f32(dir + "w.bin", (size_t)O * I * 9));
+    float* styles = upload(read_f32(dir + "styles.bin", (size_t)N * I));
+    float* dcoef = upload(read_f32(dir + "dcoef.bin", (size_t)N * O));
+    float* noise = upload(read_f32(dir + "noise.bin", (size_t)H * W));
+    float* bias = upload(read_f32(dir + "bias.bin", O));
+    float* fir = upload(read_f32(dir + "fir.bin", 16));
+    float* wrgb = upload(read_f32(dir + "wrgb.bin", (size_t)R * O));
+    float* srgb = upload(read_f32(dir + "srgb.bin", (size_t)N * O));
+    float* brgb = upload(read_f32(dir + "brgb.bin", R));
+    float* skip = upload(read_f32(dir + "skip.bin", (size_t)N * R * (H / 2) * (W / 2)));
+    hipStream_t st;
+    CHECK_HIP(hipStreamCreate(&st));
+    void *w16, *ximg, *ws; float *part, *rgb; uint32_t* sat;
+    CHECK_HIP(hipMalloc(&w16, (size_t)2 * O * 9 * I * 2));
+    CHECK_HIP(hipMalloc(&ximg, p3d_act_image_bytes(N, I, H, W)));
+    CHECK_HIP(hipMalloc((void**)&part, p3d_torgb_partial_bytes(N, O, H, W, R)));
+    CHECK_HIP(hipMalloc((void**)&rgb, (size_t)N * R * H * W * 4));
+    CHECK_HIP(hipMalloc((void**)&sat, 4));
+    CHECK_HIP(hipMemsetAsync(sat, 0, 4, st));
+    const size_t wsb = p3d_modconv2d_workspace_bytes(N, I, O, H, W, 1);
+    CHECK_HIP(hipMalloc(&ws, wsb));
+    const int layout = p3d_conv_weight_layout(I, O, W, 1);  // the layout THIS layer's dispatch consumes (P3D_WLAYOUT_PLAIN here)
+    CHECK_P3D(p3d_conv_weights_to_f16x2_layout(w, O, I, 3, layout, w16, st));
+    CHECK_P3D(p3d_act_to_image_f32(x, styles, N, I, H, W, ximg, sat, st));  // (in a generator the previous layer writes it: y_img)
+    p3d_conv_args a;
+    a.x = nullptr; a.w = w; a.w_f16 = w16; a.styles = nullptr; a.demod_coefs = dcoef; a.noise = noise; a.bias = bias; a.fir = nullptr;
+    a.y = nullptr;  // nobody reads the fp32 activation: ToRGB rides on this launch, the next block would take y_img
+    a.workspace = ws; a.saturated = sat; a.x_img = ximg; a.y_img = nullptr; a.y_img_styles = nullptr;
+    a.rgb_w = wrgb; a.rgb_styles = srgb; a.rgb_partial = part; a.rgb_channels = R; a.w_f16_layout = layout; a.workspace_bytes = wsb;
+    a.N = N; a.I = I; a.H = H; a.W = W; a.O = O; a.ks = 3; a.up = 1; a.demodulate = 1; a.noise_per_sample = 0; a.act = 1; a.mma = P3D_CONV_MMA_F16X2;
+    a.alpha = 0.2f; a.gain = 1.41421356237309515f; a.clamp = -1.0f;
+    CHECK_P3D(p3d_modconv2d_ex_f32(&a, st));
+    CHECK_P3D(p3d_torgb_combine_f32(part, O / 64, N, R, H, W, brgb, -1.0f, skip, fir, rgb, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    uint32_t hsat = 1;
+    CHECK_HIP(hipMemcpy(&hsat, sat, 4, hipMemcpyDeviceToHost));
+    std::vector<float> h((size_t)N * R * H * W);
+    CHECK_HIP(hipMemcpy(h.data(), rgb, h.size() * 4, hipMemcpyDeviceToHost));
+    write_f32(dir + "rgb.bin", h);
+    std::printf("conv1 %d -> %d @%dx%d with ToRGB on its launch, weight layout %d; operand domain flag %u\n", I, O, H, W, layout, hsat);
+    // a copy of the weights in another image layout than the layer's is refused
+    a.w_f16_layout = P3D_WLAYOUT_UP;
+    if (p3d_modconv2d_ex_f32(&a, st) != P3D_E_RANGE) return 4;
+    return hsat == 0 ? 0 : 7;
+}
+
 int main(int argc, char** argv) {
-    if (argc != 2) { std::fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 1; }
+    if (argc != 2 && argc != 3) { std::fprintf(stderr, "usage: %s <dir> [ride]\n", argv[0]); return 1; }
     if (p3d_abi_version() != P3D_ABI_VERSION) { std::fprintf(stderr, "header / library ABI mismatch\n"); return 5; }
     if (!layouts_agree()) { std::fprintf(stderr, "struct layouts of this host and of the library differ\n"); return 6; }
     std::printf("%s: struct layouts agree\n", p3d_build_info());
     const std::string dir = std::string(argv[1]) + "/";
+    if (argc == 3) return ride(dir);
     int N, I, O, H, W, up, ORGB;
     FILE* m = std::fopen((dir + "meta.txt").c_str(), "r");
     if (!m || std::fscanf(m, "%d %d %d %d %d %d %d", &N, &I, &O, &H, &W, &up, &ORGB) != 7) { std::fprintf(stderr, "bad meta.txt\n"); return 1; }

@@ -141,3 +141,53 @@ def test_cpp_host_runs_a_synthesis_layer_and_torgb(tmp_path, up):
     ref = ref * dco[:, :, None, None] + c(noise)[None, None] + c(bias)[None, :, None, None]
     ref = torch.nn.functional.leaky_relu(ref, 0.2) * float(np.sqrt(2))
     assert float((y - ref).abs().max()) <= 3e-6 * np.sqrt(9 * I) * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_cpp_host_runs_conv1_with_torgb_riding_and_the_weight_image_layout(tmp_path):
+    """examples/synthesis_c_abi.cpp `ride` (ABI 9): p3d_conv_weight_layout + p3d_conv_weights_to_f16x2_layout + p3d_act_to_image_f32 +
+    p3d_modconv2d_ex_f32 with rgb_* (no fp32 activation) + p3d_torgb_combine_f32 from C++ on the bytes the Python host
+    (ops.modulated_conv2d(..., rgb_weight=, want_y=False) + ops.torgb_combine, i.e. a super-resolution block's conv1 + ToRGB) gets:
+    the identical image; a weight copy in the wrong image layout is refused."""
+    import torch
+    import panic3d_amd as P
+    g = torch.Generator().manual_seed(91)
+    N, I, O, H, W, R = 1, 32, 128, 256, 256, 3
+    x = torch.randn(N, I, H, W, generator=g)
+    w = torch.randn(O, I, 3, 3, generator=g) / np.sqrt(9 * I)
+    styles = torch.randn(N, I, generator=g) * 0.5 + 1.0
+    noise = torch.randn(H, W, generator=g) * 0.1
+    bias = torch.randn(O, generator=g) * 0.2
+    wrgb = torch.randn(R, O, generator=g)
+    srgb = (torch.randn(N, O, generator=g) * 0.5 + 1.0) / np.sqrt(O)
+    brgb = torch.randn(R, generator=g) * 0.2
+    skip = torch.randn(N, R, H // 2, W // 2, generator=g)
+    dcoef = ((w[None] * styles[:, None, :, None, None]).square().sum(dim=(2, 3, 4)) + 1e-8).rsqrt()
+    filt = P.ops.setup_filter((1, 3, 3, 1))
+    fir = P.ops.prepared_filter(filt.cuda(), torch.device("cuda"), 4.0, False).cpu()
+    d = str(tmp_path)
+    for name, a in (("x", x), ("w", w), ("styles", styles), ("dcoef", dcoef), ("noise", noise), ("bias", bias), ("fir", fir), ("wrgb", wrgb),
+                    ("srgb", srgb), ("brgb", brgb), ("skip", skip)):
+        a.contiguous().numpy().astype(np.float32).tofile(os.path.join(d, name + ".bin"))
+    with open(os.path.join(d, "meta.txt"), "w") as f:
+        f.write(f"{N} {I} {O} {H} {W}")
+    exe = build_example(os.path.join(d, "synthesis_c_abi"), "synthesis_c_abi.cpp")
+    out = subprocess.run([exe, d, "ride"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ToRGB on its launch, weight layout 1" in out.stdout
+    c = lambda t: t.cuda().contiguous()
+    ops = P.ops
+    assert ops.conv_fuses_torgb(N, I, O, H, W, R) and ops.conv_weight_layout(I, O, W, 1) == 1
+    img = ops.act_to_image(c(x), c(styles))
+    y, yi, part = ops.modulated_conv2d(img, c(w), None, noise=c(noise), padding=1, demodulate=True, bias=c(bias), act="lrelu", gain=float(np.sqrt(2)),
+                                       dcoef=c(dcoef), weight_f16=ops.conv_weights_to_f16(c(w), split=True, layout=1), rgb_weight=c(wrgb),
+                                       rgb_styles=c(srgb), want_y=False)
+    ref = ops.torgb_combine(part, bias=c(brgb), skip=c(skip), skip_filter=c(filt))
+    got = np.fromfile(os.path.join(d, "rgb.bin"), dtype=np.float32).reshape(N, R, H, W)
+    assert y is None and np.array_equal(got, ref.cpu().numpy())
+    # and it is the block's conv1 + ToRGB + skip connection in plain torch fp32 (networks_stylegan2.py:334-380, 476-478)
+    xs = c(x) * c(styles)[:, :, None, None]
+    t = torch.nn.functional.conv2d(xs, c(w), padding=1) * c(dcoef)[:, :, None, None] + c(noise)[None, None] + c(bias)[None, :, None, None]
+    t = torch.nn.functional.leaky_relu(t, 0.2) * float(np.sqrt(2))
+    rgbt = torch.einsum("ro,no,nohw->nrhw", c(wrgb), c(srgb), t) + c(brgb)[None, :, None, None] + ops.upsample2d(c(skip), c(filt))
+    assert float((ref - rgbt).abs().max()) <= 2e-5 * float(rgbt.abs().max())
